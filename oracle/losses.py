@@ -1,0 +1,80 @@
+"""Oracle: losses on the path.  Test infrastructure only (see oracle/__init__.py)."""
+import torch
+import torch.nn.functional as F
+
+
+def tv_plane(x):
+    """Reference model/loss/loss.py:14-22 for one (1,C,H,W) tensor."""
+    b, c, h, w = x.shape
+    cnt_h = c * (h - 1) * w + 1e-4
+    cnt_w = c * h * (w - 1) + 1e-4
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum()
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum()
+    return 2 * (h_tv / cnt_h + w_tv / cnt_w) / b
+
+
+def total_tv(P, lambda_density=0.1, lambda_appearance=0.01):
+    """tensoRF.py:248-258,281-290 for the MLP-heads configuration (no semantic/instance grids):
+    planes only, each x1e-2."""
+    d = sum(tv_plane(P[f"density_plane.{i}"]) * 1e-2 for i in range(3))
+    a = sum(tv_plane(P[f"appearance_plane.{i}"]) * 1e-2 for i in range(3))
+    return d * lambda_density + a * lambda_appearance
+
+
+def contrastive(features, labels, temperature):
+    """model/loss/loss.py:62-82.  mask excludes the diagonal; temperature applies to *positive* pairs,
+    1 to negatives; denominator includes the diagonal; rows with p == 0 are dropped, sum / B."""
+    B = features.shape[0]
+    mask = (labels.view(-1, 1) == labels.view(1, -1))
+    mask = mask & ~torch.eye(B, dtype=torch.bool)
+    d2 = ((features[:, None, :] - features[None, :, :]) ** 2).sum(-1)
+    tau = torch.where(mask, torch.full_like(d2, float(temperature)), torch.ones_like(d2))
+    logits = torch.exp(torch.exp(-d2 / tau))
+    p = (logits * mask).sum(-1)
+    Z = logits.sum(-1)
+    prob = p / Z
+    return -(torch.log(prob[prob != 0])).sum() / B
+
+
+def ema_(slow_params, fast_params, momentum=0.9):
+    """trainer/train_panopli_tensorf.py:325-329."""
+    with torch.no_grad():
+        for s, f in zip(slow_params, fast_params):
+            s.mul_(momentum).add_((1 - momentum) * f.detach())
+
+
+def slow_fast(inst_feats, labels, conf):
+    """trainer/train_panopli_tensorf.py:261-309 (use_proj=False); the EMA step (T:258-259) is done by the
+    caller.  inst_feats (B, 2E) = [fast | slow]; first half of the rays is the fast set, second the slow set."""
+    E = inst_feats.shape[-1] // 2
+    fast, slow = inst_feats[:, :E], inst_feats[:, E:].detach()
+    B = labels.shape[0]
+    half = B // 2
+    fm = torch.zeros(B, dtype=torch.bool)
+    fm[:half] = True
+    sm = ~fm
+    fast_labels = torch.unique(labels[fm])
+    slow_labels = torch.unique(labels[sm])
+    if len(fast_labels) == 0 or len(slow_labels) == 0:
+        return torch.tensor(0.0)
+    cents = torch.stack([slow[sm & (labels == l)].mean(0) for l in slow_labels])
+    inter = fast_labels[torch.isin(fast_labels, slow_labels)]
+    loss = 0
+    for l in inter:
+        m_ = fm & (labels == l)
+        c_ = cents[slow_labels == l]
+        d2 = ((fast[m_] - c_) ** 2).sum(-1)
+        loss = loss + -1.0 * (torch.exp(-d2) * conf[m_]).mean()
+    if inter.shape[0] > 0:
+        loss = loss / inter.shape[0]
+    lab = labels[fm][:, None] == labels[sm][None, :]
+    sim = torch.exp(-torch.cdist(fast[fm], slow[sm], p=2))
+    logits = torch.exp(sim)
+    prob = (logits * lab).sum(-1) / logits.sum(-1)
+    return loss + -(torch.log(prob[prob != 0])).mean()
+
+
+def semantic_ce(log_probs, target_probs, conf, class_weight):
+    """CrossEntropyLoss(reduction='none', weight=w) applied to the renderer's log-probabilities with soft
+    targets, times per-pixel confidence, mean (trainer/train_panopli_tensorf.py:75,177-178)."""
+    return (F.cross_entropy(log_probs, target_probs, weight=class_weight, reduction="none") * conf).mean()

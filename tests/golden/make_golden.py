@@ -1,0 +1,413 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only, never copied)
+
+The reference (pure Python/PyTorch) is imported from /root/reference with the third-party packages
+that are absent from this image replaced by inert stand-in modules -- none of them contributes
+arithmetic to the path EXCEPT ``torch_efficient_distloss.eff_distloss`` (requirements.txt:35), which is
+replaced by this repo's restatement of its public formula (oracle/render.py:dist_loss); every fixture
+value that depends on it is stored under a key starting with ``unpinned_``.
+
+Output: small ``.npz`` files next to this script (inputs + the reference's outputs).  They are data, not
+code.  Parameters are NOT stored: both this script and the tests rebuild them with
+``oracle.params.make_params(seed, ...)`` (numpy RNG, bit-reproducible).
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CL_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle import params as op            # noqa: E402
+from oracle import render as orender       # noqa: E402
+
+
+# --------------------------------------------------------------------------- stand-in modules
+class _Inert:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+    def __getattr__(self, n):
+        return _Inert()
+
+
+def _fake(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stand_ins():
+    for n in ["imgviz", "trimesh", "ballpark", "transforms3d", "transforms3d.euler", "transforms3d.axangles",
+              "transforms3d.quaternions", "torchvision", "torchvision.transforms", "torchvision.utils",
+              "pyquaternion", "wandb", "randomname", "hdbscan", "cv2", "h5py", "imageio", "png"]:
+        _fake(n)
+    sys.modules["imgviz"].draw = types.ModuleType("imgviz.draw")
+    sys.modules["ballpark"].business = lambda *a, **k: ""
+    for n, f in (("transforms3d.euler", "euler2mat"), ("transforms3d.axangles", "axangle2mat"),
+                 ("transforms3d.quaternions", "quat2mat")):
+        setattr(sys.modules[n], f, _Inert())
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].ToTensor = _Inert
+    sys.modules["torchvision.utils"].save_image = _Inert()
+    sys.modules["torchvision.utils"].make_grid = _Inert()
+    _fake("torch_efficient_distloss", eff_distloss=lambda w, m, interval: orender.dist_loss(w, m, interval))
+    pl = _fake("pytorch_lightning", LightningModule=torch.nn.Module, seed_everything=torch.manual_seed, Trainer=_Inert)
+    pl.utilities = _fake("pytorch_lightning.utilities", rank_zero_only=lambda f: f)
+    _fake("pytorch_lightning.strategies", DDPStrategy=_Inert)
+    _fake("pytorch_lightning.callbacks", ModelCheckpoint=_Inert)
+    _fake("pytorch_lightning.loggers", TensorBoardLogger=_Inert, WandbLogger=_Inert)
+    _fake("pytorch_lightning.loggers.logger", Logger=type("Logger", (), {"__init__": lambda s, *a, **k: None}),
+          DummyExperiment=_Inert, rank_zero_experiment=lambda f: f)
+    _fake("hydra", main=lambda **k: (lambda f: f))
+    _fake("omegaconf", OmegaConf=_Inert)
+    _fake("torch_scatter", scatter_mean=_Inert())
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+# --------------------------------------------------------------------------- helpers
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def look_at(eye, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
+    """cam2world with +z forward, +x right, +y down (OpenCV), camera at ``eye`` looking at ``target``."""
+    eye = np.asarray(eye, np.float64)
+    f = np.asarray(target, np.float64) - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, np.float64))
+    r /= np.linalg.norm(r)
+    d = np.cross(f, r)
+    M = np.eye(4)
+    M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = r, d, f, eye
+    return torch.tensor(M, dtype=torch.float32)
+
+
+GRAD_STRIDE = 17
+
+
+def grad_digest(prefix, named_grads):
+    """Small tensors in full, big ones as a strided subsample + L2 norm."""
+    out = {}
+    for k, g in named_grads.items():
+        g = torch.zeros(1) if g is None else g.detach().reshape(-1)
+        out[f"{prefix}norm.{k}"] = g.norm()
+        out[f"{prefix}sub.{k}"] = g if g.numel() <= 4096 else g[::GRAD_STRIDE]
+    return out
+
+
+def build_reference_model(P, res, C, E, shift, softmax=True):
+    from model.radiance_field.tensoRF import TensorVMSplit
+    with quiet():
+        m = TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32),
+                          num_semantic_classes=C, dim_feature_instance=2 * E, splus_density_shift=shift,
+                          output_mlp_semantics=(torch.nn.Softmax(dim=-1) if softmax else torch.nn.Identity()),
+                          use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True)
+    missing, unexpected = m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+def build_reference_renderer(aabb, res, mode):
+    from model.renderer.panopli_tensoRF_renderer import TensoRFRenderer
+    with quiet():
+        return TensoRFRenderer(aabb.clone(), list(res), semantic_weight_mode=mode, stop_semantic_grad=True)
+
+
+def make_rays(res_img, K, poses, n_pick, rng):
+    from util.ray import get_ray_directions_with_intrinsics, get_rays, rays_intersect_sphere
+    tables = []
+    for c2w in poses:
+        d = get_ray_directions_with_intrinsics(res_img, res_img, K.numpy())
+        o, dd = get_rays(d, c2w)
+        far = rays_intersect_sphere(o, dd, 1)
+        tables.append(torch.cat([o, dd, 0.01 * torch.ones_like(o[:, :1]), far[:, None]], 1))
+    allr = torch.cat(tables, 0)
+    pick = torch.from_numpy(rng.choice(allr.shape[0], size=n_pick, replace=False))
+    return allr, allr[pick]
+
+
+# --------------------------------------------------------------------------- fixture groups
+def g1_rays():
+    from util.ray import create_grid, get_ray_directions_with_intrinsics, get_rays, rays_intersect_sphere
+    H, W = 6, 9
+    K = np.array([[11.5, 0, 4.25], [0, 12.25, 2.75], [0, 0, 1]], np.float64)
+    c2w = look_at((0.5, -0.3, -0.6))
+    i, j = create_grid(H, W)
+    d = get_ray_directions_with_intrinsics(H, W, K)
+    o, dd = get_rays(d, c2w)
+    far = rays_intersect_sphere(o, dd, 1)
+    npz("g1_rays", H=H, W=W, K=K, c2w=c2w, grid_i=i, grid_j=j, dirs=d, o=o, d=dd, far=far)
+
+
+def g2_sampling():
+    from model.renderer.panopli_tensoRF_renderer import sample_points_in_box
+    rng = np.random.default_rng(21)
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    res = (9, 13, 17)
+    rr = build_reference_renderer(aabb, res, "softmax")
+    K = torch.tensor([[40.0, 0, 16], [0, 40.0, 16], [0, 0, 1]])
+    _, rays = make_rays(32, K, [look_at((0.0, 0.1, -0.9)), look_at((0.7, -0.4, 0.3))], 40, rng)
+    rays[0, 3:6] = torch.tensor([0.0, 0.0, 1.0])      # exact zeros in d -> the 1e-6 substitution (renderer.py:802)
+    rays[1, 0:3] = torch.tensor([0.0, 0.0, 0.0])      # origin inside the box -> t_min clamps to near
+    out = dict(aabb=aabb, res=np.array(res), rays=rays, n_samples=rr.n_samples, step_size=rr.step_size,
+               units=rr.units, inv_box_extent=rr.inv_box_extent)
+    pts, z, m = sample_points_in_box(rays, rr.bbox_aabb, rr.n_samples, rr.step_size, 0, False)
+    out.update(pts0=pts, z0=z, mask0=m, xn0=rr.normalize_coordinates(pts))
+    torch.manual_seed(5)
+    jit = 1.0 * torch.rand(rays.shape[0], 1)          # the draw sample_points_in_box makes (renderer.py:810)
+    torch.manual_seed(5)
+    pts, z, m = sample_points_in_box(rays, rr.bbox_aabb, rr.n_samples, rr.step_size, 1.0, True)
+    out.update(jitter=jit[:, 0], pts1=pts, z1=z, mask1=m)
+    # host scalars at other sizes
+    for tag, (bb, g, ratio) in {"a": ([[-1., -1, -1], [1, 1, 1]], (128, 128, 128), 0.5),
+                                "b": ([[-1., -1, -1], [1, 1, 1]], (192, 192, 192), 0.25),
+                                "c": ([[-0.45, -0.35, -0.25], [0.45, 0.35, 0.25]], (161, 125, 90), 0.5)}.items():
+        r2 = build_reference_renderer(torch.tensor(bb), g, "softmax")
+        r2.update_step_ratio(ratio)
+        out[f"hs_{tag}_aabb"] = torch.tensor(bb)
+        out[f"hs_{tag}_grid"] = np.array(g)
+        out[f"hs_{tag}_ratio"] = ratio
+        out[f"hs_{tag}_n_samples"] = r2.n_samples
+        out[f"hs_{tag}_step_size"] = r2.step_size
+        out[f"hs_{tag}_target_res"] = np.array(r2.get_target_resolution(3_000_000))
+    npz("g2_sampling", **out)
+
+
+def g3_field():
+    from model.radiance_field.tensoRF import MLPRenderFeature
+    res, C, E = (9, 13, 17), 5, 3
+    P = op.make_params(31, res, C, E)
+    m = build_reference_model(P, res, C, E, shift=-10.0)
+    rng = np.random.default_rng(32)
+    xn = torch.from_numpy(rng.uniform(-1, 1, size=(200, 3)).astype(np.float32))
+    xn[0] = torch.tensor([-1.0, -1.0, -1.0])
+    xn[1] = torch.tensor([1.0, 1.0, 1.0])
+    xn[2] = torch.tensor([1.0, -1.0, 0.0])
+    xn[3] = torch.tensor([1.00001, 0.2, -1.00001])     # just outside: zero-padding taps
+    vd = torch.from_numpy(rng.standard_normal((200, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        feat = m.compute_appearance_feature(xn)
+        npz("g3_field", res=np.array(res), C=C, E=E, seed=31, xn=xn, viewdirs=vd,
+            density_raw=m.compute_density_without_activation(xn), density=m.compute_density(xn),
+            app_feat=feat, rgb=m.render_appearance_mlp(vd, feat),
+            sem=m.render_semantic_mlp(None, m.compute_semantic_feature(xn)),
+            inst=m.render_instance_mlp(None, m.compute_instance_feature(xn)),
+            pe=MLPRenderFeature.positional_encoding(torch.tensor([[1.0, 2.0, 3.0]]), 2))
+
+
+def g5_alpha():
+    from model.renderer.panopli_tensoRF_renderer import TensoRFRenderer
+    rng = np.random.default_rng(51)
+    sigma = torch.from_numpy(np.abs(rng.standard_normal((6, 40))).astype(np.float32) * 3)
+    sigma[0, :] = 0
+    sigma[1, 5] = 1e4
+    sigma[2, :] = 4.5e-5
+    dist = torch.full((6, 40), 0.0079 * 25)
+    dist[:, -1] = 0
+    a, w, bg = TensoRFRenderer.raw_to_alpha(sigma, dist)
+    npz("g5_alpha", sigma=sigma, dist=dist, alpha=a, weight=w, bg=bg)
+
+
+def _scene(seed, res, C, E, aabb, n_rays, shift=-3.0):
+    P = op.add_blob(op.make_params(seed, res, C, E), res, amplitude=2.5, sigma_g=0.45)
+    rng = np.random.default_rng(seed + 1)
+    K = torch.tensor([[40.0, 0, 16], [0, 40.0, 16], [0, 0, 1]])
+    poses = [look_at((0.0, 0.1, -0.9)), look_at((0.7, -0.4, 0.3)), look_at((-0.5, 0.6, 0.4))]
+    _, rays = make_rays(32, K, poses, n_rays, rng)
+    return P, rays, rng
+
+
+def g6_forward():
+    res, C, E = (9, 13, 17), 4, 3
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    P, rays, rng = _scene(61, res, C, E, aabb, 96)
+    N = rays.shape[0]
+    jitter = torch.from_numpy(rng.uniform(0, 1, size=(N,)).astype(np.float32))
+    cot = {k: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+           for k, s in (("rgb", (N, 3)), ("sem", (N, C)), ("inst", (N, 2 * E)))}
+    out = dict(res=np.array(res), C=C, E=E, seed=61, shift=-3.0, aabb=aabb, rays=rays, jitter=jitter,
+               cot_rgb=cot["rgb"], cot_sem=cot["sem"], cot_inst=cot["inst"])
+    import model.renderer.panopli_tensoRF_renderer as RR
+    for mode in ("softmax", "none"):
+        for white in (False, True):
+            tag = f"{mode}_{'w' if white else 'b'}"
+            m = build_reference_model(P, res, C, E, shift=-3.0, softmax=(mode == "softmax"))
+            rr = build_reference_renderer(aabb, res, mode)
+            # feed the explicit jitter: the reference draws perturb*torch.rand_like(rng[:, [0]]) on the CPU
+            # generator (renderer.py:810); torch.rand_like is swapped for this one call.  is_train=True
+            # also triggers the random white-bg coin (renderer.py:164); torch.rand is swapped to return 1.0
+            # (=> coin false) so that ``white`` alone decides.
+            real_rl, real_r = RR.torch.rand_like, RR.torch.rand
+            RR.torch.rand_like = lambda t, *a, **k: jitter.view(-1, 1).to(t)
+            RR.torch.rand = lambda *a, **k: torch.ones(1)
+            try:
+                rgb, sem, inst, depth, feats, dreg = rr.forward(m, rays, 1.0, white, True)
+            finally:
+                RR.torch.rand_like, RR.torch.rand = real_rl, real_r
+            L = (rgb * cot["rgb"]).sum() + (sem * cot["sem"]).sum() + (inst * cot["inst"]).sum()
+            L.backward()
+            out.update({f"{tag}.rgb": rgb, f"{tag}.sem": sem, f"{tag}.inst": inst, f"{tag}.depth": depth,
+                        f"{tag}.feats": feats, f"unpinned_{tag}.dist_reg": dreg})
+            out.update(grad_digest(f"{tag}.g", {k: p.grad for k, p in m.named_parameters()}))
+    npz("g6_forward", **out)
+
+
+def g7_instance_segment():
+    res, C, E = (9, 13, 17), 4, 3
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    P, rays, rng = _scene(71, res, C, E, aabb, 64)
+    N = rays.shape[0]
+    m = build_reference_model(P, res, C, E, shift=-3.0)
+    rr = build_reference_renderer(aabb, res, "softmax")
+    cot = torch.from_numpy(rng.standard_normal((N, 2 * E)).astype(np.float32))
+    inst, xyz = rr.forward_instance_feature(m, rays, 0, False)
+    (inst * cot).sum().backward()
+    out = dict(res=np.array(res), C=C, E=E, seed=71, shift=-3.0, aabb=aabb, rays=rays, cot_inst=cot,
+               inst=inst, xyz=xyz)
+    out.update(grad_digest("inst.g", {k: p.grad for k, p in m.named_parameters()}))
+    m.zero_grad(set_to_none=True)
+    cot2 = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32))
+    seg = rr.forward_segment_feature(m, rays, 0, False)
+    (seg * cot2).sum().backward()
+    out.update(cot_seg=cot2, seg=seg)
+    out.update(grad_digest("seg.g", {k: p.grad for k, p in m.named_parameters()}))
+    npz("g7_instance_segment", **out)
+
+
+def g8_losses():
+    from model.loss.loss import contrastive_loss
+    import trainer.train_panopli_tensorf as T
+    rng = np.random.default_rng(81)
+    out = {}
+    # --- contrastive_loss (loss.py:62-82)
+    for tag, B, nlab in (("a", 64, 5), ("b", 2, 1), ("c", 33, 40), ("d", 16, 1)):
+        f = torch.from_numpy(rng.standard_normal((B, 3)).astype(np.float32) * 0.7).requires_grad_(True)
+        y = torch.from_numpy(rng.integers(0, nlab, size=(B,)).astype(np.int64))
+        L = contrastive_loss(f, y, 100.0)
+        g = torch.autograd.grad(L, f, allow_unused=True)[0] if L.requires_grad else None
+        out.update({f"con_{tag}.f": f, f"con_{tag}.y": y, f"con_{tag}.loss": L,
+                    f"con_{tag}.grad": torch.zeros_like(f) if g is None else g})
+    # --- slow-fast (trainer T:256-310), called unbound with a stand-in self
+    E = 3
+    res, C = (5, 6, 7), 2
+    for tag, B, labels in (("a", 128, rng.integers(1, 8, size=128)),
+                           ("b", 64, np.concatenate([rng.integers(1, 4, size=32), rng.integers(3, 7, size=32)])),
+                           ("c", 16, np.ones(16, np.int64)),
+                           ("d", 7, rng.integers(1, 3, size=7))):
+        P = op.make_params(82, res, C, E)
+        m = build_reference_model(P, res, C, E, shift=-10.0)
+        fake = types.SimpleNamespace(
+            instance_loss_mode="slow_fast", model=m, config=types.SimpleNamespace(use_proj=False), device="cpu",
+            ema_update_slownet=lambda s, f, mo: T.TensoRFTrainer.ema_update_slownet(None, s, f, mo),
+            use_delta=False, temperature=100.0)
+        feats = torch.from_numpy(rng.standard_normal((B, 2 * E)).astype(np.float32) * 0.6).requires_grad_(True)
+        y = torch.from_numpy(np.asarray(labels, np.int64))
+        conf = torch.from_numpy(rng.uniform(0.2, 1.0, size=(B,)).astype(np.float32))
+        L = T.TensoRFTrainer.calculate_instance_clustering_loss(fake, y, feats, conf, None)
+        g = torch.autograd.grad(L, feats)[0]
+        out.update({f"sf_{tag}.feats": feats, f"sf_{tag}.y": y, f"sf_{tag}.conf": conf, f"sf_{tag}.loss": L,
+                    f"sf_{tag}.grad": g})
+        if tag == "a":   # slow weights after the one EMA step the loss call performed (T:258-259)
+            out["sf_ema.seed"] = 82
+            out["sf_ema.res"] = np.array(res)
+            for k, v in m.render_instance_mlp.slow_mlp.state_dict().items():
+                out[f"sf_ema.slow.{k}"] = v if v.numel() <= 4096 else v.reshape(-1)[::GRAD_STRIDE]
+    npz("g8_losses", **out)
+
+
+def g9_tv():
+    from model.loss.loss import TVLoss
+    res, C, E = (9, 13, 17), 2, 3
+    P = op.make_params(91, res, C, E)
+    m = build_reference_model(P, res, C, E, shift=-10.0)
+    tv = TVLoss()
+    out = dict(res=np.array(res), seed=91)
+    x = m.density_plane[1]
+    L = tv(x)
+    out["tv_plane1"] = L
+    out["tv_plane1_grad"] = torch.autograd.grad(L, x)[0]
+    cfg = types.SimpleNamespace(late_semantic_optimization=0, instance_optimization_epoch=0, lambda_tv_density=0.1,
+                                lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02)
+    Lt = m.total_tv_loss(tv, cfg, 1)
+    Lt.backward()
+    out["total_tv"] = Lt
+    out.update(grad_digest("tv.g", {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    npz("g9_tv", **out)
+
+
+def g10_grid_ops():
+    """upsample_volume_grid / shrink / update_bbox_aabb_and_shrink on a small grid (8f rank 1)."""
+    res, C, E = (9, 13, 17), 2, 3
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    P = op.add_blob(op.make_params(101, res, C, E), res, amplitude=2.5, sigma_g=0.3)
+    m = build_reference_model(P, res, C, E, shift=-3.0)
+    rr = build_reference_renderer(aabb, res, "softmax")
+    out = dict(res=np.array(res), seed=101, aabb=aabb, shift=-3.0)
+    with torch.no_grad(), quiet():
+        alpha, dense_xyz = rr.get_dense_alpha(m)
+        out["dense_alpha"] = alpha
+        rr.update_bbox_aabb_and_shrink(m)
+        out["shrunk_aabb"] = rr.bbox_aabb
+        out["shrunk_grid"] = rr.grid_dim
+        out["shrunk_n_samples"] = rr.n_samples
+        out["shrunk_step"] = rr.step_size
+        out["shrunk_density_plane0"] = m.density_plane[0]
+        out["shrunk_density_line0"] = m.density_line[0]
+        out["shrunk_appearance_plane2"] = m.appearance_plane[2][:, ::7]
+        target = rr.get_target_resolution(4000)
+        out["target_res"] = np.array(target)
+        m.upsample_volume_grid(target)
+        rr.update_step_size(target)
+        out["up_density_plane1"] = m.density_plane[1]
+        out["up_density_line2"] = m.density_line[2]
+        out["up_n_samples"] = rr.n_samples
+        out["up_step"] = rr.step_size
+    sched = (torch.round(torch.exp(torch.linspace(np.log(128 ** 3), np.log(192 ** 3), 5))).long()).tolist()[1:]
+    out["voxel_schedule_128_192_4"] = np.array(sched)
+    npz("g10_grid_ops", **out)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit(f"reference not found at {REF}: golden vectors can only be regenerated in the build container")
+    torch.set_num_threads(4)
+    install_stand_ins()
+    g1_rays()
+    g2_sampling()
+    g3_field()
+    g5_alpha()
+    g6_forward()
+    g7_instance_segment()
+    g8_losses()
+    g9_tv()
+    g10_grid_ops()
+
+
+if __name__ == "__main__":
+    main()
