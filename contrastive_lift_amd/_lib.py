@@ -1,0 +1,141 @@
+"""ctypes binding of libclift.so (C ABI declared in include/clift.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is raised.
+``build()`` compiles the library in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclift.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class VM(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3), ("res", C.c_int * 3), ("comps", C.c_int)]
+
+
+class VMGrad(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3)]
+
+
+class March(C.Structure):
+    _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3), ("inv_ext2", C.c_float * 3), ("step_size", C.c_float),
+                ("n_samples", C.c_int), ("distance_scale", C.c_float), ("density_shift", C.c_float),
+                ("weight_thres", C.c_float)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("a_trans", C.c_int),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("b_trans", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int),
+                ("bias", C.c_void_p), ("act", C.c_int),
+                ("mask", C.c_void_p), ("ldmask", C.c_int),
+                ("accumulate", C.c_int), ("split_k", C.c_int)]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
+_SIGNATURES = {
+    "clift_version": ([], C.c_int),
+    "clift_last_error": ([], C.c_char_p),
+    "clift_gen_rays": ([_I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
+    "clift_density_fwd": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_march_fwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "clift_march_bwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "clift_density_bwd": ([_P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_scan_counts": ([_P, _I, _P, _P], C.c_int),
+    "clift_compact_fill": ([_P, _P, _I, _I, _F, _P, _P], C.c_int),
+    "clift_app_gather_fwd": ([_P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
+    "clift_active_xyz": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P], C.c_int),
+    "clift_app_encode_bwd": ([_P, _I, _I, _I, _P, _I, _I, _P, _I, _P], C.c_int),
+    "clift_gemm": ([_P, _P], C.c_int),
+    "clift_linear_k3_fwd": ([_P, _P, _P, _I, _I, _I, _P, _I, _P], C.c_int),
+    "clift_linear_k3_bwd": ([_P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
+    "clift_colsum": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "clift_rows_act_fwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "clift_rows_act_bwd": ([_P, _I, _P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "clift_composite_fwd": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], C.c_int),
+    "clift_composite_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                             _P, _P, _P], C.c_int),
+    "clift_tv_fwd_bwd": ([_P, _I, _I, _I, _F, _P, _P, _P], C.c_int),
+    "clift_pixel_losses": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
+    "clift_contrastive": ([_P, _P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
+    "clift_slow_fast": ([_P, _P, _P, _I, _I, _P, _P, _P, _P], C.c_int),
+    "clift_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P], C.c_int),
+    "clift_ema": ([_P, _P, _L, _F, _P], C.c_int),
+}
+
+_lib = None
+
+
+class CliftError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> libclift.so for gfx950 (in-tree, so the .so travels with the repo snapshot)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise CliftError("building libclift.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the library and attach signatures.  Raises CliftError if it is missing (no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CliftError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(or `make -C {CSRC}`).  There is no CPU/PyTorch fallback for the render path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    if lib.clift_version() != ABI_VERSION:
+        raise CliftError(f"libclift.so ABI {lib.clift_version()} != binding ABI {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CliftError(f"{name} failed (rc={rc}): {lib.clift_last_error().decode()}")
+
+
+def f32(t, what="tensor"):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise CliftError(f"{what}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
+    return t

@@ -1,0 +1,342 @@
+// gemm.hip -- nn.Linear forward / dgrad / wgrad on the gfx950 matrix cores, fp32 in / fp32 accumulate.
+//
+//   C[m][n] (+)= act( sum_k A(m,k) B(n,k) + bias[n] ) * (mask[m][n] > 0)
+//
+// v_mfma_f32_32x32x2_f32: per wave a 32x32 tile, lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// exact fp32 (bit-identical to an fmaf chain), 64 cycles per instruction per SIMD = 256 FLOP/clk/CU.
+// Block = WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles.  Operand tiles
+// are staged global -> registers -> LDS in k-major order ([k][m], so a fragment read is 32 consecutive
+// floats per half-wave: conflict-free ds_read_b32) with the next k-tile's global loads in flight under the
+// MFMAs of the current one.
+//
+// Used for (reference tensoRF.py): basis Linear :65, appearance MLP :393-397, instance MLPs :475-491,
+// semantic MLP :576-582 -- forward (A = activations, B = weight (out,in)), dgrad (B transposed), wgrad
+// (both transposed, reduction over the sample dimension split over blockIdx.z with atomic accumulation).
+#include "clift_dev.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmP {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias;
+    int act;
+    const float* mask; int ldmask;
+    int accumulate;
+    int k_per_split;
+};
+
+constexpr int BK = 32;
+
+template <bool TR>
+__host__ __device__ constexpr int lds_stride(int cols) { return TR ? cols + 4 : cols + 1; }
+
+// Stage one operand tile (ROWS = BM or BN along m, BK along k) from global into registers.
+//   non-trans: element (m,k) at P[m*ld + k]  -> float4 along k
+//   trans    : element (m,k) at P[k*ld + m]  -> float4 along m
+template <int ROWS, int NT, bool TR>
+struct Stager {
+    static constexpr int NV = (ROWS * BK / 4 + NT - 1) / NT;  // float4 per thread
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int m0, int mlim, int k0, int klim, int tid) {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int e = tid + p * NT;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < ROWS * BK / 4) {
+                if (!TR) {
+                    const int m = m0 + e / (BK / 4), k = k0 + (e % (BK / 4)) * 4;
+                    if (m < mlim) {
+                        const float* q = P + (size_t)m * ld + k;
+                        if (k + 3 < klim) x = *reinterpret_cast<const float4*>(q);
+                        else {
+                            if (k < klim) x.x = q[0];
+                            if (k + 1 < klim) x.y = q[1];
+                            if (k + 2 < klim) x.z = q[2];
+                        }
+                    }
+                } else {
+                    const int k = k0 + e / (ROWS / 4), m = m0 + (e % (ROWS / 4)) * 4;
+                    if (k < klim) {
+                        const float* q = P + (size_t)k * ld + m;
+                        if (m + 3 < mlim) x = *reinterpret_cast<const float4*>(q);
+                        else {
+                            if (m < mlim) x.x = q[0];
+                            if (m + 1 < mlim) x.y = q[1];
+                            if (m + 2 < mlim) x.z = q[2];
+                        }
+                    }
+                }
+            }
+            v[p] = x;
+        }
+    }
+    // LDS image: [k][m] with row stride lds_stride<TR>(ROWS)
+    __device__ __forceinline__ void store(float* __restrict__ L, int tid) const {
+        constexpr int LS = lds_stride<TR>(ROWS);
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int e = tid + p * NT;
+            if (e < ROWS * BK / 4) {
+                if (!TR) {
+                    const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+                    L[(k + 0) * LS + m] = v[p].x; L[(k + 1) * LS + m] = v[p].y;
+                    L[(k + 2) * LS + m] = v[p].z; L[(k + 3) * LS + m] = v[p].w;
+                } else {
+                    const int k = e / (ROWS / 4), m = (e % (ROWS / 4)) * 4;
+                    *reinterpret_cast<float4*>(L + k * LS + m) = v[p];
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool AT, bool BT>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmP g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LSA = lds_stride<AT>(BM), LSB = lds_stride<BT>(BN);
+    __shared__ __attribute__((aligned(16))) float lds[BK * LSA + BK * LSB];
+    float* As = lds;
+    float* Bs = lds + BK * LSA;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntn = (g.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    Stager<BM, NT, AT> sa;
+    Stager<BN, NT, BT> sb;
+    sa.load(g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            sa.load(g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
+            sb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
+        }
+        const float* ap = As + lh * LSA + wm * (BM / WM) + li;
+        const float* bp = Bs + lh * LSB + wn * (BN / WN) + li;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = ap[kk * LSA + t * 32];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = bp[kk * LSB + t * 32];
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int n = n0 + wn * (BN / WN) + y * 32 + li;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= g.M) continue;
+                float v = acc[x][y][r] + bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
+                float* c = g.C + (size_t)m * g.ldc + n;
+                if (g.accumulate) unsafeAtomicAdd(c, v);
+                else *c = v;
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st) {
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
+    const dim3 block(WM * WN * 64);
+    if (!a_trans && !b_trans) k_gemm<BM, BN, WM, WN, false, false><<<grid, block, 0, st>>>(p);
+    else if (!a_trans && b_trans) k_gemm<BM, BN, WM, WN, false, true><<<grid, block, 0, st>>>(p);
+    else if (a_trans && b_trans) k_gemm<BM, BN, WM, WN, true, true><<<grid, block, 0, st>>>(p);
+    else k_gemm<BM, BN, WM, WN, true, false><<<grid, block, 0, st>>>(p);
+    return clift_check_launch("clift_gemm");
+}
+
+extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
+    CLIFT_REQUIRE(h->M >= 0 && h->N >= 0 && h->K >= 0, "clift_gemm: negative dimension");
+    if (h->M == 0 || h->N == 0) return 0;
+    CLIFT_REQUIRE(h->lda % 4 == 0 && h->ldb % 4 == 0, "clift_gemm: lda/ldb must be multiples of 4 (got %d, %d)", h->lda, h->ldb);
+    CLIFT_REQUIRE(((uintptr_t)h->A & 15) == 0 && ((uintptr_t)h->B & 15) == 0, "clift_gemm: A/B must be 16-byte aligned");
+    int splits = h->split_k > 1 ? h->split_k : 1;
+    CLIFT_REQUIRE(splits == 1 || h->accumulate, "clift_gemm: split_k > 1 requires accumulate");
+    CLIFT_REQUIRE(splits == 1 || (!h->bias && !h->act && !h->mask), "clift_gemm: split_k > 1 excludes bias/act/mask");
+    GemmP p;
+    p.M = h->M; p.N = h->N; p.K = h->K;
+    p.A = h->A; p.lda = h->lda; p.B = h->B; p.ldb = h->ldb; p.C = h->C; p.ldc = h->ldc;
+    p.bias = h->bias; p.act = h->act; p.mask = h->mask; p.ldmask = h->ldmask; p.accumulate = h->accumulate;
+    int kper = cdiv(cdiv(h->K, splits), BK) * BK;
+    if (kper < BK) kper = BK;
+    splits = cdiv(h->K, kper);
+    if (splits < 1) splits = 1;
+    p.k_per_split = kper;
+    hipStream_t st = as_stream(s);
+    if (h->N > 128) return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
+    if (h->N > 32) return launch_gemm<128, 128, 2, 2>(p, h->a_trans, h->b_trans, splits, st);
+    return launch_gemm<256, 32, 4, 1>(p, h->a_trans, h->b_trans, splits, st);
+}
+
+// ============================================================================ K = 3 first layers
+// out[m][n] = act(W[n][0] x + W[n][1] y + W[n][2] z + b[n]); pure store-bandwidth kernel (tensoRF.py:475,576).
+__global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W,
+                                                        const float* __restrict__ b, int M, int Nout, int relu,
+                                                        float* __restrict__ out, int ldo) {
+    const int nq = Nout / 4;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)M * nq) return;
+    const int m = (int)(gid / nq), n = (int)(gid % nq) * 4;
+    const float4 x = ld4(x4 + (size_t)m * 4);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* w = W + (size_t)(n + j) * 3;
+        float v = fmaf(w[2], x.z, fmaf(w[1], x.y, fmaf(w[0], x.x, b[n + j])));
+        o[j] = relu ? fmaxf(v, 0.f) : v;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, const float* b, int M, int Nout, int relu, float* out,
+                                   int ldo, clift_stream_t s) {
+    CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
+    if (M <= 0) return 0;
+    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, b, M, Nout, relu, out, ldo);
+    return clift_check_launch("clift_linear_k3_fwd");
+}
+
+// dW[n][0..2] += sum_m dH[m][n] x[m][:], db[n] += sum_m dH[m][n].  Thread = column n, block = slab of rows.
+__global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__ x4, const float* __restrict__ dH, int ldh, int M,
+                                                        int Nout, int rows_per_block, float* __restrict__ dW, float* __restrict__ db) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
+    __shared__ float4 xs[64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int mc = mb; mc < me; mc += 64) {
+        __syncthreads();
+        if (threadIdx.x < 64 && mc + threadIdx.x < me) xs[threadIdx.x] = ld4(x4 + (size_t)(mc + threadIdx.x) * 4);
+        __syncthreads();
+        const int lim = min(64, me - mc);
+        if (n < Nout)
+            for (int j = 0; j < lim; ++j) {
+                const float d = dH[(size_t)(mc + j) * ldh + n];
+                const float4 x = xs[j];
+                a0 = fmaf(d, x.x, a0); a1 = fmaf(d, x.y, a1); a2 = fmaf(d, x.z, a2); a3 += d;
+            }
+    }
+    if (n < Nout) {
+        unsafeAtomicAdd(dW + (size_t)n * 3 + 0, a0);
+        unsafeAtomicAdd(dW + (size_t)n * 3 + 1, a1);
+        unsafeAtomicAdd(dW + (size_t)n * 3 + 2, a2);
+        if (db) unsafeAtomicAdd(db + n, a3);
+    }
+}
+
+extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, float* db,
+                                   clift_stream_t s) {
+    if (M <= 0) return 0;
+    const int rpb = 512;
+    k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 256, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, db);
+    return clift_check_launch("clift_linear_k3_bwd");
+}
+
+// db[n] += sum_m dY[m][n]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, int M, int N, int rows_per_block,
+                                                 float* __restrict__ db) {
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
+    float a = 0.f;
+    for (int m = mb; m < me; ++m) a += dY[(size_t)m * ld + n];
+    unsafeAtomicAdd(db + n, a);
+}
+
+extern "C" int clift_colsum(const float* dY, int ld, int M, int N, float* db, clift_stream_t s) {
+    if (M <= 0 || N <= 0) return 0;
+    const int rpb = 256;
+    k_colsum<<<dim3(cdiv(M, rpb), cdiv(N, 256)), 256, 0, as_stream(s)>>>(dY, ld, M, N, rpb, db);
+    return clift_check_launch("clift_colsum");
+}
+
+// ============================================================================ row activations
+// kind 1: sigmoid (appearance head, tensoRF.py:385,410); kind 2: softmax over the row (semantic head, :37,593).
+__global__ __launch_bounds__(256) void k_rows_act_fwd(const float* __restrict__ pre, int ldp, int M, int C, int kind,
+                                                       float* __restrict__ out, int ldo) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* p = pre + (size_t)m * ldp;
+    float* o = out + (size_t)m * ldo;
+    if (kind == 1) {
+        for (int c = 0; c < C; ++c) o[c] = 1.f / (1.f + expf(-p[c]));
+    } else {
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, p[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(p[c] - mx);
+        const float inv = 1.f / sum;
+        for (int c = 0; c < C; ++c) o[c] = expf(p[c] - mx) * inv;
+    }
+}
+
+extern "C" int clift_rows_act_fwd(const float* pre, int ldp, int M, int C, int kind, float* out, int ldo, clift_stream_t s) {
+    CLIFT_REQUIRE(kind == 1 || kind == 2, "clift_rows_act_fwd: kind must be 1 (sigmoid) or 2 (softmax)");
+    if (M <= 0) return 0;
+    k_rows_act_fwd<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(pre, ldp, M, C, kind, out, ldo);
+    return clift_check_launch("clift_rows_act_fwd");
+}
+
+__global__ __launch_bounds__(256) void k_rows_act_bwd(const float* __restrict__ out, int ldo, const float* __restrict__ dout, int lddo,
+                                                       int M, int C, int kind, float* __restrict__ dpre, int ldd) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* o = out ? out + (size_t)m * ldo : nullptr;
+    const float* g = dout + (size_t)m * lddo;
+    float* d = dpre + (size_t)m * ldd;
+    if (kind == 0) {
+        for (int c = 0; c < C; ++c) d[c] = g[c];
+    } else if (kind == 1) {
+        for (int c = 0; c < C; ++c) d[c] = g[c] * o[c] * (1.f - o[c]);
+    } else {
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf(g[c], o[c], dot);
+        for (int c = 0; c < C; ++c) d[c] = o[c] * (g[c] - dot);
+    }
+    for (int c = C; c < ldd; ++c) d[c] = 0.f;  // keep the alignment padding zero (it is a GEMM K-operand)
+}
+
+extern "C" int clift_rows_act_bwd(const float* out, int ldo, const float* dout, int lddo, int M, int C, int kind, float* dpre,
+                                  int ldd, clift_stream_t s) {
+    CLIFT_REQUIRE(kind >= 0 && kind <= 2, "clift_rows_act_bwd: kind must be 0 (identity), 1 (sigmoid) or 2 (softmax)");
+    if (M <= 0) return 0;
+    k_rows_act_bwd<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(out, ldo, dout, lddo, M, C, kind, dpre, ldd);
+    return clift_check_launch("clift_rows_act_bwd");
+}

@@ -1,0 +1,297 @@
+// heads_io.hip -- appearance VM gather (a9), MLP input assembly (a10) and alpha compositing (a13), fwd + bwd.
+#include "clift_dev.h"
+
+// ============================================================================ appearance gather
+// Thread = (active sample, 4-channel group).  The 3*comps/4 threads of one sample write one contiguous row of
+// F and, per tap, read contiguous 16-byte pieces of one channels-last texel.
+__global__ __launch_bounds__(256) void k_app_gather_fwd(MarchP m, VmP t, const float* __restrict__ rays, const float* __restrict__ jitter,
+                                                         const int* __restrict__ act, long total, float* __restrict__ F,
+                                                         float* __restrict__ xa) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int g4 = t.comps / 4, G = 3 * g4;
+    const int s = (int)(gid / G), j = (int)(gid - (long)s * G);
+    const int i = j / g4, c4 = (j - i * g4) * 4;
+    const int sid = act[s];
+    const int r = sid / m.S, k = sid - r * m.S;
+    const RayG g = load_ray(rays, r, m);
+    float xn[3];
+    sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+    const VmTaps tp = vm_taps(t, i, xn);
+    const float4 v = f4_mul(vm_plane4(t, i, tp, c4), vm_line4(t, i, tp, c4));
+    *reinterpret_cast<float4*>(F + (size_t)s * (3 * t.comps) + i * t.comps + c4) = v;
+    if (j == 0 && xa) *reinterpret_cast<float4*>(xa + (size_t)s * 4) = make_float4(xn[0], xn[1], xn[2], 0.f);
+}
+
+extern "C" int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter,
+                                    const int* act_idx, int M, float* F, float* xa, clift_stream_t s) {
+    CLIFT_REQUIRE(h_app->comps % 4 == 0, "clift_app_gather_fwd: comps must be a multiple of 4");
+    if (M <= 0) return 0;
+    const long total = (long)M * (3 * h_app->comps / 4);
+    k_app_gather_fwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), rays, jitter, act_idx, total, F, xa);
+    return clift_check_launch("clift_app_gather_fwd");
+}
+
+// normalised coordinates of the active samples only (instance / segment passes, renderer.py:204,285)
+__global__ __launch_bounds__(256) void k_active_xyz(MarchP m, const float* __restrict__ rays, const float* __restrict__ jitter,
+                                                     const int* __restrict__ act, int M, float* __restrict__ xa) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M) return;
+    const int sid = act[s];
+    const int r = sid / m.S, k = sid - r * m.S;
+    const RayG g = load_ray(rays, r, m);
+    float xn[3];
+    sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+    *reinterpret_cast<float4*>(xa + (size_t)s * 4) = make_float4(xn[0], xn[1], xn[2], 0.f);
+}
+
+extern "C" int clift_active_xyz(const clift_march_t* h_m, const float* rays, const float* jitter, const int* act_idx, int M, float* xa,
+                                clift_stream_t s) {
+    if (M <= 0) return 0;
+    k_active_xyz<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), rays, jitter, act_idx, M, xa);
+    return clift_check_launch("clift_active_xyz");
+}
+
+__global__ __launch_bounds__(256) void k_app_gather_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
+                                                         const float* __restrict__ jitter, const int* __restrict__ act, long total,
+                                                         const float* __restrict__ dF) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int g4 = t.comps / 4, G = 3 * g4;
+    const int s = (int)(gid / G), j = (int)(gid - (long)s * G);
+    const int i = j / g4, c4 = (j - i * g4) * 4;
+    const int sid = act[s];
+    const int r = sid / m.S, k = sid - r * m.S;
+    const RayG g = load_ray(rays, r, m);
+    float xn[3];
+    sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+    const VmTaps tp = vm_taps(t, i, xn);
+    const float4 d = ld4(dF + (size_t)s * (3 * t.comps) + i * t.comps + c4);
+    const float4 P = vm_plane4(t, i, tp, c4), L = vm_line4(t, i, tp, c4);
+    vm_scatter4(t, gr, i, tp, c4, f4_mul(d, L), f4_mul(d, P));
+}
+
+extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
+                                    const float* rays, const float* jitter, const int* act_idx, int M, const float* dF,
+                                    clift_stream_t s) {
+    CLIFT_REQUIRE(h_app->comps % 4 == 0, "clift_app_gather_bwd: comps must be a multiple of 4");
+    if (M <= 0) return 0;
+    const long total = (long)M * (3 * h_app->comps / 4);
+    k_app_gather_bwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, total, dF);
+    return clift_check_launch("clift_app_gather_bwd");
+}
+
+// ============================================================================ appearance MLP input
+// Column map (tensoRF.py:401-408,413-418): [feat(nf) | dir(3) | sin(feat_f*2^p) (f-major, p minor) | cos(...) |
+// sin(dir_a*2^p) | cos(...) | zero pad].
+__global__ __launch_bounds__(256) void k_app_encode_fwd(const float* __restrict__ feat, int ldf, int nf, int pef, int pev,
+                                                         const float* __restrict__ rays, const int* __restrict__ act, int S, long total,
+                                                         float* __restrict__ X, int ldx) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int s = (int)(gid / ldx), c = (int)(gid - (long)s * ldx);
+    const float* f = feat + (size_t)s * ldf;
+    const float* d = rays + (size_t)(act[s] / S) * 8 + 3;
+    const int b0 = nf, b1 = b0 + 3, b2 = b1 + nf * pef, b3 = b2 + nf * pef, b4 = b3 + 3 * pev, b5 = b4 + 3 * pev;
+    float v = 0.f;
+    if (c < b0) v = f[c];
+    else if (c < b1) v = d[c - b0];
+    else if (c < b2) { const int e = c - b1; v = sinf(f[e / pef] * (float)(1 << (e % pef))); }
+    else if (c < b3) { const int e = c - b2; v = cosf(f[e / pef] * (float)(1 << (e % pef))); }
+    else if (c < b4) { const int e = c - b3; v = sinf(d[e / pev] * (float)(1 << (e % pev))); }
+    else if (c < b5) { const int e = c - b4; v = cosf(d[e / pev] * (float)(1 << (e % pev))); }
+    X[gid] = v;
+}
+
+extern "C" int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* rays,
+                                    const int* act_idx, int S, int M, float* X, int ldx, clift_stream_t s) {
+    CLIFT_REQUIRE(ldx >= nf + 3 + 2 * pe_feat * nf + 2 * pe_view * 3, "clift_app_encode_fwd: ldx %d too small", ldx);
+    CLIFT_REQUIRE(pe_feat >= 1 && pe_view >= 1, "clift_app_encode_fwd: pe_feat/pe_view must be >= 1");
+    if (M <= 0) return 0;
+    const long total = (long)M * ldx;
+    k_app_encode_fwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, pe_view, rays, act_idx, S, total, X, ldx);
+    return clift_check_launch("clift_app_encode_fwd");
+}
+
+__global__ __launch_bounds__(256) void k_app_encode_bwd(const float* __restrict__ feat, int ldf, int nf, int pef,
+                                                         const float* __restrict__ dX, int ldx, long total, float* __restrict__ dfeat,
+                                                         int lddf) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int s = (int)(gid / lddf), c = (int)(gid - (long)s * lddf);
+    float v = 0.f;
+    if (c < nf) {
+        const float* g = dX + (size_t)s * ldx;
+        const float x = feat[(size_t)s * ldf + c];
+        v = g[c];
+        const int bs = nf + 3, bc = bs + nf * pef;
+        for (int p = 0; p < pef; ++p) {
+            const float fr = (float)(1 << p), a = x * fr;
+            v += fr * (cosf(a) * g[bs + c * pef + p] - sinf(a) * g[bc + c * pef + p]);
+        }
+    }
+    dfeat[gid] = v;
+}
+
+extern "C" int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const float* dX, int ldx, int M, float* dfeat,
+                                    int lddf, clift_stream_t s) {
+    CLIFT_REQUIRE(lddf >= nf, "clift_app_encode_bwd: lddf too small");
+    if (M <= 0) return 0;
+    const long total = (long)M * lddf;
+    k_app_encode_bwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, dX, ldx, total, dfeat, lddf);
+    return clift_check_launch("clift_app_encode_bwd");
+}
+
+// ============================================================================ compositing forward
+// Thread = (ray, output channel); channel ranges [0,3) rgb, [3,3+C) semantics, [3+C,3+C+D) instances.
+// Each thread walks the ray's contiguous slice of the compacted sample list (same summation order as a
+// sequential sum over samples).
+__global__ __launch_bounds__(256) void k_composite_sum(const float* __restrict__ w, const int* __restrict__ start, const int* __restrict__ act,
+                                                        int N, int C, int D, const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                        const float* __restrict__ inst_s, float* __restrict__ rgb_raw,
+                                                        float* __restrict__ sem_raw, float* __restrict__ inst_map) {
+    const int CH = 3 + C + D;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)N * CH) return;
+    const int r = (int)(gid / CH), c = (int)(gid - (long)r * CH);
+    const float* src;
+    int ld, cc;
+    float* dst;
+    if (c < 3) { src = rgb_s; ld = 3; cc = c; dst = rgb_raw ? rgb_raw + (size_t)r * 3 + c : nullptr; }
+    else if (c < 3 + C) { src = sem_s; ld = C; cc = c - 3; dst = sem_raw ? sem_raw + (size_t)r * C + cc : nullptr; }
+    else { src = inst_s; ld = D; cc = c - 3 - C; dst = inst_map ? inst_map + (size_t)r * D + cc : nullptr; }
+    if (!src || !dst) return;
+    float acc = 0.f;
+    for (int i = start[r], e = start[r + 1]; i < e; ++i) acc = fmaf(w[act[i]], src[(size_t)i * ld + cc], acc);
+    *dst = acc;
+}
+
+__global__ __launch_bounds__(256) void k_composite_finish(int N, int C, const float* __restrict__ ray_out, int softmax_mode, int white_bg,
+                                                           float* __restrict__ rgb_raw, float* __restrict__ rgb_map,
+                                                           const float* __restrict__ sem_raw, float* __restrict__ sem_map) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    if (rgb_raw && rgb_map) {
+        const float add = white_bg ? (1.f - ray_out[(size_t)r * 8]) : 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float v = rgb_raw[(size_t)r * 3 + c] + add;
+            rgb_raw[(size_t)r * 3 + c] = v;  // pre-clamp value, kept for the clamp mask of the backward
+            rgb_map[(size_t)r * 3 + c] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+    if (sem_raw && sem_map) {
+        const float* sr = sem_raw + (size_t)r * C;
+        float* sm = sem_map + (size_t)r * C;
+        if (softmax_mode) {
+            float t = 0.f;
+            for (int c = 0; c < C; ++c) t += sr[c];
+            t += 1e-8f;
+            for (int c = 0; c < C; ++c) sm[c] = logf(sr[c] / t + 1e-8f);
+        } else {
+            for (int c = 0; c < C; ++c) sm[c] = sr[c];
+        }
+    }
+}
+
+extern "C" int clift_composite_fwd(const float* w, const int* ray_start, const int* act_idx, int N, int C, int D, const float* rgb_s,
+                                   const float* sem_s, const float* inst_s, const float* ray_out, int softmax_mode, int white_bg,
+                                   float* rgb_raw, float* rgb_map, float* sem_raw, float* sem_map, float* inst_map, clift_stream_t s) {
+    if (N <= 0) return 0;
+    const long total = (long)N * (3 + C + D);
+    k_composite_sum<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(w, ray_start, act_idx, N, C, D, rgb_s, sem_s, inst_s, rgb_raw, sem_raw, inst_map);
+    int rc = clift_check_launch("clift_composite_fwd(sum)");
+    if (rc) return rc;
+    k_composite_finish<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(N, C, ray_out, softmax_mode, white_bg, rgb_s ? rgb_raw : nullptr, rgb_map,
+                                                                sem_s ? sem_raw : nullptr, sem_map);
+    return clift_check_launch("clift_composite_fwd(finish)");
+}
+
+// ============================================================================ compositing backward
+// Stage 1 (per ray): fold clamp / white background / log-normalisation into effective per-ray gradients
+// ge (N, 3+C+D) and g_opacity.  Stage 2 (per active sample): d head outputs = w * ge, g_w = <head output, ge>.
+__global__ __launch_bounds__(256) void k_composite_bwd_ray(int N, int C, int D, const float* __restrict__ rgb_raw, const float* __restrict__ sem_raw,
+                                                            int softmax_mode, int white_bg, const float* __restrict__ g_rgb,
+                                                            const float* __restrict__ g_sem, const float* __restrict__ g_inst,
+                                                            float* __restrict__ ge, float* __restrict__ g_opacity) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const int CH = 3 + C + D;
+    float* e = ge + (size_t)r * CH;
+    float gop = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (g_rgb && rgb_raw) {
+            const float raw = rgb_raw[(size_t)r * 3 + c];
+            v = (raw >= 0.f && raw <= 1.f) ? g_rgb[(size_t)r * 3 + c] : 0.f;
+            if (white_bg) gop -= v;
+        }
+        e[c] = v;
+    }
+    if (g_sem && sem_raw) {
+        const float* sr = sem_raw + (size_t)r * C;
+        const float* gs = g_sem + (size_t)r * C;
+        if (softmax_mode) {
+            float t = 0.f;
+            for (int c = 0; c < C; ++c) t += sr[c];
+            t += 1e-8f;
+            float dot = 0.f;
+            for (int c = 0; c < C; ++c) dot += (gs[c] / (sr[c] / t + 1e-8f)) * sr[c];
+            for (int c = 0; c < C; ++c) e[3 + c] = (gs[c] / (sr[c] / t + 1e-8f)) / t - dot / (t * t);
+        } else {
+            for (int c = 0; c < C; ++c) e[3 + c] = gs[c];
+        }
+    } else {
+        for (int c = 0; c < C; ++c) e[3 + c] = 0.f;
+    }
+    for (int c = 0; c < D; ++c) e[3 + C + c] = g_inst ? g_inst[(size_t)r * D + c] : 0.f;
+    if (g_opacity) g_opacity[r] = gop;
+}
+
+__global__ __launch_bounds__(256) void k_composite_bwd_sample(const float* __restrict__ w, const int* __restrict__ act, int S, int M, int C, int D,
+                                                               const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                               const float* __restrict__ inst_s, const float* __restrict__ ge, int stop_grad,
+                                                               float* __restrict__ d_rgb_s, float* __restrict__ d_sem_s,
+                                                               float* __restrict__ d_inst_s, float* __restrict__ g_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int sid = act[i];
+    const int r = sid / S;
+    const float wv = w[sid];
+    const float* e = ge + (size_t)r * (3 + C + D);
+    float gw = 0.f;
+    if (rgb_s) {
+        for (int c = 0; c < 3; ++c) {
+            if (d_rgb_s) d_rgb_s[(size_t)i * 3 + c] = wv * e[c];
+            gw = fmaf(rgb_s[(size_t)i * 3 + c], e[c], gw);
+        }
+    }
+    if (sem_s) {
+        for (int c = 0; c < C; ++c) {
+            if (d_sem_s) d_sem_s[(size_t)i * C + c] = wv * e[3 + c];
+            if (!stop_grad) gw = fmaf(sem_s[(size_t)i * C + c], e[3 + c], gw);
+        }
+    }
+    if (inst_s) {
+        for (int c = 0; c < D; ++c) {
+            if (d_inst_s) d_inst_s[(size_t)i * D + c] = wv * e[3 + C + c];
+            if (!stop_grad) gw = fmaf(inst_s[(size_t)i * D + c], e[3 + C + c], gw);
+        }
+    }
+    if (g_w) g_w[sid] = gw;
+}
+
+extern "C" int clift_composite_bwd(const float* w, const int* ray_start, const int* act_idx, int N, int S, int M, int C, int D,
+                                   const float* rgb_s, const float* sem_s, const float* inst_s, const float* rgb_raw,
+                                   const float* sem_raw, int softmax_mode, int white_bg, int stop_grad, const float* g_rgb,
+                                   const float* g_sem, const float* g_inst, float* ge_work, float* d_rgb_s, float* d_sem_s,
+                                   float* d_inst_s, float* g_w, float* g_opacity, clift_stream_t s) {
+    (void)ray_start;
+    if (N <= 0) return 0;
+    k_composite_bwd_ray<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(N, C, D, rgb_raw, sem_raw, softmax_mode, white_bg, g_rgb, g_sem, g_inst,
+                                                                 ge_work, g_opacity);
+    int rc = clift_check_launch("clift_composite_bwd(ray)");
+    if (rc || M <= 0) return rc;
+    k_composite_bwd_sample<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(w, act_idx, S, M, C, D, rgb_s, sem_s, inst_s, ge_work, stop_grad, d_rgb_s,
+                                                                    d_sem_s, d_inst_s, g_w);
+    return clift_check_launch("clift_composite_bwd(sample)");
+}

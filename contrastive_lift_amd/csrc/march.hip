@@ -1,0 +1,263 @@
+// march.hip -- ray marching: density VM lookup, transmittance scan, compaction, and their backward.
+// Reference rows: a4 a5 a6 a7 a8.
+#include "clift_dev.h"
+
+// ============================================================================ density forward
+// 4 lanes per sample, lane q owns channels [4q, 4q+4) (+16 per extra pass) of all three plane/line pairs:
+// a tap of one sample is one contiguous 64-byte segment of the channels-last table, read by 4 adjacent
+// lanes.  Samples are consecutive along a ray, so a wave (16 samples) walks a short 3-D segment and its
+// taps mostly share cache lines.
+__global__ __launch_bounds__(256) void k_density_fwd(MarchP m, VmP t, const float* __restrict__ rays,
+                                                      const float* __restrict__ jitter, long total, float* __restrict__ sigma) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long s = gid >> 2;
+    const int q = (int)(gid & 3);
+    if (s >= total) return;
+    const int r = (int)(s / m.S), k = (int)(s - (long)r * m.S);
+    const RayG g = load_ray(rays, r, m);
+    const float jit = jitter ? jitter[r] : 0.f;
+    float xn[3];
+    const bool in = sample_xn(g, m, sample_z(g, m, k, jit), xn);
+    float acc = 0.f;
+    if (in) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const VmTaps tp = vm_taps(t, i, xn);
+            for (int c4 = q * 4; c4 < t.comps; c4 += 16) acc += f4_hsum(f4_mul(vm_plane4(t, i, tp, c4), vm_line4(t, i, tp, c4)));
+        }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (q == 0) {
+        float out = 0.f;
+        if (in) {
+            const float x = acc + m.shift;
+            out = (x > 20.f) ? x : log1pf(expf(x));
+        }
+        sigma[s] = out;
+    }
+}
+
+extern "C" int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const float* rays,
+                                 const float* jitter, int N, float* sigma, clift_stream_t s) {
+    CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_density_fwd: comps must be a multiple of 4 (got %d)", h_dens->comps);
+    if (N <= 0) return 0;
+    const long total = (long)N * h_m->n_samples;
+    k_density_fwd<<<cdiv(total * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), rays, jitter, total, sigma);
+    return clift_check_launch("clift_density_fwd");
+}
+
+// ============================================================================ density backward
+__global__ __launch_bounds__(256) void k_density_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
+                                                      const float* __restrict__ jitter, long total,
+                                                      const float* __restrict__ dsigma) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long s = gid >> 2;
+    const int q = (int)(gid & 3);
+    if (s >= total) return;
+    const float ds = dsigma[s];
+    if (ds == 0.f) return;  // uniform over the 4 lanes of a sample
+    const int r = (int)(s / m.S), k = (int)(s - (long)r * m.S);
+    const RayG g = load_ray(rays, r, m);
+    const float jit = jitter ? jitter[r] : 0.f;
+    float xn[3];
+    if (!sample_xn(g, m, sample_z(g, m, k, jit), xn)) return;
+    // recompute sigma_raw for the softplus derivative (comps <= 16*4 handled by the strided loop)
+    float acc = 0.f;
+    VmTaps tp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        tp[i] = vm_taps(t, i, xn);
+        for (int c4 = q * 4; c4 < t.comps; c4 += 16) acc += f4_hsum(f4_mul(vm_plane4(t, i, tp[i], c4), vm_line4(t, i, tp[i], c4)));
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    const float x = acc + m.shift;
+    const float dsp = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+    const float up = ds * dsp;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        for (int c4 = q * 4; c4 < t.comps; c4 += 16) {
+            const float4 P = vm_plane4(t, i, tp[i], c4), L = vm_line4(t, i, tp[i], c4);
+            vm_scatter4(t, gr, i, tp[i], c4, f4_scale(up, L), f4_scale(up, P));
+        }
+}
+
+extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const clift_vm_grad_t* h_grad,
+                                 const float* rays, const float* jitter, int N, const float* dsigma, clift_stream_t s) {
+    CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_density_bwd: comps must be a multiple of 4");
+    if (N <= 0) return 0;
+    const long total = (long)N * h_m->n_samples;
+    k_density_bwd<<<cdiv(total * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, dsigma);
+    return clift_check_launch("clift_density_bwd");
+}
+
+// ============================================================================ transmittance scan (forward)
+// One wavefront per ray; the S samples are swept in chunks of 64 lanes with a wave prefix product for
+// T = cumprod(1 - alpha + 1e-10) and prefix sums for the distortion loss.
+__global__ __launch_bounds__(256) void k_march_fwd(MarchP m, const float* __restrict__ rays, const float* __restrict__ jitter, int N,
+                                                    const float* __restrict__ sigma, float* __restrict__ alpha_o, float* __restrict__ T_o,
+                                                    float* __restrict__ w_o, float* __restrict__ ray_out, int* __restrict__ n_active) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int l = lane_id();
+    const RayG g = load_ray(rays, r, m);
+    const float jit = jitter ? jitter[r] : 0.f;
+    const int S = m.S;
+    const float z_last_mid = sample_z(g, m, max(S - 2, 0), jit);
+    float carryT = 1.f, carryW = 0.f, carryWM = 0.f;
+    float opacity = 0.f, depth = 0.f, dl = 0.f;
+    int cnt = 0;
+    for (int base = 0; base < S; base += 64) {
+        const int k = base + l;
+        const bool valid = k < S;
+        const float z0 = sample_z(g, m, k, jit);
+        const float z1 = sample_z(g, m, k + 1, jit);
+        const float delta = (valid && k < S - 1) ? __fsub_rn(z1, z0) : 0.f;
+        const float sg = valid ? sigma[(size_t)r * S + k] : 0.f;
+        const float a = 1.f - expf(-(sg * (delta * m.dist_scale)));
+        const float om = valid ? ((1.f - a) + 1e-10f) : 1.f;
+        const float incl = wave_incl_prod(om);
+        float excl = __shfl_up(incl, 1);
+        if (l == 0) excl = 1.f;
+        const float T = carryT * excl;
+        const float w = valid ? a * T : 0.f;
+        carryT *= __shfl(incl, 63);
+        // distortion loss (public eff_distloss formula; midpoints renderer.py:84)
+        const float mid = (k < S - 1) ? (z1 + z0) * 0.5f : z_last_mid;
+        const float wm = w * mid;
+        const float iw = wave_incl_sum(w), iwm = wave_incl_sum(wm);
+        const float wpre = carryW + (iw - w), wmpre = carryWM + (iwm - wm);
+        dl += (1.f / 3.f) * delta * w * w + 2.f * w * (mid * wpre - wmpre);
+        carryW += __shfl(iw, 63);
+        carryWM += __shfl(iwm, 63);
+        opacity += w;
+        depth += w * z0;
+        cnt += (valid && w > m.thres) ? 1 : 0;
+        if (valid) {
+            const size_t o = (size_t)r * S + k;
+            alpha_o[o] = a; T_o[o] = T; w_o[o] = w;
+        }
+    }
+    opacity = wave_sum(opacity);
+    depth = wave_sum(depth);
+    dl = wave_sum(dl);
+    cnt = wave_sum_i(cnt);
+    if (l == 0) {
+        float* ro = ray_out + (size_t)r * 8;
+        ro[0] = opacity; ro[1] = depth; ro[2] = carryT; ro[3] = carryW; ro[4] = carryWM; ro[5] = dl; ro[6] = g.tmin; ro[7] = 0.f;
+        n_active[r] = cnt;
+    }
+}
+
+extern "C" int clift_march_fwd(const clift_march_t* h_m, const float* rays, const float* jitter, int N, const float* sigma,
+                               float* alpha, float* T, float* w, float* ray_out, int* n_active, clift_stream_t s) {
+    if (N <= 0) return 0;
+    k_march_fwd<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(to_dev(h_m), rays, jitter, N, sigma, alpha, T, w, ray_out, n_active);
+    return clift_check_launch("clift_march_fwd");
+}
+
+// ============================================================================ transmittance scan (backward)
+// Reverse sweep with suffix sums.  g_k = g_w[k] + g_opacity + g_dist * d(dist)/dw_k;
+// dL/dalpha_k = g_k T_k - (sum_{j>k} g_j w_j) / (1 - alpha_k + 1e-10);  dL/dsigma_k = dL/dalpha_k (1-alpha_k) delta_k scale.
+__global__ __launch_bounds__(256) void k_march_bwd(MarchP m, const float* __restrict__ rays, const float* __restrict__ jitter, int N,
+                                                    const float* __restrict__ alpha_i, const float* __restrict__ T_i, const float* __restrict__ w_i,
+                                                    const float* __restrict__ ray_out, const float* __restrict__ g_w,
+                                                    const float* __restrict__ g_opacity, const float* __restrict__ g_dist,
+                                                    float* __restrict__ dsigma) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int l = lane_id();
+    const RayG g = load_ray(rays, r, m);
+    const float jit = jitter ? jitter[r] : 0.f;
+    const int S = m.S;
+    const float z_last_mid = sample_z(g, m, max(S - 2, 0), jit);
+    const float gop = g_opacity ? g_opacity[r] : 0.f;
+    const float gd = g_dist ? g_dist[0] / (float)N : 0.f;
+    const float Wtot = ray_out[(size_t)r * 8 + 3], WMtot = ray_out[(size_t)r * 8 + 4];
+    float sufW = 0.f, sufWM = 0.f, sufGW = 0.f;  // sums over samples strictly after the current chunk
+    const int nchunk = (S + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int k = c * 64 + l;
+        const bool valid = k < S;
+        const size_t o = (size_t)r * S + (valid ? k : 0);
+        const float a = valid ? alpha_i[o] : 0.f, T = valid ? T_i[o] : 0.f, w = valid ? w_i[o] : 0.f;
+        const float z0 = sample_z(g, m, k, jit), z1 = sample_z(g, m, k + 1, jit);
+        const float delta = (valid && k < S - 1) ? __fsub_rn(z1, z0) : 0.f;
+        const float mid = (k < S - 1) ? (z1 + z0) * 0.5f : z_last_mid;
+        const float wm = w * mid;
+        const float sw = wave_incl_suffix_sum(w), swm = wave_incl_suffix_sum(wm);
+        const float Wsuf = sufW + (sw - w), WMsuf = sufWM + (swm - wm);
+        const float Wpre = Wtot - Wsuf - w, WMpre = WMtot - WMsuf - wm;
+        float gk = (valid ? (g_w ? g_w[o] : 0.f) : 0.f) + gop;
+        gk += gd * ((2.f / 3.f) * delta * w + 2.f * (mid * (Wpre - Wsuf) + (WMsuf - WMpre)));
+        if (!valid) gk = 0.f;
+        const float gw = gk * w;
+        const float sgw = wave_incl_suffix_sum(gw);
+        const float GWsuf = sufGW + (sgw - gw);
+        const float om = (1.f - a) + 1e-10f;
+        const float dalpha = gk * T - GWsuf / om;
+        if (valid) dsigma[o] = dalpha * (1.f - a) * (delta * m.dist_scale);
+        sufW += __shfl(sw, 0);
+        sufWM += __shfl(swm, 0);
+        sufGW += __shfl(sgw, 0);
+    }
+}
+
+extern "C" int clift_march_bwd(const clift_march_t* h_m, const float* rays, const float* jitter, int N, const float* alpha,
+                               const float* T, const float* w, const float* ray_out, const float* g_w, const float* g_opacity,
+                               const float* g_dist, float* dsigma, clift_stream_t s) {
+    if (N <= 0) return 0;
+    k_march_bwd<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(to_dev(h_m), rays, jitter, N, alpha, T, w, ray_out, g_w, g_opacity, g_dist, dsigma);
+    return clift_check_launch("clift_march_bwd");
+}
+
+// ============================================================================ compaction
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ cnt, int N, int* __restrict__ start) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int b = t * per, e = min(b + per, N);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = b; i < e; ++i) { start[i] = run; run += cnt[i]; }
+    if (t == 1023) start[N] = part[1023];
+}
+
+extern "C" int clift_scan_counts(const int* n_active, int N, int* ray_start, clift_stream_t s) {
+    CLIFT_REQUIRE(N >= 0, "clift_scan_counts: negative N");
+    k_scan_counts<<<1, 1024, 0, as_stream(s)>>>(n_active, N, ray_start);
+    return clift_check_launch("clift_scan_counts");
+}
+
+__global__ __launch_bounds__(256) void k_compact_fill(const float* __restrict__ w, const int* __restrict__ start, int N, int S,
+                                                       float thres, int* __restrict__ act) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int l = lane_id();
+    int run = start[r];
+    for (int base = 0; base < S; base += 64) {
+        const int k = base + l;
+        const bool on = (k < S) && (w[(size_t)r * S + k] > thres);
+        const unsigned long long bal = __ballot(on);
+        const int pre = __popcll(bal & ((1ull << l) - 1ull));
+        if (on) act[run + pre] = r * S + k;
+        run += __popcll(bal);
+    }
+}
+
+extern "C" int clift_compact_fill(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx, clift_stream_t s) {
+    if (N <= 0) return 0;
+    CLIFT_REQUIRE((long)N * S < 2147483647L, "clift_compact_fill: N*S overflows int32 sample ids");
+    k_compact_fill<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(w, ray_start, N, S, thres, act_idx);
+    return clift_check_launch("clift_compact_fill");
+}

@@ -1,0 +1,451 @@
+"""Kernel sequencing for the render hot path: explicit forward / backward over libclift.so entry points.
+
+No torch autograd inside: ``render_forward`` returns the outputs plus a context holding the saved
+activations, ``render_backward`` turns output gradients into parameter gradients written straight into the
+caller's gradient views (the field's gradient arena in training).  ``renderer.py`` wraps this pair in a
+``torch.autograd.Function`` for drop-in use.
+
+Per chunk of N rays (reference renderer.py:80-176):
+  density_fwd -> march_fwd -> scan/compact (one host read of the active count) ->
+  appearance gather -> basis GEMM -> encode -> 2 GEMM+ReLU -> GEMM -> sigmoid
+  xyz heads: K=3 first layer -> GEMM+ReLU chain -> narrow GEMM (-> softmax)
+  composite.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Gemm, March, VM, VMGrad, call, ptr, stream
+
+
+# ----------------------------------------------------------------------------- struct builders
+def march_struct(renderer, model):
+    m = March()
+    lo, hi = renderer.bbox_aabb_host
+    inv = renderer.inv_box_extent_host
+    for i in range(3):
+        m.lo[i], m.hi[i], m.inv_ext2[i] = lo[i], hi[i], inv[i]
+    m.step_size = renderer.step_size_host
+    m.n_samples = int(renderer.n_samples)
+    m.distance_scale = float(renderer.distance_scale)
+    m.density_shift = float(model.splus_density_shift)
+    m.weight_thres = float(renderer.raymarch_weight_thres)
+    return m
+
+
+def vm_struct(views, prefix, res):
+    v = VM()
+    for i in range(3):
+        v.plane[i] = views[f"{prefix}_plane.{i}"].data_ptr()
+        v.line[i] = views[f"{prefix}_line.{i}"].data_ptr()
+        v.res[i] = int(res[i])
+    v.comps = int(views[f"{prefix}_plane.0"].shape[1])
+    return v
+
+
+def vm_grad_struct(gviews, prefix):
+    g = VMGrad()
+    for i in range(3):
+        g.plane[i] = gviews[f"{prefix}_plane.{i}"].data_ptr()
+        g.line[i] = gviews[f"{prefix}_line.{i}"].data_ptr()
+    return g
+
+
+def grid_res(views):
+    """(Rx,Ry,Rz) from the density table shapes: plane0 is (1,C,Ry,Rx), line0 is (1,C,Rz,1)."""
+    p0, l0 = views["density_plane.0"], views["density_line.0"]
+    return (p0.shape[3], p0.shape[2], l0.shape[2])
+
+
+def _pitch(t):
+    return t.stride(0) if t.dim() == 2 else 1
+
+
+def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=0, mask=None, ldmask=0,
+         accumulate=0, split_k=1, a_off=0, c_off=0):
+    g = Gemm()
+    g.M, g.N, g.K = int(M), int(N), int(K)
+    g.A, g.lda, g.a_trans = A.data_ptr() + 4 * a_off, int(lda), int(a_trans)
+    g.B, g.ldb, g.b_trans = B.data_ptr(), int(ldb), int(b_trans)
+    g.C, g.ldc = Cm.data_ptr() + 4 * c_off, int(ldc)
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.act = int(act)
+    g.mask = mask.data_ptr() if mask is not None else None
+    g.ldmask = int(ldmask)
+    g.accumulate, g.split_k = int(accumulate), int(split_k)
+    call("clift_gemm", C.byref(g), stream())
+
+
+def _splits(out_rows, out_cols, K):
+    """Split the (huge) sample-reduction of a wgrad over blockIdx.z so that ~1024 workgroups are in flight."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 255) // 256 if out_cols > 128 else (out_cols + 127) // 128 if out_cols > 32 else 1)
+    return max(1, min((K + 255) // 256, (1024 + tiles - 1) // tiles))
+
+
+def _lin_params(seq, views_prefix, views):
+    """[(W, b)] of an nn.Sequential MLP, fetched from a name->tensor dict (parameter or gradient views)."""
+    out = []
+    j = 0
+    while f"{views_prefix}.{j}.weight" in views:
+        out.append((views[f"{views_prefix}.{j}.weight"], views[f"{views_prefix}.{j}.bias"]))
+        j += 2
+    return out
+
+
+# ----------------------------------------------------------------------------- xyz MLP heads (semantic / instance)
+def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
+    """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
+    activation) into out[:, col_off:col_off+n_out] with row pitch ldo."""
+    dev = xa.device
+    acts = []
+    W0, b0 = layers[0]
+    h = torch.empty((M, W0.shape[0]), dtype=torch.float32, device=dev)
+    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], stream())
+    acts.append(h)
+    for W, b in layers[1:-1]:
+        hn = torch.empty((M, W.shape[0]), dtype=torch.float32, device=dev)
+        gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
+        acts.append(hn)
+        h = hn
+    W, b = layers[-1]
+    gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), out, ldo, bias=b, c_off=col_off)
+    return acts
+
+
+def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M):
+    """dpre (M, ld) = gradient w.r.t. the last layer's pre-activation output (ld % 4 == 0, pad zero)."""
+    dev = xa.device
+    d = dpre
+    n = len(layers)
+    for li in range(n - 1, 0, -1):
+        W, b = layers[li]
+        gW, gb = glayers[li]
+        h = acts[li - 1]
+        no, ni = W.shape
+        gemm(no, ni, M, d, d.shape[1], h, h.shape[1], gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1,
+             split_k=_splits(no, ni, M))
+        call("clift_colsum", ptr(d), d.shape[1], M, no, ptr(gb), stream())
+        dn = torch.empty((M, ni), dtype=torch.float32, device=dev)
+        gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
+        d = dn
+    gW, gb = glayers[0]
+    call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), ptr(gb), stream())
+
+
+# ----------------------------------------------------------------------------- forward
+class RenderCtx:
+    pass
+
+
+def _density_march(model, renderer, rays, jitter):
+    views = model.named_views()
+    N = rays.shape[0]
+    S = int(renderer.n_samples)
+    dev = rays.device
+    ms = march_struct(renderer, model)
+    res = grid_res(views)
+    vd = vm_struct(views, "density", res)
+    sigma = torch.empty((N, S), dtype=torch.float32, device=dev)
+    alpha, T, w = torch.empty_like(sigma), torch.empty_like(sigma), torch.empty_like(sigma)
+    ray_out = torch.empty((N, 8), dtype=torch.float32, device=dev)
+    n_active = torch.empty((N,), dtype=torch.int32, device=dev)
+    st = stream()
+    call("clift_density_fwd", C.byref(ms), C.byref(vd), ptr(rays), ptr(jitter), N, ptr(sigma), st)
+    call("clift_march_fwd", C.byref(ms), ptr(rays), ptr(jitter), N, ptr(sigma), ptr(alpha), ptr(T), ptr(w), ptr(ray_out),
+         ptr(n_active), st)
+    ray_start = torch.empty((N + 1,), dtype=torch.int32, device=dev)
+    call("clift_scan_counts", ptr(n_active), N, ptr(ray_start), st)
+    M = int(ray_start[N].item())        # the one host sync of the chunk: sizes the active-sample buffers
+    act_idx = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+    call("clift_compact_fill", ptr(w), ptr(ray_start), N, S, float(renderer.raymarch_weight_thres), ptr(act_idx), st)
+    ctx = RenderCtx()
+    ctx.ms, ctx.res, ctx.N, ctx.S, ctx.M = ms, res, N, S, M
+    ctx.rays, ctx.jitter = rays, jitter
+    ctx.alpha, ctx.T, ctx.w, ctx.ray_out, ctx.ray_start, ctx.act_idx = alpha, T, w, ray_out, ray_start, act_idx
+    return ctx
+
+
+def _check_rays(rays, jitter):
+    if rays.dim() != 2 or rays.shape[1] != 8:
+        raise ValueError(f"rays must be (N,8) [o,d,near,far], got {tuple(rays.shape)}")
+    _lib.f32(rays, "rays")
+    rays = rays.contiguous()
+    if jitter is not None:
+        jitter = _lib.f32(jitter, "jitter").reshape(-1).contiguous()
+        if jitter.shape[0] != rays.shape[0]:
+            raise ValueError("jitter must have one entry per ray")
+    return rays, jitter
+
+
+def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True):
+    """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context."""
+    rays, jitter = _check_rays(rays, jitter)
+    views = model.named_views()
+    ctx = _density_march(model, renderer, rays, jitter)
+    N, S, M = ctx.N, ctx.S, ctx.M
+    dev = rays.device
+    st = stream()
+    Ccls = model.num_semantic_classes
+    D = model.dim_feature_instance if (want_inst and model.render_instance_mlp is not None) else 0
+    softmax_mode = 1 if renderer.semantic_weight_mode == "softmax" else 0
+    ctx.white_bg, ctx.softmax_mode, ctx.stop_grad = int(bool(white_bg)), softmax_mode, int(bool(renderer.stop_semantic_grad))
+    ctx.C, ctx.D = Ccls, D
+    ctx.rgb_s = ctx.sem_s = ctx.inst_s = None
+    if M > 0:
+        xa = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        ctx.xa = xa
+        if want_rgb:
+            va = vm_struct(views, "appearance", ctx.res)
+            nc = 3 * va.comps
+            F = torch.empty((M, nc), dtype=torch.float32, device=dev)
+            call("clift_app_gather_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(F), ptr(xa), st)
+            Wb = views["appearance_basis_mat.weight"]
+            nf = Wb.shape[0]
+            ldf = (nf + 3) // 4 * 4
+            feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
+            gemm(M, nf, nc, F, nc, Wb, _pitch(Wb), feat, ldf)
+            app = _lin_params(model.render_appearance_mlp.mlp, "render_appearance_mlp.mlp", views)
+            ldx = _pitch(app[0][0])
+            X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
+            call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
+                 ptr(X), ldx, st)
+            (W1, b1), (W2, b2), (W3, b3) = app
+            H1 = torch.empty((M, W1.shape[0]), dtype=torch.float32, device=dev)
+            gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
+            H2 = torch.empty((M, W2.shape[0]), dtype=torch.float32, device=dev)
+            gemm(M, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
+            pre = torch.empty((M, 3), dtype=torch.float32, device=dev)
+            gemm(M, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
+            rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
+            call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, st)
+            ctx.F, ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2, ctx.rgb_s = F, feat, ldf, nf, X, ldx, H1, H2, rgb_s
+        else:
+            call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
+        if want_sem:
+            sem_layers = _lin_params(model.render_semantic_mlp.mlp, "render_semantic_mlp.mlp", views)
+            logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, logits, Ccls)
+            if model.render_semantic_mlp.softmax:
+                sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(sem_s), Ccls, st)
+            else:
+                sem_s = logits
+            ctx.sem_s = sem_s
+        if D > 0:
+            E = model.render_instance_mlp.output_channels
+            inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
+            fast = _lin_params(model.render_instance_mlp.mlp, "render_instance_mlp.mlp", views)
+            ctx.inst_fast_acts = xyz_mlp_fwd(fast, xa, M, inst_s, D, 0)
+            if model.slow_fast_mode:
+                slow = _lin_params(model.render_instance_mlp.slow_mlp, "render_instance_mlp.slow_mlp", views)
+                ctx.inst_slow_acts = xyz_mlp_fwd(slow, xa, M, inst_s, D, E)
+            ctx.inst_s = inst_s
+    rgb_raw = torch.zeros((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
+    rgb_map = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
+    sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
+    sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
+    inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D > 0 else None
+    if M > 0:
+        call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D,
+             ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.ray_out), softmax_mode, ctx.white_bg,
+             ptr(rgb_raw), ptr(rgb_map), ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
+    else:   # no active sample in the chunk (reference: the `if appearance_mask.any()` branch is skipped)
+        call("clift_composite_fwd", None, ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D,
+             None, None, None, ptr(ctx.ray_out), softmax_mode, ctx.white_bg,
+             ptr(rgb_raw), ptr(rgb_map), ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
+        _finish_empty(ctx, rgb_raw, rgb_map, sem_raw, sem_map)
+    ctx.rgb_raw, ctx.sem_raw = rgb_raw, sem_raw
+    ctx.want = (want_rgb, want_sem, D > 0)
+    out = dict(rgb=rgb_map, semantics=sem_map, instances=inst_map, depth=ctx.ray_out[:, 1],
+               dist_reg=ctx.ray_out[:, 5].mean(), opacity=ctx.ray_out[:, 0])
+    return out, ctx
+
+
+def _finish_empty(ctx, rgb_raw, rgb_map, sem_raw, sem_map):
+    """Compositing of a chunk with zero active samples, done with the same finishing kernel semantics."""
+    if rgb_map is not None:
+        add = (1.0 - ctx.ray_out[:, 0:1]) if ctx.white_bg else 0.0
+        rgb_raw.copy_(rgb_raw + add)
+        rgb_map.copy_(rgb_raw.clamp(0, 1))
+    if sem_map is not None:
+        if ctx.softmax_mode:
+            sem_map.copy_(torch.log(sem_raw / (sem_raw.sum(-1, keepdim=True) + 1e-8) + 1e-8))
+        else:
+            sem_map.copy_(sem_raw)
+
+
+# ----------------------------------------------------------------------------- backward
+def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_dist=None, density_grad=True,
+                    slow_grad=False):
+    """Accumulate parameter gradients into ``gviews`` (name -> tensor with the parameter's layout).
+    g_rgb (N,3), g_sem (N,C), g_inst (N,D): output gradients or None; g_dist: device scalar tensor or None."""
+    views = model.named_views()
+    N, S, M = ctx.N, ctx.S, ctx.M
+    dev = ctx.rays.device
+    st = stream()
+    Ccls, D = ctx.C, ctx.D
+    want_rgb, want_sem, want_inst = ctx.want
+    g_rgb = g_rgb.contiguous() if (g_rgb is not None and want_rgb) else None
+    g_sem = g_sem.contiguous() if (g_sem is not None and want_sem) else None
+    g_inst = g_inst.contiguous() if (g_inst is not None and want_inst) else None
+    g_w = torch.zeros((N, S), dtype=torch.float32, device=dev)
+    g_op = torch.zeros((N,), dtype=torch.float32, device=dev)
+    if M > 0 and (g_rgb is not None or g_sem is not None or g_inst is not None):
+        ge = torch.empty((N, 3 + Ccls + D), dtype=torch.float32, device=dev)
+        d_rgb = torch.empty((M, 3), dtype=torch.float32, device=dev) if g_rgb is not None else None
+        d_sem = torch.empty((M, Ccls), dtype=torch.float32, device=dev) if g_sem is not None else None
+        d_inst = torch.empty((M, D), dtype=torch.float32, device=dev) if g_inst is not None else None
+        call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
+             ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
+             ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
+             ptr(g_w), ptr(g_op), st)
+        # ---------------- appearance head
+        if d_rgb is not None:
+            app = _lin_params(None, "render_appearance_mlp.mlp", views)
+            gapp = _lin_params(None, "render_appearance_mlp.mlp", gviews)
+            (W1, b1), (W2, b2), (W3, b3) = app
+            (gW1, gb1), (gW2, gb2), (gW3, gb3) = gapp
+            dpre = torch.empty((M, 4), dtype=torch.float32, device=dev)
+            call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, st)
+            H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
+            n2 = W3.shape[1]
+            gemm(3, n2, M, dpre, 4, H2, n2, gW3, _pitch(gW3), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(3, n2, M))
+            call("clift_colsum", ptr(dpre), 4, M, 3, ptr(gb3), st)
+            dH2 = torch.empty((M, n2), dtype=torch.float32, device=dev)
+            gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
+            n1 = W2.shape[1]
+            gemm(n2, n1, M, dH2, n2, H1, n1, gW2, _pitch(gW2), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(n2, n1, M))
+            call("clift_colsum", ptr(dH2), n2, M, n2, ptr(gb2), st)
+            dH1 = torch.empty((M, n1), dtype=torch.float32, device=dev)
+            gemm(M, n1, n2, dH2, n2, W2, _pitch(W2), dH1, n1, b_trans=1, mask=H1, ldmask=n1)
+            gemm(n1, ldx, M, dH1, n1, X, ldx, gW1, ldx, a_trans=1, b_trans=1, accumulate=1, split_k=_splits(n1, ldx, M))
+            call("clift_colsum", ptr(dH1), n1, M, n1, ptr(gb1), st)
+            dX = torch.empty((M, ldx), dtype=torch.float32, device=dev)
+            gemm(M, ldx, n1, dH1, n1, W1, ldx, dX, ldx, b_trans=1)
+            nf, ldf = ctx.nf, ctx.ldf
+            dfeat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
+            call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, st)
+            Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
+            nc = Wb.shape[1]
+            gemm(nf, nc, M, dfeat, ldf, ctx.F, nc, gWb, _pitch(gWb), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(nf, nc, M))
+            dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
+            gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
+            va = vm_struct(views, "appearance", ctx.res)
+            ga = vm_grad_struct(gviews, "appearance")
+            call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
+                 ptr(ctx.act_idx), M, ptr(dF), st)
+        # ---------------- semantic head
+        if d_sem is not None:
+            ldp = (Ccls + 3) // 4 * 4
+            dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+            kind = 2 if model.render_semantic_mlp.softmax else 0
+            call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, st)
+            xyz_mlp_bwd(_lin_params(None, "render_semantic_mlp.mlp", views), _lin_params(None, "render_semantic_mlp.mlp", gviews),
+                        ctx.xa, ctx.sem_acts, dpre, M)
+        # ---------------- instance heads
+        if d_inst is not None:
+            E = model.render_instance_mlp.output_channels
+            ldp = (E + 3) // 4 * 4
+            nets = [("render_instance_mlp.mlp", ctx.inst_fast_acts, 0)]
+            if model.slow_fast_mode and slow_grad:
+                nets.append(("render_instance_mlp.slow_mlp", ctx.inst_slow_acts, E))
+            for prefix, acts, off in nets:
+                dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+                call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E, 0, ptr(dpre), ldp, st)
+                xyz_mlp_bwd(_lin_params(None, prefix, views), _lin_params(None, prefix, gviews), ctx.xa, acts, dpre, M)
+    elif g_rgb is not None and ctx.white_bg:
+        # no active samples but the white background still routes d rgb into the opacity
+        inside = ((ctx.rgb_raw >= 0) & (ctx.rgb_raw <= 1)).to(torch.float32)
+        g_op = -(g_rgb * inside).sum(-1)
+    # ---------------- density path
+    if density_grad:
+        dsigma = torch.empty((N, S), dtype=torch.float32, device=dev)
+        call("clift_march_bwd", C.byref(ctx.ms), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(ctx.alpha), ptr(ctx.T), ptr(ctx.w),
+             ptr(ctx.ray_out), ptr(g_w), ptr(g_op), ptr(g_dist), ptr(dsigma), st)
+        vd = vm_struct(views, "density", ctx.res)
+        gd = vm_grad_struct(gviews, "density")
+        call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma), st)
+
+
+# ----------------------------------------------------------------------------- instance / segment feature passes
+def feature_forward(model, renderer, rays, jitter, head):
+    """renderer.py:178-217 (head='instance') / :259-300 (head='semantic'): density and weights carry no gradient,
+    only the head does."""
+    rays, jitter = _check_rays(rays, jitter)
+    views = model.named_views()
+    ctx = _density_march(model, renderer, rays, jitter)
+    N, S, M = ctx.N, ctx.S, ctx.M
+    dev = rays.device
+    st = stream()
+    ctx.white_bg, ctx.stop_grad = 0, 1
+    ctx.softmax_mode = 1 if (head == "semantic" and renderer.semantic_weight_mode == "softmax") else 0
+    Ccls = model.num_semantic_classes if head == "semantic" else 0
+    D = model.dim_feature_instance if head == "instance" else 0
+    ctx.C, ctx.D = Ccls, D
+    ctx.rgb_s = ctx.sem_s = ctx.inst_s = None
+    ctx.rgb_raw = None
+    if M > 0:
+        xa = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        ctx.xa = xa
+        call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
+        if head == "semantic":
+            layers = _lin_params(None, "render_semantic_mlp.mlp", views)
+            logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, logits, Ccls)
+            if model.render_semantic_mlp.softmax:
+                ctx.sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(ctx.sem_s), Ccls, st)
+            else:
+                ctx.sem_s = logits
+        else:
+            E = model.render_instance_mlp.output_channels
+            ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
+            ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
+            if model.slow_fast_mode:
+                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E)
+    sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
+    sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
+    inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D else None
+    call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls, D, None, ptr(ctx.sem_s), ptr(ctx.inst_s),
+         ptr(ctx.ray_out), ctx.softmax_mode, 0, None, None, ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
+    if M == 0 and sem_map is not None:
+        _finish_empty(ctx, None, None, sem_raw, sem_map)
+    ctx.sem_raw = sem_raw
+    ctx.want = (False, head == "semantic", head == "instance")
+    if head == "instance":
+        xyz = rays[:, 0:3] + ctx.ray_out[:, 1:2] * rays[:, 3:6]      # renderer.py:213-215
+        return (inst_map, xyz), ctx
+    return sem_map, ctx
+
+
+def feature_backward(model, ctx, gviews, g_out, slow_grad=False):
+    if ctx.want[1]:
+        render_backward(model, ctx, gviews, g_sem=g_out, density_grad=False)
+    else:
+        render_backward(model, ctx, gviews, g_inst=g_out, density_grad=False, slow_grad=slow_grad)
+
+
+# ----------------------------------------------------------------------------- point-wise utilities (reference field API)
+def density_points(model, xyz, activation=True):
+    raise NotImplementedError("clift: point-wise density evaluation lands with the alpha-mask shrink (SURVEY 8f rank 1)")
+
+
+def appearance_feature_points(model, xyz):
+    raise NotImplementedError("clift: point-wise appearance features land with the alpha-mask shrink (SURVEY 8f rank 1)")
+
+
+def xyz_mlp_points(seq, xyz):
+    """Evaluate an xyz MLP head on arbitrary points (inference utility, no gradient)."""
+    xyz = _lib.f32(xyz, "xyz").reshape(-1, xyz.shape[-1])
+    M = xyz.shape[0]
+    xa = torch.zeros((M, 4), dtype=torch.float32, device=xyz.device)
+    xa[:, :3] = xyz[:, :3]
+    layers = [(m.weight, m.bias) for m in seq if isinstance(m, torch.nn.Linear)]
+    out = torch.empty((M, layers[-1][0].shape[0]), dtype=torch.float32, device=xyz.device)
+    xyz_mlp_fwd(layers, xa, M, out, out.shape[1])
+    return out
+
+
+def appearance_mlp_points(module, viewdirs, features):
+    raise NotImplementedError("clift: stand-alone appearance MLP evaluation is not exposed yet; use the renderer")

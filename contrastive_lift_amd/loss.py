@@ -1,0 +1,92 @@
+"""Losses of the path -- mirrors of reference model/loss/loss.py:9-26,62-82 and the slow-fast branch of
+trainer/train_panopli_tensorf.py:256-310,325-329, running as HIP kernels (clift_tv_fwd_bwd, clift_contrastive,
+clift_slow_fast, clift_ema).  Each returns a differentiable 0-dim tensor through a tiny autograd.Function whose
+backward only scales the gradient the kernel already produced in the forward launch.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class _Scaled(torch.autograd.Function):
+    """loss value + precomputed d loss / d x: backward = upstream * grad."""
+
+    @staticmethod
+    def forward(ctx, x, loss, grad):
+        ctx.save_for_backward(grad)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None
+
+
+def contrastive_loss(features, instance_labels, temperature):
+    """loss.py:62-82.  features (B,E) float32 cuda, instance_labels (B,) integer."""
+    f = _lib.f32(features, "features").contiguous()
+    B, E = f.shape
+    y = instance_labels.to(device=f.device, dtype=torch.int32).contiguous()
+    loss = torch.empty((1,), dtype=torch.float32, device=f.device)
+    grad = torch.empty_like(f)
+    work = torch.empty((max(4 * B, 4),), dtype=torch.float32, device=f.device)
+    _lib.call("clift_contrastive", _lib.ptr(f), _lib.ptr(y), B, E, float(temperature), _lib.ptr(loss), _lib.ptr(grad),
+              _lib.ptr(work), _lib.stream())
+    return _Scaled.apply(features, loss[0], grad)
+
+
+def slow_fast_loss(instance_features, labels_gt, confidences, return_grad=False):
+    """Slow-fast branch of calculate_instance_clustering_loss (T:261-309, use_proj=False); the EMA step that the
+    reference performs first (T:258-259) is ``ema_update``.  instance_features (B,2E) = [fast | slow]."""
+    f = _lib.f32(instance_features, "instance_features").contiguous()
+    B, D = f.shape
+    E = D // 2
+    y = labels_gt.to(device=f.device, dtype=torch.int32).contiguous()
+    conf = _lib.f32(confidences.to(f.device), "confidences").contiguous()
+    loss = torch.empty((1,), dtype=torch.float32, device=f.device)
+    grad = torch.empty_like(f)
+    work = torch.empty((8 * B + 2 * B * E + 8,), dtype=torch.float32, device=f.device)
+    _lib.call("clift_slow_fast", _lib.ptr(f), _lib.ptr(y), _lib.ptr(conf), B, E, _lib.ptr(loss), _lib.ptr(grad),
+              _lib.ptr(work), _lib.stream())
+    if return_grad:
+        return loss[0], grad
+    return _Scaled.apply(instance_features, loss[0], grad)
+
+
+@torch.no_grad()
+def ema_update(slownet, fastnet, momentum):
+    """trainer T:325-329: slow <- momentum*slow + (1-momentum)*fast, parameter by parameter."""
+    for pf, ps in zip(fastnet.parameters(), slownet.parameters()):
+        if ps.is_contiguous() and pf.is_contiguous():
+            _lib.call("clift_ema", _lib.ptr(ps), _lib.ptr(pf), ps.numel(), float(momentum), _lib.stream())
+        else:
+            ps.mul_(momentum).add_((1 - momentum) * pf)
+
+
+class TVLoss(nn.Module):
+    """loss.py:9-26 on a (1,C,H,W) tensor (any strides; channels-last is the native layout)."""
+
+    def forward(self, x):
+        return _TVFn.apply(x)
+
+
+class _TVFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.f32(x, "x")
+        b, c, h, w = x.shape
+        if b != 1:
+            raise NotImplementedError("clift TVLoss: batch must be 1")
+        xc = x.permute(0, 2, 3, 1).contiguous()          # (1,H,W,C): a no-op view for channels-last parameters
+        loss = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        grad = torch.zeros_like(xc)
+        _lib.call("clift_tv_fwd_bwd", _lib.ptr(xc), h, w, c, 1.0, _lib.ptr(grad), _lib.ptr(loss), _lib.stream())
+        ctx.save_for_backward(grad)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (g * grad).permute(0, 3, 1, 2)

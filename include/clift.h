@@ -1,0 +1,194 @@
+/* clift.h -- C ABI of libclift.so: the MI355X (gfx950) kernels of the Contrastive-Lift render hot path.
+ *
+ * The reference (yashbhalgat/Contrastive-Lift) is pure Python/PyTorch: it has no FFI layer.  The
+ * boundary a maintainer would bind is therefore the set of ATen-op groups its renderer/field/loss
+ * objects bottom out in.  Every entry point below cites the reference
+ * file:line whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 / int32 data unless its name starts with h_ (host);
+ *   - matrices are row-major with an explicit leading dimension where one is given;
+ *   - VM tables are channels-last: plane i is [res[b_i]][res[a_i]][comps], line i is [res[v_i]][comps]
+ *     with (a_i,b_i) = (0,1),(0,2),(1,2) and v_i = 2,1,0 (reference tensoRF.py:61-62,104-105; the PyTorch
+ *     tensors keep the reference shape (1,C,H,W) and use channels_last strides);
+ *   - the library never allocates or frees device memory, never synchronises the device and launches
+ *     only on the caller's stream; the caller owns all buffers (torch tensors);
+ *   - every function returns 0 on success, non-zero on error (message via clift_last_error());
+ *     no C++ exception crosses this boundary;
+ *   - one host thread per process drives the library (same threading model as the reference: one
+ *     Python thread per DDP rank).
+ */
+#ifndef CLIFT_H
+#define CLIFT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* clift_stream_t; /* hipStream_t */
+
+/* ABI version (bumped on any signature change) and last error string of the calling process. */
+int clift_version(void);
+const char* clift_last_error(void);
+
+/* One VM-decomposed table set (3 planes + 3 lines, equal component count). */
+typedef struct {
+    const float* plane[3];
+    const float* line[3];
+    int res[3]; /* Rx, Ry, Rz */
+    int comps;  /* components per plane (16 density / 48 appearance in the reference configs) */
+} clift_vm_t;
+
+/* Gradient accumulators for a table set (same layout; accumulated into with atomics). */
+typedef struct {
+    float* plane[3];
+    float* line[3];
+} clift_vm_grad_t;
+
+/* Renderer state: reference model/renderer/panopli_tensoRF_renderer.py:42-71 (buffers bbox_aabb,
+ * inv_box_extent; python attrs step_size, n_samples, distance_scale, raymarch_weight_thres) and
+ * tensoRF.py:35 (splus_density_shift). */
+typedef struct {
+    float lo[3];
+    float hi[3];
+    float inv_ext2[3]; /* 2 / (hi - lo) */
+    float step_size;
+    int n_samples;
+    float distance_scale;
+    float density_shift;
+    float weight_thres;
+} clift_march_t;
+
+/* ---- a1-a3: util/ray.py:8-12,25-31,46-54,81-99.  rays (H*W, 8) = [o, d, near, far].
+ * *bad_count is incremented for every ray whose sphere discriminant is negative (reference asserts). */
+int clift_gen_rays(int H, int W, const float* h_K9, const float* h_c2w16, float near_plane, float* rays,
+                   int* bad_count, clift_stream_t s);
+
+/* ---- a4-a6: renderer.py:800-817 (sampling; jitter = perturb*rand per ray, NULL for none), :633-634
+ * (normalise), tensoRF.py:108-125 (density VM lookup + shift + softplus).  sigma (N, S), 0 outside the box. */
+int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const float* rays, const float* jitter,
+                      int N, float* sigma, clift_stream_t s);
+
+/* ---- a7-a8: renderer.py:83-84,100-103,137,173-174,626-631 + eff_distloss (renderer.py:101).
+ * Per sample alpha, T (transmittance before the sample), w = alpha*T, all (N, S).
+ * ray_out (N, 8) = [opacity, depth, bg, w_total, wm_total, dist_loss, t_min, 0]; n_active (N) = #(w > thres). */
+int clift_march_fwd(const clift_march_t* h_m, const float* rays, const float* jitter, int N, const float* sigma,
+                    float* alpha, float* T, float* w, float* ray_out, int* n_active, clift_stream_t s);
+
+/* Backward of a7-a8: g_w (N,S) = dL/dw contributions from compositing (zero where inactive),
+ * g_opacity (N) = dL/d(sum w), g_dist = device scalar dL/d(dist_reg) (nullable) -> dsigma (N,S) = dL/dsigma. */
+int clift_march_bwd(const clift_march_t* h_m, const float* rays, const float* jitter, int N, const float* alpha,
+                    const float* T, const float* w, const float* ray_out, const float* g_w,
+                    const float* g_opacity, const float* g_dist, float* dsigma, clift_stream_t s);
+
+/* Backward of a6: scatter dsigma through softplus and the VM products into the table gradients. */
+int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const clift_vm_grad_t* h_grad,
+                      const float* rays, const float* jitter, int N, const float* dsigma, clift_stream_t s);
+
+/* ---- compaction of active samples (replaces the boolean-mask gathers renderer.py:103-108):
+ * ray_start (N+1) = exclusive scan of n_active; act_idx[ray_start[r] .. ray_start[r+1]) = r*S + k in
+ * increasing k for every k with w > thres. */
+int clift_scan_counts(const int* n_active, int N, int* ray_start, clift_stream_t s);
+int clift_compact_fill(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx,
+                       clift_stream_t s);
+
+/* ---- a9: tensoRF.py:127-134 (plane x line products, plane-major concat) on the compacted samples.
+ * F (M, 3*comps); xa (M, 4) = [xn.x, xn.y, xn.z, 0] (input of the xyz MLP heads, tensoRF.py:142-156). */
+int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter,
+                         const int* act_idx, int M, float* F, float* xa, clift_stream_t s);
+/* xa only (instance / segment passes: renderer.py:204,285 evaluate the xyz heads without appearance). */
+int clift_active_xyz(const clift_march_t* h_m, const float* rays, const float* jitter, const int* act_idx, int M,
+                     float* xa, clift_stream_t s);
+int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
+                         const float* rays, const float* jitter, const int* act_idx, int M, const float* dF,
+                         clift_stream_t s);
+
+/* ---- a10 input assembly: tensoRF.py:400-408,413-418.  X (M, ldx) = [feat(nf), dir(3), sin/cos PE(feat),
+ * sin/cos PE(dir), zero pad]; ldx >= nf + 3 + 2*pe_feat*nf + 2*pe_view*3. */
+int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* rays,
+                         const int* act_idx, int S, int M, float* X, int ldx, clift_stream_t s);
+int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const float* dX, int ldx, int M,
+                         float* dfeat, int lddf, clift_stream_t s);
+
+/* ---- nn.Linear building block on the matrix cores (tensoRF.py:65,393-397,475-491,576-582 and their
+ * backward).  C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] ) * (mask[m][n] > 0)
+ *   A(m,k) = a_trans ? A[k*lda+m] : A[m*lda+k];   B(n,k) = b_trans ? B[k*ldb+n] : B[n*ldb+k].
+ * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32).  K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
+ * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C). */
+typedef struct {
+    int M, N, K;
+    const float* A; int lda; int a_trans;
+    const float* B; int ldb; int b_trans;
+    float* C; int ldc;
+    const float* bias;              /* nullable */
+    int act;                        /* 0 none, 1 relu */
+    const float* mask; int ldmask;  /* nullable */
+    int accumulate;
+    int split_k;
+} clift_gemm_t;
+int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
+
+/* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4). */
+int clift_linear_k3_fwd(const float* x4, const float* W, const float* b, int M, int Nout, int relu, float* out,
+                        int ldo, clift_stream_t s);
+/* dW (Nout,3) += dH^T x ; db (Nout) += colsum(dH). */
+int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, float* db,
+                        clift_stream_t s);
+/* db (N) += colsum(dY (M,N)). */
+int clift_colsum(const float* dY, int ld, int M, int N, float* db, clift_stream_t s);
+
+/* Row activations of the head outputs: kind 1 = sigmoid (tensoRF.py:385,410), 2 = softmax (tensoRF.py:37,593);
+ * the backward also accepts kind 0 = identity (re-pitches dout (M,C) into the 4-float-aligned dpre (M,ldd)). */
+int clift_rows_act_fwd(const float* pre, int ldp, int M, int C, int kind, float* out, int ldo, clift_stream_t s);
+int clift_rows_act_bwd(const float* out, int ldo, const float* dout, int lddo, int M, int C, int kind, float* dpre,
+                       int ldd, clift_stream_t s);
+
+/* ---- a13 compositing: renderer.py:137-167.  rgb_s (M,3) sem_s (M,C) inst_s (M,D) are per-active-sample
+ * head outputs (NULL to skip a head).  Outputs rgb_raw (N,3) (pre-clamp), rgb_map (N,3), sem_raw (N,C)
+ * (weighted sums), sem_map (N,C) (log-normalised when softmax_mode), inst_map (N,D). */
+int clift_composite_fwd(const float* w, const int* ray_start, const int* act_idx, int N, int C, int D,
+                        const float* rgb_s, const float* sem_s, const float* inst_s, const float* ray_out,
+                        int softmax_mode, int white_bg, float* rgb_raw, float* rgb_map, float* sem_raw,
+                        float* sem_map, float* inst_map, clift_stream_t s);
+/* Backward.  stop_grad = renderer.stop_semantic_grad (w detached for semantics/instances, renderer.py:144-147).
+ * Writes d_rgb_s/d_sem_s/d_inst_s (per active sample, M rows), g_w at the active positions of a ZEROED (N,S)
+ * buffer, g_opacity (N).  Any of g_rgb/g_sem/g_inst (and the matching head buffers) may be NULL (treated as
+ * zero / skipped).  ge_work: scratch of N*(3+C+D) floats. */
+int clift_composite_bwd(const float* w, const int* ray_start, const int* act_idx, int N, int S, int M, int C, int D,
+                        const float* rgb_s, const float* sem_s, const float* inst_s, const float* rgb_raw,
+                        const float* sem_raw, int softmax_mode, int white_bg, int stop_grad, const float* g_rgb,
+                        const float* g_sem, const float* g_inst, float* ge_work, float* d_rgb_s, float* d_sem_s,
+                        float* d_inst_s, float* g_w, float* g_opacity, clift_stream_t s);
+
+/* ---- a18: model/loss/loss.py:14-22 on one channels-last plane (H,W,C); loss_accum[0] += weight*TV(x);
+ * grad (nullable) += weight * dTV/dx. */
+int clift_tv_fwd_bwd(const float* plane, int H, int W, int C, float weight, float* grad, float* loss_accum,
+                     clift_stream_t s);
+
+/* ---- a19 pixel losses of training_step (trainer/train_panopli_tensorf.py:155-160,177-178):
+ * out2[0] += mean((mask*(rgb-gt))^2); out2[1] += mean_i( mask_i conf_i * -sum_c cw_c p_ic log_softmax(sem_i)_c ).
+ * g_rgb = w_rgb * d out2[0]/d rgb ; g_sem = w_sem * d out2[1]/d sem (either nullable); maskf (N) 0/1, nullable. */
+int clift_pixel_losses(const float* rgb, const float* rgb_gt, const float* sem, const float* probs,
+                       const float* conf, const float* class_w, const float* maskf, int N, int C, float w_rgb,
+                       float w_sem, float* out2, float* g_rgb, float* g_sem, clift_stream_t s);
+
+/* ---- a16: model/loss/loss.py:62-82.  loss[0] = value; g_feat (B,E) = d loss / d features (nullable). */
+int clift_contrastive(const float* feat, const int* labels, int B, int E, float temperature, float* loss,
+                      float* g_feat, float* work /* >= 4*B floats */, clift_stream_t s);
+
+/* ---- a17: trainer/train_panopli_tensorf.py:261-309 (use_proj = False).  inst (B, 2E) = [fast | slow];
+ * loss[0] = value; g_inst (B,2E) = gradient (zero for the slow half and the slow ray set).
+ * work >= 8*B + 2*B*E floats. */
+int clift_slow_fast(const float* inst, const int* labels, const float* conf, int B, int E, float* loss,
+                    float* g_inst, float* work, clift_stream_t s);
+
+/* ---- optimiser plumbing on flat fp32 ranges: torch.optim.Adam semantics (L2 weight decay folded into the
+ * gradient; bias correction with step >= 1) and the slow-net EMA (trainer T:325-329). */
+int clift_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, clift_stream_t s);
+int clift_ema(float* slow, const float* fast, long n, float momentum, clift_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIFT_H */

@@ -1,0 +1,54 @@
+"""CPU-only checks of the drop-in boundary: libclift.so loads (hipcc cross-compiled, no GPU needed to load it) and
+exports every symbol include/clift.h declares; the ctypes table covers exactly that set; no compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "clift.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(clift_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("clift_gen_rays", "clift_density_fwd", "clift_march_fwd", "clift_march_bwd", "clift_density_bwd", "clift_gemm",
+                 "clift_composite_fwd", "clift_composite_bwd", "clift_contrastive", "clift_slow_fast", "clift_tv_fwd_bwd",
+                 "clift_adam", "clift_ema", "clift_last_error", "clift_version"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from contrastive_lift_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/clift.h but not exported by libclift.so"
+    assert sorted(_lib.exported_symbols()) == declared_symbols()
+    assert _lib.load().clift_version() == _lib.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from contrastive_lift_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CliftError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under contrastive_lift_amd/ may import it."""
+    pkg = os.path.join(REPO, "contrastive_lift_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle"

@@ -1,0 +1,421 @@
+"""GPU parity tests: the HIP path (through the C ABI of libclift.so) against the CPU oracle on identical seeded
+inputs and against the committed reference-generated golden vectors.
+
+Tolerance (BASELINE.json north_star): 1e-3 relative, fp32.  ``rel_close`` asserts |a-b| <= 1e-3*|b| + 1e-5*max|b|.
+Most checks pass a tighter rtol (stated per call).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, T, rel_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _import():
+    import contrastive_lift_amd as cl
+    from oracle import params as op, render as orender, field as ofld, losses as olosses, rays as orays
+    return cl, op, orender, ofld, olosses, orays
+
+
+def build_model(cl, P, res, C_, E, shift, mode="softmax"):
+    m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_,
+                         dim_feature_instance=2 * E, splus_density_shift=shift,
+                         output_mlp_semantics=(torch.nn.Softmax(dim=-1) if mode == "softmax" else torch.nn.Identity()),
+                         use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True, device=DEV)
+    missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+def scene(op, orays, seed, res, C_, E, n_rays, img=48, amp=2.5, sg=0.45):
+    P = op.add_blob(op.make_params(seed, res, C_, E), res, amplitude=amp, sigma_g=sg)
+    rng = np.random.default_rng(seed + 1)
+    K = torch.tensor([[img * 1.25, 0, img / 2], [0, img * 1.25, img / 2], [0, 0, 1]])
+
+    def look_at(eye):
+        eye = np.asarray(eye, np.float64)
+        f = -eye / np.linalg.norm(eye)
+        r = np.cross(f, [0.0, 1.0, 0.0]); r /= np.linalg.norm(r)
+        d = np.cross(f, r)
+        M = np.eye(4); M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = r, d, f, eye
+        return torch.tensor(M, dtype=torch.float32)
+    tabs = [orays.ray_table(img, img, K, look_at(e)) for e in ((0.0, 0.1, -0.9), (0.7, -0.4, 0.3), (-0.5, 0.6, 0.4))]
+    allr = torch.cat(tabs, 0)
+    pick = torch.from_numpy(rng.choice(allr.shape[0], size=n_rays, replace=False))
+    return P, allr[pick].contiguous(), rng
+
+
+# ============================================================================ GEMM building block
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 128, 152), (517, 27, 144), (257, 3, 128), (129, 150, 36), (64, 22, 7)])
+def test_gemm_matches_fp64(at, bt, M, N, K):
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + at * 2 + bt)
+    Kp = (K + 3) // 4 * 4
+    Mp = (M + 3) // 4 * 4
+    Np = (N + 3) // 4 * 4
+    A = torch.randn((K, Mp) if at else (M, Kp), generator=g)
+    B = torch.randn((K, Np) if bt else (N, Kp), generator=g)
+    bias = torch.randn(N, generator=g)
+    Aop = A[:, :M].T if at else A[:, :K]
+    Bop = B[:, :N].T if bt else B[:, :K]
+    ref = Aop.double() @ Bop.double().T + bias.double()
+    mask = torch.randn(M, N, generator=g)
+    ref_act = torch.relu(ref) * (mask > 0)
+    Ad, Bd, biasd, maskd = A.to(DEV), B.to(DEV), bias.to(DEV), mask.to(DEV).contiguous()
+    out = torch.full((M, N + 1), -7.0, device=DEV)
+    engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out, N + 1, a_trans=at, b_trans=bt, bias=biasd)
+    rel_close(out[:, :N], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="gemm")
+    assert bool((out[:, N] == -7.0).all())           # never writes outside N
+    out2 = torch.zeros((M, N), device=DEV)
+    engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out2, N, a_trans=at, b_trans=bt, bias=biasd, act=1, mask=maskd, ldmask=N)
+    rel_close(out2, ref_act, 2e-5, atol=2e-5 * float(ref.abs().max()), what="gemm relu+mask")
+    out3 = torch.ones((M, N), device=DEV)
+    engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out3, N, a_trans=at, b_trans=bt, accumulate=1, split_k=3)
+    rel_close(out3, ref - bias.double() + 1.0, 2e-5, atol=4e-5 * float(ref.abs().max()), what="gemm split-k accumulate")
+
+
+def test_gemm_transpose_detecting():
+    """A = I against an asymmetric B: a swapped C-write would pass a symmetric test."""
+    from contrastive_lift_amd import engine
+    n = 64
+    A = torch.eye(n, device=DEV)
+    B = (torch.arange(n * n, dtype=torch.float32, device=DEV).reshape(n, n) / 100).contiguous()
+    out = torch.empty((n, n), device=DEV)
+    engine.gemm(n, n, n, A, n, B, n, out, n)
+    assert torch.equal(out, B.T.contiguous())
+
+
+# ============================================================================ ray generation (a1-a3)
+def test_gen_rays_golden():
+    cl, *_ = _import()
+    g = load_golden("g1_rays")
+    rays = cl.generate_ray_table(int(g["H"]), int(g["W"]), g["K"], g["c2w"])
+    rel_close(rays[:, 0:3], g["o"], 1e-6, what="o")
+    rel_close(rays[:, 3:6], g["d"], 1e-5, what="d")
+    rel_close(rays[:, 7], g["far"], 1e-5, what="far")
+    assert float((rays[:, 6] - 0.01).abs().max()) == 0.0
+    with pytest.raises(AssertionError):
+        c2w = np.eye(4, dtype=np.float32); c2w[:3, 3] = [0, 0, -3.0]
+        cl.generate_ray_table(4, 4, np.array([[1e-3, 0, 2], [0, 1e-3, 2], [0, 0, 1]], np.float32), c2w)
+
+
+# ============================================================================ sampling / density / weights (a4-a8)
+@pytest.mark.parametrize("case", ["tiny_jitter", "tiny_plain", "mid"])
+def test_density_and_weights_vs_oracle(case):
+    cl, op, orender, ofld, olosses, orays = _import()
+    if case == "mid":
+        res, n_rays, aabb = (40, 48, 56), 700, torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    else:
+        res, n_rays, aabb = (9, 13, 17), 130, torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    P, rays, rng = scene(op, orays, 11, res, 3, 3, n_rays)
+    rays[0, 3:6] = torch.tensor([0.0, 0.0, 1.0])
+    rays[1, 0:3] = 0.0
+    jitter = None if case == "tiny_plain" else torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0)
+    with torch.no_grad():
+        (_, _, _, depth, _, dreg), aux = orender.render_forward(P, rays, cfg, jitter, False, return_aux=True)
+    from contrastive_lift_amd import engine
+    m = build_model(cl, P, res, 3, 3, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    assert r.n_samples == cfg.n_samples
+    ctx = engine._density_march(m, r, rays.to(DEV), None if jitter is None else jitter.to(DEV))
+    rel_close(ctx.w, aux["w"], 1e-4, atol=1e-7, what="weights")
+    rel_close(ctx.alpha, aux["alpha"], 1e-4, atol=2e-7, what="alpha")
+    rel_close(ctx.ray_out[:, 0], aux["opacity"], 1e-4, what="opacity")
+    rel_close(ctx.ray_out[:, 1], depth, 1e-4, what="depth")
+    rel_close(ctx.ray_out[:, 2], aux["bg"][:, 0], 1e-4, atol=1e-7, what="bg")
+    rel_close(ctx.ray_out[:, 5].mean(), dreg, 1e-4, what="dist_reg (unpinned formula)")
+    # the compacted list is exactly the oracle's active mask (threshold flips allowed only within 1e-7 of it)
+    act = torch.zeros(ctx.N * ctx.S, dtype=torch.bool)
+    act[ctx.act_idx[:ctx.M].cpu().long()] = True
+    diff = act.view(ctx.N, ctx.S) != aux["active"]
+    assert int(diff.sum()) == 0 or float((aux["w"][diff] - 1e-4).abs().max()) < 1e-7
+    assert bool((ctx.act_idx[:ctx.M][1:] > ctx.act_idx[:ctx.M][:-1]).all())       # sorted = ray-major, k ascending
+
+
+# ============================================================================ full forward + backward (a9-a13)
+def _run_forward_backward(cl, m, r, rays, jitter, white, cots):
+    for p in m.parameters():
+        p.requires_grad_(True)
+    rgb, sem, inst, depth, feats, dreg = r.forward(m, rays.to(DEV), 1.0, white, True, jitter=jitter.to(DEV), white_bg_resolved=white)
+    L = (rgb * cots[0].to(DEV)).sum() + (sem * cots[1].to(DEV)).sum() + (inst * cots[2].to(DEV)).sum()
+    if len(cots) > 3:
+        L = L + cots[3] * dreg
+    grads = torch.autograd.grad(L, list(m.parameters()), allow_unused=True)
+    return (rgb, sem, inst, depth, feats, dreg), {n: g for (n, _), g in zip(m.named_parameters(), grads)}
+
+
+@pytest.mark.parametrize("mode", ["softmax", "none"])
+@pytest.mark.parametrize("white", [False, True])
+def test_forward_backward_golden_g6(mode, white):
+    """Against the reference's own outputs and gradients (tests/golden/g6_forward.npz)."""
+    cl, op, *_ = _import()
+    g = load_golden("g6_forward")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, float(g["shift"]), mode)
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode=mode).to(DEV)
+    tag = f"{mode}_{'w' if white else 'b'}"
+    outs, grads = _run_forward_backward(cl, m, r, T(g["rays"]), T(g["jitter"]), white, (T(g["cot_rgb"]), T(g["cot_sem"]), T(g["cot_inst"])))
+    rel_close(outs[0], g[f"{tag}.rgb"], 1e-3, what="rgb")
+    rel_close(outs[1], g[f"{tag}.sem"], 1e-3, what="sem")
+    rel_close(outs[2], g[f"{tag}.inst"], 1e-3, what="inst")
+    rel_close(outs[3], g[f"{tag}.depth"], 1e-3, what="depth")
+    assert tuple(outs[4].shape) == (1, 1)
+    n = 0
+    for k, gr in grads.items():
+        key = f"{tag}.gsub.{k}"
+        if key not in g:
+            continue
+        flat = gr.detach().reshape(-1) if gr is not None else torch.zeros(1)
+        if gr is not None and gr.dim() == 4:    # channels-last view -> logical NCHW order of the fixture
+            flat = gr.detach().contiguous(memory_format=torch.contiguous_format).reshape(-1)
+        elif gr is not None:
+            flat = gr.detach().contiguous().reshape(-1)
+        sub = flat if flat.numel() <= 4096 else flat[::17]
+        ref = T(g[key]).double()
+        scale = float(T(g[f"{tag}.gnorm.{k}"])) / max(1.0, np.sqrt(flat.numel()))
+        rel_close(sub, ref, 2e-3, atol=2e-3 * max(scale, 1e-12) + 1e-9, what=key)
+        rel_close(flat.norm(), g[f"{tag}.gnorm.{k}"], 1e-3, atol=1e-9, what=f"norm {k}")
+        n += 1
+    assert n >= 30
+
+
+@pytest.mark.parametrize("mode,white", [("softmax", False), ("none", True)])
+def test_forward_backward_vs_oracle_mid(mode, white):
+    """A larger anisotropic scene (grid 40x48x56, 900 rays, C=22) including the dist-reg gradient path."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    res, C_, E, n_rays = (40, 48, 56), 22, 3, 900
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, 23, res, C_, E, n_rays, amp=2.2, sg=0.4)
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((n_rays, 3), (n_rays, C_), (n_rays, 2 * E))]
+    Pg = op.clone_params(P, requires_grad=True)
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0, semantic_weight_mode=mode)
+    o = orender.render_forward(Pg, rays, cfg, jitter, white)
+    L = (o[0] * cots[0]).sum() + (o[1] * cots[1]).sum() + (o[2] * cots[2]).sum() + 3.0 * o[5]
+    L.backward()
+    m = build_model(cl, P, res, C_, E, -3.0, mode)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode=mode).to(DEV)
+    outs, grads = _run_forward_backward(cl, m, r, rays, jitter, white, cots + [3.0])
+    for a, b, nm in zip(outs[:4], o[:4], ("rgb", "sem", "inst", "depth")):
+        rel_close(a, b.detach(), 1e-3, what=nm)
+    rel_close(outs[5], o[5].detach(), 1e-3, what="dist_reg")
+    for k, gr in grads.items():
+        ref = Pg[k].grad
+        ref = torch.zeros_like(Pg[k]) if ref is None else ref
+        got = torch.zeros_like(ref) if gr is None else gr.detach().cpu()
+        rel_close(got, ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=f"grad {k}")
+
+
+def test_instance_and_segment_golden_g7():
+    cl, op, *_ = _import()
+    g = load_golden("g7_instance_segment")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, float(g["shift"]))
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+    rays = T(g["rays"]).to(DEV)
+    inst, xyz = r.forward_instance_feature(m, rays, 0, False)
+    rel_close(inst, g["inst"], 1e-3, what="inst")
+    rel_close(xyz, g["xyz"], 1e-3, what="xyz")
+    grads = torch.autograd.grad((inst * T(g["cot_inst"]).to(DEV)).sum(), list(m.parameters()), allow_unused=True)
+    n = 0
+    for (k, _), gr in zip(m.named_parameters(), grads):
+        ref = T(g[f"inst.gsub.{k}"]).double()
+        if gr is None:
+            assert float(ref.abs().max()) == 0.0, k
+            continue
+        flat = gr.detach().contiguous().reshape(-1)
+        rel_close(flat if flat.numel() <= 4096 else flat[::17], ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=k)
+        n += 1
+    assert n >= 12
+    seg = r.forward_segment_feature(m, rays, 0, False)
+    rel_close(seg, g["seg"], 1e-3, what="seg")
+    grads = torch.autograd.grad((seg * T(g["cot_seg"]).to(DEV)).sum(), list(m.parameters()), allow_unused=True)
+    for (k, _), gr in zip(m.named_parameters(), grads):
+        ref = T(g[f"seg.gsub.{k}"]).double()
+        if gr is None:
+            assert float(ref.abs().max()) == 0.0, k
+            continue
+        flat = gr.detach().contiguous().reshape(-1)
+        rel_close(flat if flat.numel() <= 4096 else flat[::17], ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=k)
+
+
+def test_empty_and_ragged_chunks():
+    """Rays that miss the box entirely (no in-box sample, no active sample) and a single-ray chunk."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    res, C_, E = (9, 13, 17), 4, 3
+    aabb = torch.tensor([[-0.3, -0.3, -0.3], [0.3, 0.3, 0.3]])
+    P = op.add_blob(op.make_params(5, res, C_, E), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0)
+    miss = torch.tensor([[0.9, 0.9, -0.9, 0.0, 0.0, 1.0, 0.01, 1.2], [-0.8, 0.7, -0.9, 0.0, 0.0, 1.0, 0.01, 1.1]])
+    for rays, white in ((miss, False), (miss, True), (miss[:1], True)):
+        with torch.no_grad():
+            o = orender.render_forward(P, rays, cfg, None, white)
+            rgb, sem, inst, depth, _, dreg = r.forward(m, rays.to(DEV), 0, white, False)
+        rel_close(rgb, o[0], 1e-3, atol=1e-6, what="rgb (miss)")
+        rel_close(sem, o[1], 1e-3, atol=1e-5, what="sem (miss)")
+        rel_close(inst, o[2], 1e-3, atol=1e-6, what="inst (miss)")
+    hit = torch.tensor([[0.0, 0.0, -0.9, 0.0, 0.0, 1.0, 0.01, 1.9]])
+    with torch.no_grad():
+        o = orender.render_forward(P, hit, cfg, None, False)
+        rgb, sem, inst, depth, _, dreg = r.forward(m, hit.to(DEV), 0, False, False)
+    rel_close(rgb, o[0], 1e-3, what="rgb (single ray)")
+    rel_close(sem, o[1], 1e-3, what="sem (single ray)")
+
+
+# ============================================================================ losses (a16-a19), optimiser plumbing
+def test_contrastive_golden_g8():
+    cl, *_ = _import()
+    g = load_golden("g8_losses")
+    for tag in "abcd":
+        f = T(g[f"con_{tag}.f"]).to(DEV).requires_grad_(True)
+        L = cl.contrastive_loss(f, T(g[f"con_{tag}.y"]).to(DEV), 100.0)
+        rel_close(L, g[f"con_{tag}.loss"], 1e-4, atol=1e-6, what=f"contrastive {tag}")
+        gr = torch.autograd.grad(L, f)[0]
+        rel_close(gr, g[f"con_{tag}.grad"], 1e-3, atol=1e-7, what=f"contrastive grad {tag}")
+
+
+def test_slow_fast_golden_g8():
+    cl, *_ = _import()
+    g = load_golden("g8_losses")
+    for tag in "abcd":
+        f = T(g[f"sf_{tag}.feats"]).to(DEV).requires_grad_(True)
+        L = cl.slow_fast_loss(f, T(g[f"sf_{tag}.y"]).to(DEV), T(g[f"sf_{tag}.conf"]).to(DEV))
+        rel_close(L, g[f"sf_{tag}.loss"], 1e-4, atol=1e-6, what=f"slow_fast {tag}")
+        gr = torch.autograd.grad(L, f)[0]
+        rel_close(gr, g[f"sf_{tag}.grad"], 1e-3, atol=1e-7, what=f"slow_fast grad {tag}")
+
+
+def test_slow_fast_large_vs_oracle():
+    cl, op, orender, ofld, olosses, orays = _import()
+    rng = np.random.default_rng(3)
+    B, E = 1024, 3
+    f = torch.from_numpy(rng.standard_normal((B, 2 * E)).astype(np.float32) * 0.5)
+    y = torch.from_numpy(rng.zipf(1.6, size=B).clip(max=25).astype(np.int64))
+    y[:B // 2][y[:B // 2] == 7] = 26          # a label present only in the fast half
+    conf = torch.from_numpy(rng.uniform(0.1, 1, B).astype(np.float32))
+    fo = f.clone().requires_grad_(True)
+    Lo = olosses.slow_fast(fo, y, conf)
+    go = torch.autograd.grad(Lo, fo)[0]
+    fd = f.to(DEV).requires_grad_(True)
+    L = cl.slow_fast_loss(fd, y.to(DEV), conf.to(DEV))
+    rel_close(L, Lo.detach(), 1e-4, what="slow_fast 1024")
+    rel_close(torch.autograd.grad(L, fd)[0], go, 1e-3, atol=1e-8, what="slow_fast 1024 grad")
+    fo2 = f[:, :E].clone().requires_grad_(True)
+    Lc = olosses.contrastive(fo2, y, 100.0)
+    gc = torch.autograd.grad(Lc, fo2)[0]
+    fd2 = f[:, :E].contiguous().to(DEV).requires_grad_(True)
+    L2 = cl.contrastive_loss(fd2, y.to(DEV), 100.0)
+    rel_close(L2, Lc.detach(), 1e-4, what="contrastive 1024")
+    rel_close(torch.autograd.grad(L2, fd2)[0], gc, 1e-3, atol=1e-8, what="contrastive 1024 grad")
+
+
+def test_tv_golden_g9_and_total():
+    cl, op, *_ = _import()
+    g = load_golden("g9_tv")
+    res = tuple(int(x) for x in g["res"])
+    P = op.make_params(int(g["seed"]), res, 2, 3)
+    x = P["density_plane.1"].to(DEV).requires_grad_(True)
+    L = cl.TVLoss()(x)
+    rel_close(L, g["tv_plane1"], 1e-4, what="tv")
+    rel_close(torch.autograd.grad(L, x)[0], g["tv_plane1_grad"], 1e-3, atol=1e-9, what="tv grad")
+    m = build_model(cl, P, res, 2, 3, -10.0)
+    m.zero_grad_arena()
+    Lt = m.total_tv_loss(None, None, 1)
+    rel_close(Lt, g["total_tv"], 1e-4, what="total tv")
+    for k, gr in m.named_grad_views().items():
+        key = f"tv.gsub.{k}"
+        if key in g:
+            flat = gr.contiguous(memory_format=torch.contiguous_format).reshape(-1) if gr.dim() == 4 else gr.contiguous().reshape(-1)
+            rel_close(flat if flat.numel() <= 4096 else flat[::17], g[key], 1e-3, atol=1e-10, what=key)
+
+
+def test_pixel_losses_adam_ema_vs_torch():
+    from contrastive_lift_amd import _lib
+    cl, op, orender, ofld, olosses, orays = _import()
+    rng = np.random.default_rng(9)
+    N, C_ = 777, 22
+    rgb = torch.from_numpy(rng.uniform(0, 1, (N, 3)).astype(np.float32)).requires_grad_(True)
+    gt = torch.from_numpy(rng.uniform(0, 1, (N, 3)).astype(np.float32))
+    sem = torch.log(torch.softmax(torch.from_numpy(rng.standard_normal((N, C_)).astype(np.float32)), -1) + 1e-8).requires_grad_(True)
+    probs = torch.softmax(torch.from_numpy(rng.standard_normal((N, C_)).astype(np.float32)), -1)
+    conf = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
+    cw = torch.ones(C_); cw[0] = 0.0
+    mask = torch.from_numpy((rng.uniform(0, 1, N) > 0.2).astype(np.float32))
+    l_rgb = torch.nn.functional.mse_loss(rgb * mask[:, None], gt * mask[:, None])
+    l_sem = olosses.semantic_ce(sem, probs, conf * mask, cw)
+    (1.0 * l_rgb + 0.1 * l_sem).backward()
+    out2 = torch.zeros(2, device=DEV)
+    g_rgb, g_sem = torch.empty((N, 3), device=DEV), torch.empty((N, C_), device=DEV)
+    d = lambda t: t.detach().to(DEV).contiguous()
+    _lib.call("clift_pixel_losses", _lib.ptr(d(rgb)), _lib.ptr(d(gt)), _lib.ptr(d(sem)), _lib.ptr(d(probs)), _lib.ptr(d(conf)),
+              _lib.ptr(d(cw)), _lib.ptr(d(mask)), N, C_, 1.0, 0.1, _lib.ptr(out2), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
+    rel_close(out2[0], l_rgb.detach(), 1e-4, what="mse")
+    rel_close(out2[1], l_sem.detach(), 1e-4, what="ce")
+    rel_close(g_rgb, rgb.grad, 1e-3, atol=1e-9, what="g_rgb")
+    rel_close(g_sem, sem.grad, 1e-3, atol=1e-9, what="g_sem")
+    # Adam: 3 steps against torch.optim.Adam with weight decay
+    n = 10007
+    p0 = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-3)
+    pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gstep = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+        pt.grad = gstep.clone()
+        opt.step()
+        _lib.call("clift_adam", _lib.ptr(pd), _lib.ptr(gstep.to(DEV)), _lib.ptr(md), _lib.ptr(vd), n, 1e-2, 0.9, 0.99, 1e-8, 1e-3, step, _lib.stream())
+    rel_close(pd, pt.detach(), 1e-4, atol=1e-6, what="adam")
+    s, f = torch.from_numpy(rng.standard_normal(n).astype(np.float32)), torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+    sd = s.to(DEV)
+    _lib.call("clift_ema", _lib.ptr(sd), _lib.ptr(f.to(DEV)), n, 0.9, _lib.stream())
+    rel_close(sd, s * 0.9 + 0.1 * f, 1e-6, atol=1e-7, what="ema")
+
+
+# ============================================================================ full-size, size-independent properties
+def test_full_size_properties():
+    """BASELINE config sizes (4096 rays, grid 128^3 => S = 440): identities that need no oracle run.
+       (1) opacity + background transmittance == 1 per ray (telescoping product, eps 1e-10 per sample);
+       (2) compositing is linear: instance map of (fast|slow) equals the two halves composited separately, and
+           white-background rgb == black-background rgb + (1 - opacity) before the clamp;
+       (3) the compacted sample list is strictly increasing and counts match n_active;
+       (4) determinism of the forward (bit-identical on repeat)."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd import engine
+    res, C_, E, N = (128, 128, 128), 22, 3, 4096
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    P, rays, rng = scene(op, orays, 41, res, C_, E, N, img=64, amp=3.0, sg=0.35)
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    assert r.n_samples == 440
+    rays = rays.to(DEV)
+    jit = torch.rand(N, device=DEV)
+    with torch.no_grad():
+        o1, c1 = engine.render_forward(m, r, rays, jit, False)
+        o2, c2 = engine.render_forward(m, r, rays, jit, True)
+        o3, c3 = engine.render_forward(m, r, rays, jit, False)
+    rel_close(c1.ray_out[:, 0] + c1.ray_out[:, 2], torch.ones(N), 1e-5, atol=1e-5, what="opacity + bg == 1")
+    assert torch.equal(o1["rgb"], o3["rgb"]) and torch.equal(o1["semantics"], o3["semantics"]) and torch.equal(o1["instances"], o3["instances"])
+    rel_close(c2.rgb_raw, c1.rgb_raw + (1 - c1.ray_out[:, 0:1]), 1e-5, atol=1e-6, what="white bg linearity")
+    idx = c1.act_idx[:c1.M]
+    assert bool((idx[1:] > idx[:-1]).all())
+    assert int(c1.ray_start[-1]) == c1.M and c1.M == int((c1.w > 1e-4).sum())
+    frac_act = c1.M / (N * 440)
+    assert 0.02 < frac_act < 0.6, frac_act
+    # semantic map: exp(log-probs) sums to ~1 where the ray hit something
+    hit = c1.ray_out[:, 0] > 0.5
+    ps = torch.exp(o1["semantics"][hit]).sum(-1)
+    rel_close(ps, torch.ones_like(ps), 1e-3, what="sum_c exp(sem) == 1")
