@@ -208,7 +208,7 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
 
 // ============================================================================ K = 3 first layers
 // out[m][n] = act(W[n][0] x + W[n][1] y + W[n][2] z + b[n]); pure store-bandwidth kernel (tensoRF.py:475,576).
-__global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W, int ldw,
                                                         const float* __restrict__ b, int M, int Nout, int relu,
                                                         float* __restrict__ out, int ldo) {
     const int nq = Nout / 4;
@@ -219,24 +219,24 @@ __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float* w = W + (size_t)(n + j) * 3;
+        const float* w = W + (size_t)(n + j) * ldw;
         float v = fmaf(w[2], x.z, fmaf(w[1], x.y, fmaf(w[0], x.x, b[n + j])));
         o[j] = relu ? fmaxf(v, 0.f) : v;
     }
     *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, const float* b, int M, int Nout, int relu, float* out,
-                                   int ldo, clift_stream_t s) {
+extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b, int M, int Nout, int relu,
+                                   float* out, int ldo, clift_stream_t s) {
     CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
     if (M <= 0) return 0;
-    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, b, M, Nout, relu, out, ldo);
+    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo);
     return clift_check_launch("clift_linear_k3_fwd");
 }
 
 // dW[n][0..2] += sum_m dH[m][n] x[m][:], db[n] += sum_m dH[m][n].  Thread = column n, block = slab of rows.
 __global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__ x4, const float* __restrict__ dH, int ldh, int M,
-                                                        int Nout, int rows_per_block, float* __restrict__ dW, float* __restrict__ db) {
+                                                        int Nout, int rows_per_block, float* __restrict__ dW, int ldw, float* __restrict__ db) {
     const int n = blockIdx.y * 256 + threadIdx.x;
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     __shared__ float4 xs[64];
@@ -254,18 +254,18 @@ __global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__
             }
     }
     if (n < Nout) {
-        unsafeAtomicAdd(dW + (size_t)n * 3 + 0, a0);
-        unsafeAtomicAdd(dW + (size_t)n * 3 + 1, a1);
-        unsafeAtomicAdd(dW + (size_t)n * 3 + 2, a2);
+        unsafeAtomicAdd(dW + (size_t)n * ldw + 0, a0);
+        unsafeAtomicAdd(dW + (size_t)n * ldw + 1, a1);
+        unsafeAtomicAdd(dW + (size_t)n * ldw + 2, a2);
         if (db) unsafeAtomicAdd(db + n, a3);
     }
 }
 
-extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, float* db,
+extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                                    clift_stream_t s) {
     if (M <= 0) return 0;
     const int rpb = 512;
-    k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 256, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, db);
+    k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 256, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, ldw, db);
     return clift_check_launch("clift_linear_k3_bwd");
 }
 

@@ -101,7 +101,7 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
     acts = []
     W0, b0 = layers[0]
     h = torch.empty((M, W0.shape[0]), dtype=torch.float32, device=dev)
-    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], stream())
+    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], stream())
     acts.append(h)
     for W, b in layers[1:-1]:
         hn = torch.empty((M, W.shape[0]), dtype=torch.float32, device=dev)
@@ -130,7 +130,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M):
         gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
     gW, gb = glayers[0]
-    call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), ptr(gb), stream())
+    call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), _pitch(gW), ptr(gb), stream())
 
 
 # ----------------------------------------------------------------------------- forward

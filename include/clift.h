@@ -128,11 +128,12 @@ typedef struct {
 } clift_gemm_t;
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 
-/* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4). */
-int clift_linear_k3_fwd(const float* x4, const float* W, const float* b, int M, int Nout, int relu, float* out,
-                        int ldo, clift_stream_t s);
-/* dW (Nout,3) += dH^T x ; db (Nout) += colsum(dH). */
-int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, float* db,
+/* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4), W (Nout, 3)
+ * with row pitch ldw. */
+int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b, int M, int Nout, int relu,
+                        float* out, int ldo, clift_stream_t s);
+/* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
+int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         clift_stream_t s);
 /* db (N) += colsum(dY (M,N)). */
 int clift_colsum(const float* dY, int ld, int M, int N, float* db, clift_stream_t s);

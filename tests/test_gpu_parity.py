@@ -360,9 +360,9 @@ def test_pixel_losses_adam_ema_vs_torch():
     (1.0 * l_rgb + 0.1 * l_sem).backward()
     out2 = torch.zeros(2, device=DEV)
     g_rgb, g_sem = torch.empty((N, 3), device=DEV), torch.empty((N, C_), device=DEV)
-    d = lambda t: t.detach().to(DEV).contiguous()
-    _lib.call("clift_pixel_losses", _lib.ptr(d(rgb)), _lib.ptr(d(gt)), _lib.ptr(d(sem)), _lib.ptr(d(probs)), _lib.ptr(d(conf)),
-              _lib.ptr(d(cw)), _lib.ptr(d(mask)), N, C_, 1.0, 0.1, _lib.ptr(out2), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
+    keep = [t.detach().to(DEV).contiguous() for t in (rgb, gt, sem, probs, conf, cw, mask)]   # keep alive across the launch
+    _lib.call("clift_pixel_losses", *[_lib.ptr(t) for t in keep], N, C_, 1.0, 0.1, _lib.ptr(out2), _lib.ptr(g_rgb),
+              _lib.ptr(g_sem), _lib.stream())
     rel_close(out2[0], l_rgb.detach(), 1e-4, what="mse")
     rel_close(out2[1], l_sem.detach(), 1e-4, what="ce")
     rel_close(g_rgb, rgb.grad, 1e-3, atol=1e-9, what="g_rgb")
@@ -377,11 +377,13 @@ def test_pixel_losses_adam_ema_vs_torch():
         gstep = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
         pt.grad = gstep.clone()
         opt.step()
-        _lib.call("clift_adam", _lib.ptr(pd), _lib.ptr(gstep.to(DEV)), _lib.ptr(md), _lib.ptr(vd), n, 1e-2, 0.9, 0.99, 1e-8, 1e-3, step, _lib.stream())
+        gdev = gstep.to(DEV)
+        _lib.call("clift_adam", _lib.ptr(pd), _lib.ptr(gdev), _lib.ptr(md), _lib.ptr(vd), n, 1e-2, 0.9, 0.99, 1e-8, 1e-3, step, _lib.stream())
+        torch.cuda.synchronize()
     rel_close(pd, pt.detach(), 1e-4, atol=1e-6, what="adam")
     s, f = torch.from_numpy(rng.standard_normal(n).astype(np.float32)), torch.from_numpy(rng.standard_normal(n).astype(np.float32))
-    sd = s.to(DEV)
-    _lib.call("clift_ema", _lib.ptr(sd), _lib.ptr(f.to(DEV)), n, 0.9, _lib.stream())
+    sd, fd = s.to(DEV), f.to(DEV)
+    _lib.call("clift_ema", _lib.ptr(sd), _lib.ptr(fd), n, 0.9, _lib.stream())
     rel_close(sd, s * 0.9 + 0.1 * f, 1e-6, atol=1e-7, what="ema")
 
 
