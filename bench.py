@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-samples/sec of a train step of the Contrastive-Lift render hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Step = one full ``training_step`` of the reference (trainer/train_panopli_tensorf.py:148-228) at steady state:
+main pass over 4096 rays (forward of all heads, MSE + TV + confidence-weighted CE + dist-reg, backward, Adam)
+followed by the instance pass over 1024 rays (EMA, forward_instance_feature, slow-fast loss, backward, Adam).
+Workload = BASELINE.json configs[1] ("ScanNet scene0423_02, 4096 rays/batch, fp32") as a synthetic stand-in of
+the same shapes (no dataset offline): C = 22 classes, E = 3 (D = 6), grid 128^3 => S = 440 samples/ray.
+Unit = nominal ray-sample (rays x S); value = world * (4096 + 1024) * S / step time, weak scaling
+(every rank renders its own rays; one RCCL all-reduce of the gradient arena range per backward).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--inst-rays", type=int, default=1024)
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--classes", type=int, default=22)
+    ap.add_argument("--chunk", type=int, default=0, help="rays per renderer call; 0 = whole batch (reference: 2048)")
+    ap.add_argument("--lean", action="store_true", help="skip the instance heads in the main pass (their output is discarded)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import contrastive_lift_amd as cl
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+
+    model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+    S = int(renderer.n_samples)
+    cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0)
+    tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
+    n_batches = 4
+    batches = [synthetic.make_batches(pool, a.rays, a.inst_rays, a.classes, 25, seed=100 + rank * 17 + i, device=dev) for i in range(n_batches)]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        tr.training_step(batches[i % n_batches], lean=a.lean)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        tr.training_step(batches[i % n_batches], lean=a.lean)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / a.steps * 1e3
+    samples_step = world * (a.rays + a.inst_rays) * S
+    value = samples_step / (dt / a.steps)
+
+    extra = {}
+    roof = None
+    cpu = None
+    if rank == 0:
+        # ---- per-pass split and sample statistics (outside the timed region)
+        def timed(fn, n=5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        if world == 1:
+            t_main = timed(lambda: tr.main_pass(batches[0][0], lean=a.lean))
+            t_inst = timed(lambda: tr.instance_pass(batches[0][1]))
+            ctxs = tr.main_pass(batches[0][0], lean=a.lean)
+            M = sum(c.M for c in ctxs)
+            inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
+            extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
+                         main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
+                         f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
+            roof = roofline(tr, batches[0], a.lean, engine)
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(model, renderer, batches[0], a, S)
+    if rank == 0:
+        line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
+                                       "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32",
+                           "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
+                           "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean),
+                           "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
+                "roofline": roof, "cpu_baseline": cpu}
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(tr, batch, lean, engine):
+    """Instrumented step: every clift_gemm launch is bracketed by HIP events on the launch stream (torch's current
+    stream = the stream the library launches on).  achieved = sum of algorithmic GEMM flops (2*M*N*K per launch, the
+    matrix-core work of the heads; SURVEY 8d: ~1.0 MFLOP per active sample forward) / summed launch durations."""
+    rec = []
+    real = engine.gemm
+
+    def wrapped(M, N, K, *args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real(M, N, K, *args, **kw)
+        e1.record()
+        kind = ("wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd")
+        rec.append((kind, M, N, K, e0, e1))
+    engine.gemm = wrapped
+    try:
+        tr.main_pass(batch[0], lean=lean)
+        tr.instance_pass(batch[1])
+        torch.cuda.synchronize()
+    finally:
+        engine.gemm = real
+    tot_f, tot_ms, by = 0.0, 0.0, {}
+    for kind, M, N, K, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        fl = 2.0 * M * N * K
+        tot_f += fl
+        tot_ms += ms
+        b = by.setdefault(kind, [0.0, 0.0, 0])
+        b[0] += fl; b[1] += ms; b[2] += 1
+    ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32; fwd/dgrad/wgrad instantiations)",
+            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": len(rec), "avg_launch_ms": tot_ms / max(1, len(rec)), "gemm_ms_per_step": tot_ms,
+            "gflop_per_step": tot_f / 1e9,
+            "by_kind": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0, "ms": v[1], "launches": v[2]} for k, v in by.items()}}
+
+
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(model, renderer, batch, a, S):
+    """The oracle (CPU-PyTorch restatement of the reference path, same ATen ops / shapes / chunk 2048) timed on the
+    host cores of this box: 1 warm-up + up to 3 full-size steps within the budget."""
+    from oracle import render as orender
+    from oracle.train_step import CpuTrainer
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    P = {k: v.detach().cpu() for k, v in model.export_state_dict().items()}
+    cfg = orender.RenderCfg(renderer.bbox_aabb.cpu(), tuple(int(x) for x in renderer.grid_dim.tolist()), density_shift=-3.0)
+    ct = CpuTrainer(P, cfg, chunk=2048, epoch=4)
+    b0, b1 = batch[0], batch[1][0]
+    rays, rgbs, probs, conf = (b0[k].cpu() for k in ("rays", "rgbs", "probabilities", "confidences"))
+    ir, il, ic = b1["rays"].cpu(), b1["instances"].cpu(), b1["confidences"].cpu()
+    g = torch.Generator().manual_seed(1)
+
+    def step():
+        jit = torch.rand(rays.shape[0], generator=g)
+        ct.main_pass(rays, rgbs, probs, conf, jit, [False] * ((rays.shape[0] + 2047) // 2048))
+        ct.instance_pass(ir, il, ic, torch.rand(ir.shape[0], generator=g))
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    ts = []
+    while len(ts) < 3 and (time.perf_counter() - t0) + warm < a.cpu_budget_s:
+        t = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t)
+    if not ts:
+        ts = [warm]
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": (a.rays + a.inst_rays) * S / med, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts)} full-size training_step(s) after 1 warm-up ({a.rays}+{a.inst_rays} rays x S={S}, chunk 2048, "
+                      f"torch {torch.__version__} CPU, {cores} threads), median {med:.2f} s/step",
+            "s_per_step": med}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+"""Training step of the hot path -- mirror of reference trainer/train_panopli_tensorf.py:98-103 (optimizers),
+:105-146 (chunked forwards), :148-228 (training_step), :256-310 + :325-329 (slow-fast loss + EMA), :446-447
+(dist-reg ramp), driven directly through engine.py (no autograd graph, no Lightning).
+
+Data-parallel: one process per GPU; every rank renders its own shard of the ray batch; after each backward ONE
+all-reduce (RCCL over xGMI, `torch.distributed` backend "nccl") sums the contiguous gradient range of the arena
+that the pass touched -- the reference's DDP does the same exchange bucket by bucket, twice per step
+(SURVEY 2a/2b).  The slow net is an EMA of synchronised fast weights, so it needs no exchange.
+"""
+import math
+import types
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, engine
+from .loss import slow_fast_loss
+
+
+def default_config(**over):
+    """Hot-path keys of config/template/panopli_paper.yaml with the contrastive-lift overlays
+    (config/experiment/contrastive_lift*.yaml)."""
+    c = dict(lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
+             lambda_tv_density=0.1, lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02,
+             late_semantic_optimization=1, instance_optimization_epoch=3, chunk=2048, perturb=1.0, batch_size=2048,
+             max_rays_instances=1024, max_instances=3, instance_loss_mode="slow_fast", use_DINO_style=True,
+             semantic_weight_mode="softmax", stop_semantic_grad=True, probabilistic_ce_mode="TTAConf", weight_class_0=0.0,
+             decay_step=[9, 10], decay_gamma=0.5, temperature=100.0, white_bg=False)
+    c.update(over)
+    return types.SimpleNamespace(**c)
+
+
+class ArenaAdam:
+    """torch.optim.Adam semantics (trainer/__init__.py:134-135) over contiguous arena ranges: one clift_adam launch
+    per (lr, weight_decay) range.  ``ranges`` = [(start, end, lr)]."""
+
+    def __init__(self, model, ranges, betas, weight_decay, eps=1e-8):
+        self.model, self.ranges, self.betas, self.wd, self.eps = model, ranges, betas, weight_decay, eps
+        self.m = torch.zeros_like(model.param_flat)
+        self.v = torch.zeros_like(model.param_flat)
+        self.t = 0
+        self.lr_scale = 1.0
+
+    def step(self):
+        self.t += 1
+        p, g = self.model.param_flat, self.model.grad_flat
+        st = _lib.stream()
+        for a, b, lr in self.ranges:
+            _lib.call("clift_adam", _lib.ptr(p[a:b]), _lib.ptr(g[a:b]), _lib.ptr(self.m[a:b]), _lib.ptr(self.v[a:b]), b - a,
+                      float(lr * self.lr_scale), self.betas[0], self.betas[1], self.eps, float(self.wd), self.t, st)
+
+
+class HotPathTrainer:
+    """Owns field + renderer + the two Adam optimizers; ``training_step`` = main pass + instance pass."""
+
+    def __init__(self, model, renderer, config, class_weights=None, current_epoch=0):
+        self.model, self.renderer, self.config = model, renderer, config
+        self.device = model.param_flat.device
+        self.current_epoch = current_epoch
+        C = model.num_semantic_classes
+        cw = torch.ones(C) if class_weights is None else torch.as_tensor(class_weights, dtype=torch.float32).clone()
+        if class_weights is None:
+            cw[0] = config.weight_class_0                              # T:70
+        self.class_weights = cw.to(self.device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.setup_optimizers()
+        self.on_train_epoch_start()
+        self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)   # rgb, sem, tv, clustering (last step)
+
+    # ------------------------------------------------------------------ optimizers (T:98-103)
+    def setup_optimizers(self):
+        m, c = self.model, self.config
+        a0, a1 = m.arena.range_of("grid_density", "grid_app")
+        b0, b1 = m.arena.range_of("net_main")
+        self.opt_main = ArenaAdam(m, [(a0, a1, c.lr * 20), (b0, b1, c.lr)], (0.9, 0.99), c.weight_decay)
+        self.main_range = m.arena.range_of("grid_density", "grid_app", "net_main")
+        groups = ["inst_fast"] + (["inst_slow"] if (m.slow_fast_mode and not c.use_DINO_style) else [])
+        i0, i1 = m.arena.range_of(*groups)
+        self.opt_inst = ArenaAdam(m, [(i0, i1, c.lr)], (0.9, 0.999), c.weight_decay)
+        self.inst_range = (i0, i1)
+
+    def on_train_epoch_start(self):
+        """T:447: dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch))."""
+        self.current_lambda_dist_reg = self.config.lambda_dist_reg * (1 - math.exp(-0.25 * self.current_epoch))
+
+    def _allreduce(self, rng):
+        if self.world > 1:
+            g = self.model.grad_flat[rng[0]:rng[1]]
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.mul_(1.0 / self.world)
+
+    # ------------------------------------------------------------------ main pass (T:151-208)
+    def main_pass(self, batch, jitter=None, white_bg=None, lean=False):
+        """batch: dict with rays (B,8), rgbs (B,3), probabilities (B,C), confidences (B,), mask (B,) bool/float.
+        ``lean`` skips the instance heads, whose output the reference's main pass computes and discards (T:155)."""
+        c, m, r = self.config, self.model, self.renderer
+        rays = batch["rays"]
+        B = rays.shape[0]
+        m.grad_flat[self.main_range[0]:self.main_range[1]].zero_()
+        if jitter is None and c.perturb != 0:
+            jitter = c.perturb * torch.rand(B, device=self.device)
+        chunk = c.chunk if c.chunk and c.chunk > 0 else B
+        ctxs, outs = [], []
+        for i in range(0, B, chunk):
+            if white_bg is None:
+                wb = bool(c.white_bg) or bool(torch.rand((1,)) < 0.5)       # renderer.py:164
+            else:
+                wb = bool(white_bg)
+            o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,
+                                           want_inst=not lean)
+            ctxs.append(ctx)
+            outs.append(o)
+        rgb = outs[0]["rgb"] if len(outs) == 1 else torch.cat([o["rgb"] for o in outs], 0)
+        sem = outs[0]["semantics"] if len(outs) == 1 else torch.cat([o["semantics"] for o in outs], 0)
+        sem_on = self.current_epoch >= c.late_semantic_optimization
+        w_rgb = float(c.lambda_rgb)
+        w_sem = float(c.lambda_semantics) if sem_on else 0.0
+        g_rgb = torch.empty_like(rgb)
+        g_sem = torch.empty_like(sem)
+        mask = batch.get("mask")
+        maskf = mask.to(torch.float32) if mask is not None else None
+        self.losses.zero_()
+        _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
+                  _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
+                  _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
+        g_dist = torch.full((1,), w_rgb * self.current_lambda_dist_reg / len(ctxs), dtype=torch.float32, device=self.device)
+        gv = m.named_grad_views()
+        for k, ctx in enumerate(ctxs):
+            s = slice(k * chunk, k * chunk + ctx.N)
+            engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True)
+        tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
+        self.losses[2] = tv
+        self._allreduce(self.main_range)
+        self.opt_main.step()
+        self.last_outputs = (rgb, sem)
+        return ctxs
+
+    # ------------------------------------------------------------------ instance pass (T:210-222, 256-310)
+    def instance_pass(self, inst_batch, jitter=None):
+        """inst_batch: list of dicts (one per image) with rays (n,8), instances (n,) int, confidences (n,)."""
+        c, m, r = self.config, self.model, self.renderer
+        if c.instance_loss_mode != "slow_fast":
+            raise NotImplementedError("HotPathTrainer: only instance_loss_mode='slow_fast' is wired (contrastive via "
+                                      "contrastive_lift_amd.contrastive_loss)")
+        m.grad_flat[self.inst_range[0]:self.inst_range[1]].zero_()
+        gv = m.named_grad_views()
+        for img in inst_batch:
+            rays = img["rays"]
+            n = rays.shape[0]
+            jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
+            # EMA first (T:258-259): one fused axpy over the contiguous fast/slow arena ranges
+            f0, f1 = m.arena.range_of("inst_fast")
+            s0, s1 = m.arena.range_of("inst_slow")
+            _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
+            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance")
+            loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
+            self.losses[3] = self.losses[3] + loss
+            engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
+        self._allreduce(self.inst_range)
+        self.opt_inst.step()
+
+    def training_step(self, batch, lean=False):
+        """batch[0] = pixel batch dict, batch[1] = list of instance-image dicts (reference CombinedLoader layout)."""
+        self.main_pass(batch[0], lean=lean)
+        if self.current_epoch >= self.config.instance_optimization_epoch and batch.get(1):
+            self.instance_pass(batch[1])
+
+    # ------------------------------------------------------------------ checkpoint (Lightning layout)
+    def state_dict_lightning(self):
+        sd = {f"model.{k}": v for k, v in self.model.export_state_dict().items()}
+        for k, v in self.renderer.state_dict().items():
+            sd[f"renderer.{k}"] = v.detach().clone()
+        sd["loss_semantics.weight"] = self.class_weights.detach().clone()
+        return sd
+
+    def save_checkpoint(self, path, global_step=0):
+        torch.save({"state_dict": self.state_dict_lightning(), "epoch": self.current_epoch, "global_step": global_step,
+                    "pytorch-lightning_version": "2.0.4"}, path)

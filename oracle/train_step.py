@@ -1,0 +1,66 @@
+"""Oracle: one training_step of the hot path on the CPU (reference trainer/train_panopli_tensorf.py:148-228):
+main pass (chunked forward, MSE + TV + confidence-weighted CE + dist-reg, backward, Adam betas (0.9,0.99)) and
+instance pass (forward_instance_feature, slow-fast loss after the EMA step, backward, Adam betas (0.9,0.999)).
+
+Test infrastructure only (see oracle/__init__.py).  It is what ``bench.py`` times as ``cpu_baseline`` (kind
+"port": same ATen ops, same shapes and chunking as the reference's CPU-PyTorch path) and what the GPU training
+step is checked against in tests/.
+"""
+import math
+
+import torch
+
+from . import losses as olosses
+from . import render as orender
+
+GRID_KEYS = ("density_plane", "density_line", "appearance_plane", "appearance_line")
+
+
+class CpuTrainer:
+    def __init__(self, P, cfg, lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
+                 lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True):
+        self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+        self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
+        self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
+        self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
+        grids = [v for k, v in self.P.items() if k.startswith(GRID_KEYS)]
+        nets = [v for k, v in self.P.items() if not k.startswith(GRID_KEYS) and not k.startswith("render_instance_mlp")]
+        self.main_params = grids + nets
+        self.opt_main = torch.optim.Adam([{"params": grids, "lr": lr * 20}, {"params": nets, "lr": lr}], lr=lr,
+                                         weight_decay=weight_decay, betas=(0.9, 0.99))     # T:99-100
+        self.fast = [v for k, v in self.P.items() if k.startswith("render_instance_mlp.mlp.")]
+        self.slow = [v for k, v in self.P.items() if k.startswith("render_instance_mlp.slow_mlp.")]
+        self.opt_inst = torch.optim.Adam([{"params": self.fast + ([] if dino else self.slow), "lr": lr}], lr=lr,
+                                         weight_decay=weight_decay, betas=(0.9, 0.999))    # T:101-102
+        C = self.P[[k for k in self.P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".bias")][-1]].shape[0]
+        self.cw = torch.ones(C) if class_weights is None else class_weights
+        if class_weights is None:
+            self.cw[0] = 0.0
+
+    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags):
+        self.opt_main.zero_grad(set_to_none=True)
+        for p in self.fast + self.slow:
+            p.grad = None
+        outs = []
+        for ci, i in enumerate(range(0, rays.shape[0], self.chunk)):
+            jit = None if jitter is None else jitter[i:i + self.chunk]
+            outs.append(orender.render_forward(self.P, rays[i:i + self.chunk], self.cfg, jit, bool(white_flags[ci])))
+        rgb = torch.cat([o[0] for o in outs])
+        sem = torch.cat([o[1] for o in outs])
+        dreg = torch.stack([o[5] for o in outs]).mean()
+        l_rgb = torch.nn.functional.mse_loss(rgb, rgbs)
+        l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva)
+        l_sem = olosses.semantic_ce(sem, probs, conf, self.cw)
+        loss = self.l_rgb * (l_rgb + l_tv + dreg * self.l_dist) + self.l_sem * l_sem
+        loss.backward()
+        self.opt_main.step()
+        return dict(rgb=rgb.detach(), sem=sem.detach(), loss_rgb=l_rgb.detach(), loss_sem=l_sem.detach(), loss_tv=l_tv.detach())
+
+    def instance_pass(self, rays, labels, conf, jitter):
+        self.opt_inst.zero_grad(set_to_none=True)
+        olosses.ema_(self.slow, self.fast, 0.9)
+        inst, xyz = orender.render_instance_feature(self.P, rays, self.cfg, jitter)
+        loss = olosses.slow_fast(inst, labels, conf)
+        loss.backward()
+        self.opt_inst.step()
+        return dict(loss=loss.detach(), inst=inst.detach())
