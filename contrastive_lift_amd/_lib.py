@@ -23,7 +23,7 @@ class VM(C.Structure):
 
 
 class VMGrad(C.Structure):
-    _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3)]
+    _fields_ = [("plane", C.c_void_p * 3), ("line", C.c_void_p * 3), ("xcd_stride", C.c_long)]
 
 
 class March(C.Structure):
@@ -51,6 +51,7 @@ _SIGNATURES = {
     "clift_march_fwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "clift_march_bwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "clift_density_bwd": ([_P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_xcd_reduce": ([_P, _L, _L, _P, _P], C.c_int),
     "clift_scan_counts": ([_P, _I, _P, _P], C.c_int),
     "clift_compact_fill": ([_P, _P, _I, _I, _F, _P, _P], C.c_int),
     "clift_app_gather_fwd": ([_P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),

@@ -38,6 +38,7 @@ struct VmP {
 struct VmG {
     float* plane[3];
     float* line[3];
+    long xcd_stride;  // floats between the 8 per-XCD accumulation copies; 0 = single copy, device-scope atomics
 };
 
 static inline MarchP to_dev(const clift_march_t* m) {
@@ -56,6 +57,7 @@ static inline VmP to_dev(const clift_vm_t* v) {
 static inline VmG to_dev(const clift_vm_grad_t* g) {
     VmG p;
     for (int i = 0; i < 3; ++i) { p.plane[i] = g->plane[i]; p.line[i] = g->line[i]; }
+    p.xcd_stride = g->xcd_stride;
     return p;
 }
 
@@ -178,6 +180,18 @@ __device__ __forceinline__ float f4_hsum(float4 a) { return (a.x + a.y) + (a.z +
 __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
     unsafeAtomicAdd(p + 0, v.x); unsafeAtomicAdd(p + 1, v.y); unsafeAtomicAdd(p + 2, v.z); unsafeAtomicAdd(p + 3, v.w);
 }
+// XCD-private accumulation.  MI355X has 8 XCDs with private, mutually non-coherent L2s; a device-scope fp32 atomic
+// is one fabric transaction to the memory side (measured here: ~40-75 G atomics/s).  An atomic that only has to be
+// coherent inside one XCD executes in that XCD's L2.  Each XCD therefore accumulates into its OWN copy of the
+// gradient table, selected by the hardware XCC id (read from HW_REG_XCC_ID, so it is correct for any
+// workgroup->XCD placement), and a streaming kernel sums the 8 copies afterwards (kernel boundary = L2 write-back).
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7; }
+__device__ __forceinline__ void atomic_add4_xcd(float* p, float4 v) {
+    __hip_atomic_fetch_add(p + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // matrix_mode / vector_mode of the reference (tensoRF.py:61-62)
 __device__ __forceinline__ void vm_axes(int i, int& a, int& b, int& v) {
@@ -219,18 +233,74 @@ __device__ __forceinline__ float4 vm_line4(const VmP& t, int i, const VmTaps& k,
     acc = f4_fma(k.tz.w1, ld4(p + (size_t)k.tz.i1 * C + c4), acc);
     return acc;
 }
-// scatter d(plane*line) for one 4-channel group: gP = upstream * line value, gL = upstream * plane value
-__device__ __forceinline__ void vm_scatter4(const VmP& t, const VmG& g, int i, const VmTaps& k, int c4, float4 gP, float4 gL) {
+// scatter d(plane*line) for one 4-channel group: gP = upstream * line value, gL = upstream * plane value.
+// Plane taps go to global memory (per-XCD copy when xcd_stride > 0).  Line taps: every sample of the batch hits
+// the same few hundred line texels, so global atomics on them serialise thousands-deep; with LDS_LINES the block
+// accumulates them in LDS (lds_line = this line's [R][C] slab) and flushes once at the end (scatter_flush_lines).
+template <bool XCD, bool LDS_LINES>
+__device__ __forceinline__ void vm_scatter4_t(const VmP& t, const VmG& g, int i, const VmTaps& k, int c4, float4 gP, float4 gL, size_t xoff,
+                                              float* lds_line) {
     int a, b, v;
     vm_axes(i, a, b, v);
     const int W = t.res[a], C = t.comps;
-    float* p = g.plane[i];
-    float* l = g.line[i];
+    float* p = g.plane[i] + xoff;
     const float w00 = k.tx.w0 * k.ty.w0, w10 = k.tx.w1 * k.ty.w0, w01 = k.tx.w0 * k.ty.w1, w11 = k.tx.w1 * k.ty.w1;
-    if (w00 != 0.f) atomic_add4(p + ((size_t)k.ty.i0 * W + k.tx.i0) * C + c4, f4_scale(w00, gP));
-    if (w10 != 0.f) atomic_add4(p + ((size_t)k.ty.i0 * W + k.tx.i1) * C + c4, f4_scale(w10, gP));
-    if (w01 != 0.f) atomic_add4(p + ((size_t)k.ty.i1 * W + k.tx.i0) * C + c4, f4_scale(w01, gP));
-    if (w11 != 0.f) atomic_add4(p + ((size_t)k.ty.i1 * W + k.tx.i1) * C + c4, f4_scale(w11, gP));
-    if (k.tz.w0 != 0.f) atomic_add4(l + (size_t)k.tz.i0 * C + c4, f4_scale(k.tz.w0, gL));
-    if (k.tz.w1 != 0.f) atomic_add4(l + (size_t)k.tz.i1 * C + c4, f4_scale(k.tz.w1, gL));
+#define CLIFT_ADD4(ptr, val) do { if (XCD) atomic_add4_xcd(ptr, val); else atomic_add4(ptr, val); } while (0)
+    if (w00 != 0.f) CLIFT_ADD4(p + ((size_t)k.ty.i0 * W + k.tx.i0) * C + c4, f4_scale(w00, gP));
+    if (w10 != 0.f) CLIFT_ADD4(p + ((size_t)k.ty.i0 * W + k.tx.i1) * C + c4, f4_scale(w10, gP));
+    if (w01 != 0.f) CLIFT_ADD4(p + ((size_t)k.ty.i1 * W + k.tx.i0) * C + c4, f4_scale(w01, gP));
+    if (w11 != 0.f) CLIFT_ADD4(p + ((size_t)k.ty.i1 * W + k.tx.i1) * C + c4, f4_scale(w11, gP));
+    if (LDS_LINES) {
+        if (k.tz.w0 != 0.f) { float* q = lds_line + k.tz.i0 * C + c4; const float4 x = f4_scale(k.tz.w0, gL);
+            atomicAdd(q, x.x); atomicAdd(q + 1, x.y); atomicAdd(q + 2, x.z); atomicAdd(q + 3, x.w); }
+        if (k.tz.w1 != 0.f) { float* q = lds_line + k.tz.i1 * C + c4; const float4 x = f4_scale(k.tz.w1, gL);
+            atomicAdd(q, x.x); atomicAdd(q + 1, x.y); atomicAdd(q + 2, x.z); atomicAdd(q + 3, x.w); }
+    } else {
+        float* l = g.line[i] + xoff;
+        if (k.tz.w0 != 0.f) CLIFT_ADD4(l + (size_t)k.tz.i0 * C + c4, f4_scale(k.tz.w0, gL));
+        if (k.tz.w1 != 0.f) CLIFT_ADD4(l + (size_t)k.tz.i1 * C + c4, f4_scale(k.tz.w1, gL));
+    }
+#undef CLIFT_ADD4
+}
+template <bool LDS_LINES>
+__device__ __forceinline__ void vm_scatter4(const VmP& t, const VmG& g, int i, const VmTaps& k, int c4, float4 gP, float4 gL, size_t xoff,
+                                            float* lds_line) {
+    if (g.xcd_stride > 0) vm_scatter4_t<true, LDS_LINES>(t, g, i, k, c4, gP, gL, xoff, lds_line);
+    else vm_scatter4_t<false, LDS_LINES>(t, g, i, k, c4, gP, gL, xoff, lds_line);
+}
+// LDS line accumulators: slab i starts at line_lds_offset(t, i) floats, size res[v_i]*comps.
+__device__ __forceinline__ int line_lds_offset(const VmP& t, int i) {
+    int off = 0;
+    for (int j = 0; j < i; ++j) off += t.res[2 - j] * t.comps;
+    return off;
+}
+__host__ __device__ __forceinline__ int line_lds_floats(const int res[3], int comps) { return (res[0] + res[1] + res[2]) * comps; }
+// Launch geometry of the persistent scatter kernels: as many resident threads per CU as the LDS line slab allows
+// (160 KiB LDS per CU): <= 40 KiB -> 4 x 256 threads, <= 80 KiB -> 2 x 512, <= 160 KiB -> 1 x 1024, else no LDS slab.
+static inline bool scatter_geometry(int lds_bytes, int* threads, int* per_cu) {
+    if (lds_bytes <= 40 * 1024) { *threads = 256; *per_cu = 4; return true; }
+    if (lds_bytes <= 80 * 1024) { *threads = 512; *per_cu = 2; return true; }
+    if (lds_bytes <= 160 * 1024 - 512) { *threads = 1024; *per_cu = 1; return true; }
+    *threads = 256; *per_cu = 4;
+    return false;
+}
+__device__ __forceinline__ void scatter_zero_lines(float* lds, int n) {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) lds[e] = 0.f;
+    __syncthreads();
+}
+__device__ __forceinline__ void scatter_flush_lines(const VmP& t, const VmG& g, float* lds, size_t xoff) {
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int n = t.res[2 - i] * t.comps;
+        float* dst = g.line[i] + xoff;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const float v = lds[base + e];
+            if (v != 0.f) {
+                if (g.xcd_stride > 0) __hip_atomic_fetch_add(dst + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else unsafeAtomicAdd(dst + e, v);
+            }
+        }
+        base += n;
+    }
 }

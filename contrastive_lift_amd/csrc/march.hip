@@ -48,47 +48,97 @@ extern "C" int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_d
 }
 
 // ============================================================================ density backward
-__global__ __launch_bounds__(256) void k_density_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
-                                                      const float* __restrict__ jitter, long total,
-                                                      const float* __restrict__ dsigma) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long s = gid >> 2;
-    const int q = (int)(gid & 3);
-    if (s >= total) return;
-    const float ds = dsigma[s];
-    if (ds == 0.f) return;  // uniform over the 4 lanes of a sample
-    const int r = (int)(s / m.S), k = (int)(s - (long)r * m.S);
-    const RayG g = load_ray(rays, r, m);
-    const float jit = jitter ? jitter[r] : 0.f;
-    float xn[3];
-    if (!sample_xn(g, m, sample_z(g, m, k, jit), xn)) return;
-    // recompute sigma_raw for the softplus derivative (comps <= 16*4 handled by the strided loop)
-    float acc = 0.f;
-    VmTaps tp[3];
+// Persistent blocks (grid-stride over samples), `comps` lanes per sample with ONE CHANNEL PER LANE (comps = 4..64,
+// power of two; 16 in the reference configs => 4 samples per wave): every atomic instruction covers whole 64-byte
+// texels.  Line gradients accumulate in LDS and are flushed once per block, plane gradients go to the per-XCD
+// accumulation copies (clift_dev.h).
+template <bool LDS_LINES>
+__global__ __launch_bounds__(1024) void k_density_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
+                                                       const float* __restrict__ jitter, long total, int lg_c,
+                                                       const float* __restrict__ dsigma) {
+    extern __shared__ __attribute__((aligned(16))) float lds_lines[];
+    const int nl = line_lds_floats(t.res, t.comps);
+    if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
+    const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
+    const int C = t.comps;
+    const long nthreads = (long)gridDim.x * blockDim.x;      // multiple of 64 >= C: the C lanes of a sample iterate together
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < (total << lg_c); gid += nthreads) {
+        const long s = gid >> lg_c;
+        const int c = (int)(gid & (C - 1));
+        const float ds = dsigma[s];
+        if (ds == 0.f) continue;  // uniform over the lanes of a sample
+        const int r = (int)(s / m.S), k = (int)(s - (long)r * m.S);
+        const RayG g = load_ray(rays, r, m);
+        float xn[3];
+        if (!sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn)) continue;
+        float P[3], L[3], w4[3][4], wz[3][2];
+        size_t o4[3][4];
+        int oz[3][2];
+        float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        tp[i] = vm_taps(t, i, xn);
-        for (int c4 = q * 4; c4 < t.comps; c4 += 16) acc += f4_hsum(f4_mul(vm_plane4(t, i, tp[i], c4), vm_line4(t, i, tp[i], c4)));
-    }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    const float x = acc + m.shift;
-    const float dsp = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
-    const float up = ds * dsp;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        for (int c4 = q * 4; c4 < t.comps; c4 += 16) {
-            const float4 P = vm_plane4(t, i, tp[i], c4), L = vm_line4(t, i, tp[i], c4);
-            vm_scatter4(t, gr, i, tp[i], c4, f4_scale(up, L), f4_scale(up, P));
+        for (int i = 0; i < 3; ++i) {
+            const VmTaps tp = vm_taps(t, i, xn);
+            int a, b, v;
+            vm_axes(i, a, b, v);
+            const int W = t.res[a];
+            o4[i][0] = ((size_t)tp.ty.i0 * W + tp.tx.i0) * C + c; o4[i][1] = ((size_t)tp.ty.i0 * W + tp.tx.i1) * C + c;
+            o4[i][2] = ((size_t)tp.ty.i1 * W + tp.tx.i0) * C + c; o4[i][3] = ((size_t)tp.ty.i1 * W + tp.tx.i1) * C + c;
+            w4[i][0] = tp.tx.w0 * tp.ty.w0; w4[i][1] = tp.tx.w1 * tp.ty.w0; w4[i][2] = tp.tx.w0 * tp.ty.w1; w4[i][3] = tp.tx.w1 * tp.ty.w1;
+            oz[i][0] = tp.tz.i0 * C + c; oz[i][1] = tp.tz.i1 * C + c;
+            wz[i][0] = tp.tz.w0; wz[i][1] = tp.tz.w1;
+            const float* pp = t.plane[i];
+            const float* lp = t.line[i];
+            P[i] = fmaf(w4[i][3], pp[o4[i][3]], fmaf(w4[i][2], pp[o4[i][2]], fmaf(w4[i][1], pp[o4[i][1]], w4[i][0] * pp[o4[i][0]])));
+            L[i] = fmaf(wz[i][1], lp[oz[i][1]], wz[i][0] * lp[oz[i][0]]);
+            acc = fmaf(P[i], L[i], acc);
         }
+        for (int d = 1; d < C; d <<= 1) acc += __shfl_xor(acc, d);
+        const float x = acc + m.shift;
+        const float up = ds * ((x > 20.f) ? 1.f : 1.f / (1.f + expf(-x)));
+        int loff = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float gP = up * L[i], gL = up * P[i];
+            float* gp = gr.plane[i] + xoff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (w4[i][q] != 0.f) {
+                    if (gr.xcd_stride > 0) __hip_atomic_fetch_add(gp + o4[i][q], w4[i][q] * gP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else unsafeAtomicAdd(gp + o4[i][q], w4[i][q] * gP);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (wz[i][q] != 0.f) {
+                    if (LDS_LINES) atomicAdd(lds_lines + loff + oz[i][q], wz[i][q] * gL);
+                    else if (gr.xcd_stride > 0) __hip_atomic_fetch_add(gr.line[i] + xoff + oz[i][q], wz[i][q] * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else unsafeAtomicAdd(gr.line[i] + oz[i][q], wz[i][q] * gL);
+                }
+            loff += t.res[2 - i] * C;
+        }
+    }
+    if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
 
 extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const clift_vm_grad_t* h_grad,
                                  const float* rays, const float* jitter, int N, const float* dsigma, clift_stream_t s) {
-    CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_density_bwd: comps must be a multiple of 4");
+    const int Cc = h_dens->comps;
+    CLIFT_REQUIRE(Cc >= 4 && Cc <= 64 && (Cc & (Cc - 1)) == 0, "clift_density_bwd: comps must be a power of two in [4,64] (got %d)", Cc);
     if (N <= 0) return 0;
+    int lg = 0;
+    while ((1 << lg) < Cc) ++lg;
     const long total = (long)N * h_m->n_samples;
-    k_density_bwd<<<cdiv(total * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, dsigma);
+    const int lds_bytes = line_lds_floats(h_dens->res, Cc) * 4;
+    int threads, per_cu;
+    const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
+    const int want = cdiv(total << lg, threads);
+    const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
+    if (use_lds) {
+        if (lds_bytes > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        k_density_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, lg, dsigma);
+    } else {
+        k_density_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, lg, dsigma);
+    }
     return clift_check_launch("clift_density_bwd");
 }
 
@@ -260,4 +310,28 @@ extern "C" int clift_compact_fill(const float* w, const int* ray_start, int N, i
     CLIFT_REQUIRE((long)N * S < 2147483647L, "clift_compact_fill: N*S overflows int32 sample ids");
     k_compact_fill<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(w, ray_start, N, S, thres, act_idx);
     return clift_check_launch("clift_compact_fill");
+}
+
+// ============================================================================ fold the 8 per-XCD accumulation copies
+__global__ __launch_bounds__(256) void k_xcd_reduce(float* __restrict__ work, long stride, long n4, float* __restrict__ dst) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 acc = *reinterpret_cast<const float4*>(dst + i * 4);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            float4* w = reinterpret_cast<float4*>(work + (size_t)x * stride + i * 4);
+            const float4 v = *w;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            *w = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4*>(dst + i * 4) = acc;
+    }
+}
+
+extern "C" int clift_xcd_reduce(float* work, long xcd_stride, long n, float* dst, clift_stream_t s) {
+    CLIFT_REQUIRE(n % 4 == 0 && xcd_stride % 4 == 0, "clift_xcd_reduce: n and xcd_stride must be multiples of 4");
+    if (n <= 0) return 0;
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    k_xcd_reduce<<<blocks, 256, 0, as_stream(s)>>>(work, xcd_stride, n4, dst);
+    return clift_check_launch("clift_xcd_reduce");
 }

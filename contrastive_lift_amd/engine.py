@@ -12,6 +12,7 @@ Per chunk of N rays (reference renderer.py:80-176):
   composite.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -44,12 +45,39 @@ def vm_struct(views, prefix, res):
     return v
 
 
-def vm_grad_struct(gviews, prefix):
+XCD_PRIVATE = os.environ.get("CLIFT_XCD_PRIVATE", "1") != "0"
+_GROUP_OF = {"density": "grid_density", "appearance": "grid_app"}
+
+
+def vm_grad_struct(model, gviews, prefix):
+    """Gradient target of a scatter kernel.  Default: eight per-XCD accumulation copies (model-owned, persistent,
+    zero between uses) that ``vm_grad_finish`` folds into ``gviews``; CLIFT_XCD_PRIVATE=0: the final tables directly
+    with device-scope atomics."""
     g = VMGrad()
+    if not XCD_PRIVATE:
+        for i in range(3):
+            g.plane[i] = gviews[f"{prefix}_plane.{i}"].data_ptr()
+            g.line[i] = gviews[f"{prefix}_line.{i}"].data_ptr()
+        g.xcd_stride = 0
+        return g
+    a, b = model.arena.range_of(_GROUP_OF[prefix])
+    n = b - a
+    work = model.xcd_workspace(prefix, 8 * n)
+    base = work.data_ptr()
     for i in range(3):
-        g.plane[i] = gviews[f"{prefix}_plane.{i}"].data_ptr()
-        g.line[i] = gviews[f"{prefix}_line.{i}"].data_ptr()
+        g.plane[i] = base + 4 * (model.arena.by_name[f"{prefix}_plane.{i}"].offset - a)
+        g.line[i] = base + 4 * (model.arena.by_name[f"{prefix}_line.{i}"].offset - a)
+    g.xcd_stride = n
     return g
+
+
+def vm_grad_finish(model, gviews, prefix, g):
+    if g.xcd_stride > 0:
+        a, b = model.arena.range_of(_GROUP_OF[prefix])
+        work = model.xcd_workspace(prefix, 8 * (b - a))
+        # the tables of one group are contiguous in every arena-layout buffer, starting at plane 0
+        dst = gviews[f"{prefix}_plane.0"]
+        call("clift_xcd_reduce", ptr(work), g.xcd_stride, b - a, C.c_void_p(dst.data_ptr()), stream())
 
 
 def grid_res(views):
@@ -332,9 +360,10 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
             gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             va = vm_struct(views, "appearance", ctx.res)
-            ga = vm_grad_struct(gviews, "appearance")
+            ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
                  ptr(ctx.act_idx), M, ptr(dF), st)
+            vm_grad_finish(model, gviews, "appearance", ga)
         # ---------------- semantic head
         if d_sem is not None:
             ldp = (Ccls + 3) // 4 * 4
@@ -364,8 +393,9 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
         call("clift_march_bwd", C.byref(ctx.ms), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(ctx.alpha), ptr(ctx.T), ptr(ctx.w),
              ptr(ctx.ray_out), ptr(g_w), ptr(g_op), ptr(g_dist), ptr(dsigma), st)
         vd = vm_struct(views, "density", ctx.res)
-        gd = vm_grad_struct(gviews, "density")
+        gd = vm_grad_struct(model, gviews, "density")
         call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma), st)
+        vm_grad_finish(model, gviews, "density", gd)
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes

@@ -207,6 +207,16 @@ class TensorVMSplit(nn.Module):
     def named_views(self):
         return self._views
 
+    def xcd_workspace(self, key, numel):
+        """Persistent zero-initialised scratch for the per-XCD gradient accumulation copies (engine.vm_grad_struct);
+        clift_xcd_reduce leaves it zeroed again."""
+        ws = self.__dict__.setdefault("_xcd_ws", {})
+        t = ws.get(key)
+        if t is None or t.numel() != numel or t.device != self.param_flat.device:
+            t = torch.zeros(numel, dtype=torch.float32, device=self.param_flat.device)
+            ws[key] = t
+        return t
+
     def named_grad_views(self):
         return self._gviews
 

@@ -39,11 +39,20 @@ typedef struct {
     int comps;  /* components per plane (16 density / 48 appearance in the reference configs) */
 } clift_vm_t;
 
-/* Gradient accumulators for a table set (same layout; accumulated into with atomics). */
+/* Gradient accumulators for a table set (same layout; accumulated into with atomics).
+ * xcd_stride == 0: the pointers are the final gradient tables, accumulated with device-scope atomics.
+ * xcd_stride  > 0: the pointers address copy 0 of EIGHT zero-initialised accumulation copies, xcd_stride floats
+ *   apart; every XCD of the MI355X accumulates into its own copy with atomics that execute in its private L2
+ *   (selected by the hardware XCC id, placement-independent); the caller then folds the copies into the real
+ *   gradient with clift_xcd_reduce (which also re-zeroes them). */
 typedef struct {
     float* plane[3];
     float* line[3];
+    long xcd_stride;
 } clift_vm_grad_t;
+
+/* dst[i] += sum_{x<8} work[x*xcd_stride + i] for i < n; work is re-zeroed. */
+int clift_xcd_reduce(float* work, long xcd_stride, long n, float* dst, clift_stream_t s);
 
 /* Renderer state: reference model/renderer/panopli_tensoRF_renderer.py:42-71 (buffers bbox_aabb,
  * inv_box_extent; python attrs step_size, n_samples, distance_scale, raymarch_weight_thres) and
