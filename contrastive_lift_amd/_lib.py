@@ -39,7 +39,7 @@ class Gemm(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int),
                 ("bias", C.c_void_p), ("act", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int),
-                ("accumulate", C.c_int), ("split_k", C.c_int)]
+                ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long

@@ -7,7 +7,10 @@
 // Block = WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles.  Operand tiles
 // are staged global -> registers -> LDS in k-major order ([k][m], so a fragment read is 32 consecutive
 // floats per half-wave: conflict-free ds_read_b32) with the next k-tile's global loads in flight under the
-// MFMAs of the current one.
+// MFMAs of the current one; interior tiles load without any bounds checks (rows clamped, never stored).
+// Measured (profiles/, tools/ksweep.py): the k-loop itself sustains ~128 TFLOP/s (4096^3); at the K = 256 of the
+// MLP layers ~40 % of a launch is K-independent -- the 268 MB output store burst (~65 us, not overlapped: vmcnt is
+// in-order) and block start-up -- which is what fusing consecutive layers will remove (next round).
 //
 // Used for (reference tensoRF.py): basis Linear :65, appearance MLP :393-397, instance MLPs :475-491,
 // semantic MLP :576-582 -- forward (A = activations, B = weight (out,in)), dgrad (B transposed), wgrad
@@ -26,6 +29,8 @@ struct GemmP {
     const float* mask; int ldmask;
     int accumulate;
     int k_per_split;
+    int c_trans;      // write C[n*ldc + m] instead of C[m*ldc + n]
+    float* colsum;    // nullable: colsum[m] += sum_k A(m,k)   (bias gradient fused into the wgrad, a_trans only)
 };
 
 constexpr int BK = 32;
@@ -41,6 +46,31 @@ struct Stager {
     static constexpr int NV = (ROWS * BK / 4 + NT - 1) / NT;  // float4 per thread
     float4 v[NV];
 
+    // interior tiles: no bounds checks at all.  non-trans rows beyond mlim are clamped to the last valid row (their
+    // products land in accumulator rows the epilogue never stores); requires k0 + BK <= klim (and, for trans operands,
+    // m0 + ROWS <= mlim) -- see fast_ok().
+    static __device__ __forceinline__ bool fast_ok(int m0, int mlim, int k0, int klim) {
+        return (k0 + BK <= klim) && (!TR || m0 + ROWS <= mlim) && mlim > 0;
+    }
+    __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int m0, int mlim, int k0, int tid) {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int e = tid + p * NT;
+            if ((ROWS * BK / 4) % NT == 0 || e < ROWS * BK / 4) {
+                if (!TR) {
+                    const int m = min(m0 + e / (BK / 4), mlim - 1), k = k0 + (e % (BK / 4)) * 4;
+                    v[p] = *reinterpret_cast<const float4*>(P + (size_t)m * ld + k);
+                } else {
+                    const int k = k0 + e / (ROWS / 4), m = m0 + (e % (ROWS / 4)) * 4;
+                    v[p] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + m);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void load_any(const float* __restrict__ P, int ld, int m0, int mlim, int k0, int klim, int tid) {
+        if (fast_ok(m0, mlim, k0, klim)) load_fast(P, ld, m0, mlim, k0, tid);
+        else load(P, ld, m0, mlim, k0, klim, tid);
+    }
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int m0, int mlim, int k0, int klim, int tid) {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -95,7 +125,7 @@ struct Stager {
 };
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
-__global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmP g) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(GemmP g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LSA = lds_stride<AT>(BM), LSB = lds_stride<BT>(BN);
@@ -112,6 +142,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmP g) {
     const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
+    const bool do_colsum = AT && g.colsum != nullptr && n0 == 0;
+    float csum = 0.f;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -123,15 +155,19 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmP g) {
 
     Stager<BM, NT, AT> sa;
     Stager<BN, NT, BT> sb;
-    sa.load(g.A, g.lda, m0, g.M, kbeg, kend, tid);
-    sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    sa.load_any(g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    sb.load_any(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         sa.store(As, tid);
         sb.store(Bs, tid);
         __syncthreads();
+        if (AT && do_colsum && tid < BM) {
+#pragma unroll 8
+            for (int kk = 0; kk < BK; ++kk) csum += As[kk * LSA + tid];
+        }
         if (k0 + BK < kend) {
-            sa.load(g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
-            sb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
+            sa.load_any(g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
+            sb.load_any(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
         }
         const float* ap = As + lh * LSA + wm * (BM / WM) + li;
         const float* bp = Bs + lh * LSB + wn * (BN / WN) + li;
@@ -165,22 +201,27 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm(GemmP g) {
                 float v = acc[x][y][r] + bv;
                 if (g.act == 1) v = fmaxf(v, 0.f);
                 if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
-                float* c = g.C + (size_t)m * g.ldc + n;
+                float* c = g.c_trans ? g.C + (size_t)n * g.ldc + m : g.C + (size_t)m * g.ldc + n;
                 if (g.accumulate) unsafeAtomicAdd(c, v);
                 else *c = v;
             }
         }
+    if (AT && do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
+}
+
+template <int BM, int BN, int WM, int WN, bool AT, bool BT>
+static int launch_one(const GemmP& p, int splits, hipStream_t st) {
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
+    k_gemm<BM, BN, WM, WN, AT, BT><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
+    return clift_check_launch("clift_gemm");
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st) {
-    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
-    const dim3 block(WM * WN * 64);
-    if (!a_trans && !b_trans) k_gemm<BM, BN, WM, WN, false, false><<<grid, block, 0, st>>>(p);
-    else if (!a_trans && b_trans) k_gemm<BM, BN, WM, WN, false, true><<<grid, block, 0, st>>>(p);
-    else if (a_trans && b_trans) k_gemm<BM, BN, WM, WN, true, true><<<grid, block, 0, st>>>(p);
-    else k_gemm<BM, BN, WM, WN, true, false><<<grid, block, 0, st>>>(p);
-    return clift_check_launch("clift_gemm");
+    if (!a_trans && !b_trans) return launch_one<BM, BN, WM, WN, false, false>(p, splits, st);
+    if (!a_trans && b_trans) return launch_one<BM, BN, WM, WN, false, true>(p, splits, st);
+    if (a_trans && b_trans) return launch_one<BM, BN, WM, WN, true, true>(p, splits, st);
+    return launch_one<BM, BN, WM, WN, true, false>(p, splits, st);
 }
 
 extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
@@ -191,17 +232,21 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     int splits = h->split_k > 1 ? h->split_k : 1;
     CLIFT_REQUIRE(splits == 1 || h->accumulate, "clift_gemm: split_k > 1 requires accumulate");
     CLIFT_REQUIRE(splits == 1 || (!h->bias && !h->act && !h->mask), "clift_gemm: split_k > 1 excludes bias/act/mask");
+    CLIFT_REQUIRE(!h->colsum || h->a_trans, "clift_gemm: colsum requires a_trans (wgrad form)");
     GemmP p;
     p.M = h->M; p.N = h->N; p.K = h->K;
     p.A = h->A; p.lda = h->lda; p.B = h->B; p.ldb = h->ldb; p.C = h->C; p.ldc = h->ldc;
     p.bias = h->bias; p.act = h->act; p.mask = h->mask; p.ldmask = h->ldmask; p.accumulate = h->accumulate;
+    p.c_trans = h->c_trans; p.colsum = h->colsum;
     int kper = cdiv(cdiv(h->K, splits), BK) * BK;
     if (kper < BK) kper = BK;
     splits = cdiv(h->K, kper);
     if (splits < 1) splits = 1;
     p.k_per_split = kper;
     hipStream_t st = as_stream(s);
-    if (h->N > 128) return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
+    if (h->N > 128) {
+        return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
+    }
     if (h->N > 32) return launch_gemm<128, 128, 2, 2>(p, h->a_trans, h->b_trans, splits, st);
     return launch_gemm<256, 32, 4, 1>(p, h->a_trans, h->b_trans, splits, st);
 }

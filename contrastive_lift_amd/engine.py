@@ -91,7 +91,7 @@ def _pitch(t):
 
 
 def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=0, mask=None, ldmask=0,
-         accumulate=0, split_k=1, a_off=0, c_off=0):
+         accumulate=0, split_k=1, a_off=0, c_off=0, c_trans=0, colsum=None):
     g = Gemm()
     g.M, g.N, g.K = int(M), int(N), int(K)
     g.A, g.lda, g.a_trans = A.data_ptr() + 4 * a_off, int(lda), int(a_trans)
@@ -102,7 +102,20 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.mask = mask.data_ptr() if mask is not None else None
     g.ldmask = int(ldmask)
     g.accumulate, g.split_k = int(accumulate), int(split_k)
+    g.c_trans = int(c_trans)
+    g.colsum = colsum.data_ptr() if colsum is not None else None
     call("clift_gemm", C.byref(g), stream())
+
+
+def wgrad(no, ni, M, dY, ldd, X, ldx, gW, gb):
+    """gW (no, ni) += dY^T X over the M samples; gb (no) += column sums of dY.  Wide layers: the bias sum is fused
+    into the GEMM (read from the A tile already staged in LDS).  Narrow layers (no <= 32): solved as the transposed
+    problem gW^T = X^T dY so that the narrow dimension is the 32-wide N tile instead of wasting a 128-row M tile."""
+    if no > 32:
+        gemm(no, ni, M, dY, ldd, X, ldx, gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(no, ni, M), colsum=gb)
+    else:
+        gemm(ni, no, M, X, ldx, dY, ldd, gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(ni, no, M), c_trans=1)
+        call("clift_colsum", ptr(dY), ldd, M, no, ptr(gb), stream())
 
 
 def _splits(out_rows, out_cols, K):
@@ -151,9 +164,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M):
         gW, gb = glayers[li]
         h = acts[li - 1]
         no, ni = W.shape
-        gemm(no, ni, M, d, d.shape[1], h, h.shape[1], gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1,
-             split_k=_splits(no, ni, M))
-        call("clift_colsum", ptr(d), d.shape[1], M, no, ptr(gb), stream())
+        wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
         dn = torch.empty((M, ni), dtype=torch.float32, device=dev)
         gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
@@ -338,17 +349,14 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, st)
             H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
             n2 = W3.shape[1]
-            gemm(3, n2, M, dpre, 4, H2, n2, gW3, _pitch(gW3), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(3, n2, M))
-            call("clift_colsum", ptr(dpre), 4, M, 3, ptr(gb3), st)
+            wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
             dH2 = torch.empty((M, n2), dtype=torch.float32, device=dev)
             gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
             n1 = W2.shape[1]
-            gemm(n2, n1, M, dH2, n2, H1, n1, gW2, _pitch(gW2), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(n2, n1, M))
-            call("clift_colsum", ptr(dH2), n2, M, n2, ptr(gb2), st)
+            wgrad(n2, n1, M, dH2, n2, H1, n1, gW2, gb2)
             dH1 = torch.empty((M, n1), dtype=torch.float32, device=dev)
             gemm(M, n1, n2, dH2, n2, W2, _pitch(W2), dH1, n1, b_trans=1, mask=H1, ldmask=n1)
-            gemm(n1, ldx, M, dH1, n1, X, ldx, gW1, ldx, a_trans=1, b_trans=1, accumulate=1, split_k=_splits(n1, ldx, M))
-            call("clift_colsum", ptr(dH1), n1, M, n1, ptr(gb1), st)
+            wgrad(n1, ldx, M, dH1, n1, X, ldx, gW1, gb1)
             dX = torch.empty((M, ldx), dtype=torch.float32, device=dev)
             gemm(M, ldx, n1, dH1, n1, W1, ldx, dX, ldx, b_trans=1)
             nf, ldf = ctx.nf, ctx.ldf
@@ -356,7 +364,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, st)
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
-            gemm(nf, nc, M, dfeat, ldf, ctx.F, nc, gWb, _pitch(gWb), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(nf, nc, M))
+            gemm(nc, nf, M, ctx.F, nc, dfeat, ldf, gWb, _pitch(gWb), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(nc, nf, M), c_trans=1)
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
             gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             va = vm_struct(views, "appearance", ctx.res)

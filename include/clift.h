@@ -134,6 +134,8 @@ typedef struct {
     const float* mask; int ldmask;  /* nullable */
     int accumulate;
     int split_k;
+    int c_trans;                    /* write C[n*ldc + m] (lets a narrow-M wgrad run as a narrow-N problem) */
+    float* colsum;                  /* nullable; a_trans only: colsum[m] += sum_k A(m,k)  (bias gradient) */
 } clift_gemm_t;
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 

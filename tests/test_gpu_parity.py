@@ -81,6 +81,33 @@ def test_gemm_matches_fp64(at, bt, M, N, K):
     rel_close(out3, ref - bias.double() + 1.0, 2e-5, atol=4e-5 * float(ref.abs().max()), what="gemm split-k accumulate")
 
 
+def test_gemm_tail_split_ctrans_colsum():
+    """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 128 * 547 + 77, 256, 64                      # 548 row tiles -> 1 full round of 512 + remainder
+    A = torch.randn((M, K), generator=g).to(DEV)
+    B = torch.randn((N, K), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    mask = torch.randn((M, N), generator=g).to(DEV)
+    out = torch.empty((M, N), device=DEV)
+    engine.gemm(M, N, K, A, K, B, K, out, N, bias=bias, act=1, mask=mask, ldmask=N)
+    ref = torch.relu(A.double() @ B.double().T + bias.double()) * (mask > 0)
+    rel_close(out, ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="tail-split gemm")
+    # wgrad forms: dW (no x ni) = dY^T X, with fused column sums (wide) and via the transposed problem (narrow)
+    Ms = 40000
+    for no, ni in ((256, 256), (128, 152), (22, 256), (3, 128), (27, 144)):
+        ldd = (no + 3) // 4 * 4
+        dY = torch.zeros((Ms, ldd), device=DEV); dY[:, :no] = torch.randn((Ms, no), generator=g).to(DEV)
+        X = torch.randn((Ms, ni), generator=g).to(DEV)
+        gW = torch.zeros((no, ni), device=DEV); gb = torch.zeros(no, device=DEV)
+        engine.wgrad(no, ni, Ms, dY, ldd, X, ni, gW, gb)
+        refW = dY[:, :no].double().T @ X.double()
+        rel_close(gW, refW, 1e-4, atol=1e-4 * float(refW.abs().max()), what=f"wgrad {no}x{ni}")
+        refb = dY[:, :no].double().sum(0)
+        rel_close(gb, refb, 1e-4, atol=1e-4 * float(refb.abs().max()) + 1e-4, what=f"bias grad {no}")
+
+
 def test_gemm_transpose_detecting():
     """A = I against an asymmetric B: a swapped C-write would pass a symmetric test."""
     from contrastive_lift_amd import engine

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of clift_gemm on the shapes of the bench workload (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from contrastive_lift_amd import engine
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 265000
+dev = "cuda"
+shapes = [("fwd 256x256", M, 256, 256, 0, 0), ("dgrad 256x256", M, 256, 256, 0, 1), ("wgrad 256x256", 256, 256, M, 1, 1),
+          ("fwd 152->128", M, 128, 152, 0, 0), ("fwd 128->128", M, 128, 128, 0, 0), ("fwd 256->22", M, 22, 256, 0, 0),
+          ("fwd 144->27", M, 27, 144, 0, 0), ("dgrad 22->256", M, 256, 22, 0, 1), ("wgrad 22x256", 22, 256, M, 1, 1)]
+for name, m, n, k, at, bt in shapes:
+    if at:   # wgrad: A = dY (K x m) stored (K, m) row-major; B = X (K x n)
+        A = torch.randn(k, (m + 3) // 4 * 4, device=dev); B = torch.randn(k, n, device=dev)
+        lda, ldb = A.shape[1], n
+    else:
+        A = torch.randn(m, (k + 3) // 4 * 4, device=dev)
+        B = torch.randn(k, n, device=dev) if bt else torch.randn(n, (k + 3) // 4 * 4, device=dev)
+        lda, ldb = A.shape[1], B.shape[1]
+    Cm = torch.zeros(m, n, device=dev)
+    kw = dict(a_trans=at, b_trans=bt)
+    if at:
+        kw.update(accumulate=1, split_k=engine._splits(m, n, k))
+    for _ in range(3):
+        engine.gemm(m, n, k, A, lda, B, ldb, Cm, n, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    reps = 10
+    for _ in range(reps):
+        engine.gemm(m, n, k, A, lda, B, ldb, Cm, n, **kw)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{name:16s} M={m:7d} N={n:4d} K={k:7d}  {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:7.1f} TFLOP/s")
