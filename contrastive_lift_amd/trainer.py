@@ -118,7 +118,7 @@ class HotPathTrainer:
         g_rgb = torch.empty_like(rgb)
         g_sem = torch.empty_like(sem)
         mask = batch.get("mask")
-        maskf = mask.to(torch.float32) if mask is not None else None
+        maskf = mask.to(torch.float32) if mask is not None else None        # T:156-158 (masked pixels contribute nothing)
         self.losses.zero_()
         _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
                   _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,

@@ -48,3 +48,19 @@ def rel_close(a, b, rtol=1e-3, atol=None, what=""):
         i = int(torch.argmax(err - bound))
         raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} outside rtol={rtol} atol={atol:.3g}; "
                              f"worst a={a.reshape(-1)[i].item():.8g} b={b.reshape(-1)[i].item():.8g}")
+
+
+def grad_close(a, b, what="", rtol=2e-3, scale_atol=1e-3, outlier_frac=1e-3, outlier_cap=1e-2):
+    """Gradient tensors are sums of mixed-sign per-sample terms, so their error is relative to the tensor's scale.
+    All elements within rtol*|b| + scale_atol*max|b|, except at most ``outlier_frac`` of them (samples whose weight sits
+    within float round-off of the 1e-4 activity threshold flip in/out of the appearance pass between implementations),
+    which must still be within outlier_cap*max|b|."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    mx = float(b.abs().max()) if b.numel() else 0.0
+    err = (a - b).abs()
+    bad = err > rtol * b.abs() + scale_atol * mx + 1e-12
+    nbad = int(bad.sum())
+    assert nbad <= max(1, int(outlier_frac * b.numel())), f"{what}: {nbad}/{b.numel()} elements outside tolerance (max|b|={mx:.3g})"
+    assert float(err.max()) <= outlier_cap * mx + 1e-12, f"{what}: max error {float(err.max()):.3g} vs scale {mx:.3g}"

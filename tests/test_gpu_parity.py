@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, T, rel_close
+from conftest import load_golden, T, rel_close, grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -448,3 +448,61 @@ def test_full_size_properties():
     hit = c1.ray_out[:, 0] > 0.5
     ps = torch.exp(o1["semantics"][hit]).sum(-1)
     rel_close(ps, torch.ones_like(ps), 1e-3, what="sum_c exp(sem) == 1")
+
+
+# ============================================================================ training step (a20) vs the oracle's CPU trainer
+def test_training_step_vs_oracle():
+    """HotPathTrainer (engine-driven main pass + slow-fast instance pass, arena Adam) against oracle.train_step.CpuTrainer
+    (torch autograd + torch.optim.Adam) on identical inputs, jitter and white-background draws: gradients of every
+    parameter after the backward, then parameters after two optimizer steps."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from oracle.train_step import CpuTrainer
+    res, C_, E, B, Bi = (24, 28, 32), 5, 3, 384, 160
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, 77, res, C_, E, B + Bi, amp=2.3, sg=0.42)
+    rays_main, rays_inst = rays[:B].contiguous(), rays[B:].contiguous()
+    rgbs = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+    probs = torch.softmax(torch.from_numpy(rng.standard_normal((B, C_)).astype(np.float32)), -1)
+    conf = torch.from_numpy(rng.uniform(0.2, 1, B).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(1, 6, Bi).astype(np.int64))
+    iconf = torch.from_numpy(rng.uniform(0.2, 1, Bi).astype(np.float32))
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    cfg = default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0)
+    tr = HotPathTrainer(m, r, cfg, current_epoch=4)
+    ct = CpuTrainer(P, orender.RenderCfg(aabb, res, density_shift=-3.0), chunk=4096, epoch=4)
+    for step in range(2):
+        jit = torch.from_numpy(rng.uniform(0, 1, B).astype(np.float32))
+        jit_i = torch.from_numpy(rng.uniform(0, 1, Bi).astype(np.float32))
+        white = bool(step % 2)
+        oc = ct.main_pass(rays_main, rgbs, probs, conf, jit, [white])
+        oi = ct.instance_pass(rays_inst, labels, iconf, jit_i)
+        batch0 = dict(rays=rays_main.to(DEV), rgbs=rgbs.to(DEV), probabilities=probs.to(DEV), confidences=conf.to(DEV), mask=None)
+        tr.main_pass(batch0, jitter=jit.to(DEV), white_bg=white)
+        rel_close(tr.last_outputs[0], oc["rgb"], 1e-3, what=f"step {step} rgb")
+        rel_close(tr.last_outputs[1], oc["sem"], 1e-3, what=f"step {step} sem")
+        rel_close(tr.losses[0], oc["loss_rgb"], 1e-3, what="loss_rgb")
+        rel_close(tr.losses[1], oc["loss_sem"], 1e-3, what="loss_sem")
+        rel_close(tr.losses[2], oc["loss_tv"], 1e-3, what="loss_tv")
+        if step == 0:    # gradients (the arena keeps them after the optimizer step)
+            gv = m.named_grad_views()
+            for k, pref in ct.P.items():
+                if k.startswith("render_instance_mlp"):
+                    continue
+                ref = pref.grad
+                grad_close(gv[k].detach().cpu(), ref, what=f"main grad {k}")
+        tr.instance_pass([dict(rays=rays_inst.to(DEV), instances=labels.to(DEV), confidences=iconf.to(DEV))], jitter=jit_i.to(DEV))
+        rel_close(tr.losses[3], oi["loss"], 1e-3, what="slow-fast loss")
+        if step == 0:
+            gv = m.named_grad_views()
+            for k, pref in ct.P.items():
+                if k.startswith("render_instance_mlp.mlp."):
+                    grad_close(gv[k].detach().cpu(), pref.grad, what=f"inst grad {k}")
+    # parameters after two Adam steps of both optimizers + two EMA updates.  Adam's first steps move every weight by
+    # ~lr regardless of gradient size, so the comparison is absolute in units of the learning rate.
+    sd = m.state_dict()
+    for k, pref in ct.P.items():
+        lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
+        diff = float((sd[k].detach().cpu() - pref.detach()).abs().max())
+        assert diff <= 0.1 * lr * 2 + 1e-7, f"param {k}: max |diff| {diff:.3e} vs lr {lr}"   # elements with |g| ~ eps amplify gradient round-off
