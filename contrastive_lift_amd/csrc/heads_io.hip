@@ -33,6 +33,55 @@ extern "C" int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* 
     return clift_check_launch("clift_app_gather_fwd");
 }
 
+// plane x line products at arbitrary normalised points (reference field API compute_appearance_feature, tensoRF.py:127-137)
+__global__ __launch_bounds__(256) void k_vm_products_points(VmP t, const float* __restrict__ xn3, int ldx, long total, float* __restrict__ F) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int g4 = t.comps / 4, G = 3 * g4;
+    const long s = gid / G;
+    const int j = (int)(gid - s * G);
+    const int i = j / g4, c4 = (j - i * g4) * 4;
+    const float xn[3] = {xn3[s * ldx + 0], xn3[s * ldx + 1], xn3[s * ldx + 2]};
+    const VmTaps tp = vm_taps(t, i, xn);
+    *reinterpret_cast<float4*>(F + (size_t)s * (3 * t.comps) + i * t.comps + c4) = f4_mul(vm_plane4(t, i, tp, c4), vm_line4(t, i, tp, c4));
+}
+
+extern "C" int clift_vm_products_points(const clift_vm_t* h_vm, const float* xn, int ldx, long n, float* F, clift_stream_t s) {
+    CLIFT_REQUIRE(h_vm->comps % 4 == 0, "clift_vm_products_points: comps must be a multiple of 4");
+    if (n <= 0) return 0;
+    const long total = n * (3 * h_vm->comps / 4);
+    k_vm_products_points<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(to_dev(h_vm), xn, ldx, total, F);
+    return clift_check_launch("clift_vm_products_points");
+}
+
+// MLP input assembly from explicit view directions (reference field API render_appearance_mlp(viewdirs, features))
+__global__ __launch_bounds__(256) void k_app_encode_points(const float* __restrict__ feat, int ldf, int nf, int pef, int pev,
+                                                            const float* __restrict__ dirs, int ldd, long total, float* __restrict__ X, int ldx) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const long s = gid / ldx;
+    const int c = (int)(gid - s * ldx);
+    const float* f = feat + (size_t)s * ldf;
+    const float* d = dirs + (size_t)s * ldd;
+    const int b0 = nf, b1 = b0 + 3, b2 = b1 + nf * pef, b3 = b2 + nf * pef, b4 = b3 + 3 * pev, b5 = b4 + 3 * pev;
+    float v = 0.f;
+    if (c < b0) v = f[c];
+    else if (c < b1) v = d[c - b0];
+    else if (c < b2) { const int e = c - b1; v = sinf(f[e / pef] * (float)(1 << (e % pef))); }
+    else if (c < b3) { const int e = c - b2; v = cosf(f[e / pef] * (float)(1 << (e % pef))); }
+    else if (c < b4) { const int e = c - b3; v = sinf(d[e / pev] * (float)(1 << (e % pev))); }
+    else if (c < b5) { const int e = c - b4; v = cosf(d[e / pev] * (float)(1 << (e % pev))); }
+    X[gid] = v;
+}
+
+extern "C" int clift_app_encode_points(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* dirs, int ldd, long n,
+                                       float* X, int ldx, clift_stream_t s) {
+    CLIFT_REQUIRE(ldx >= nf + 3 + 2 * pe_feat * nf + 2 * pe_view * 3, "clift_app_encode_points: ldx too small");
+    if (n <= 0) return 0;
+    k_app_encode_points<<<cdiv(n * ldx, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, pe_view, dirs, ldd, n * ldx, X, ldx);
+    return clift_check_launch("clift_app_encode_points");
+}
+
 // normalised coordinates of the active samples only (instance / segment passes, renderer.py:204,285)
 __global__ __launch_bounds__(256) void k_active_xyz(MarchP m, const float* __restrict__ rays, const float* __restrict__ jitter,
                                                      const int* __restrict__ act, int M, float* __restrict__ xa) {

@@ -47,6 +47,40 @@ extern "C" int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_d
     return clift_check_launch("clift_density_fwd");
 }
 
+// ============================================================================ density at arbitrary points
+// tensoRF.py:114-125 on explicit normalised coordinates (dense alpha grid of the bbox shrink, renderer.py:717-754;
+// reference field API compute_density).  Same 4-lanes-per-point mapping as k_density_fwd; no in-box mask (taps outside
+// the table are zero-padded exactly like grid_sample).
+__global__ __launch_bounds__(256) void k_density_points(VmP t, const float* __restrict__ xn3, int ldx, long total, float shift, int activation,
+                                                         float* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long s = gid >> 2;
+    const int q = (int)(gid & 3);
+    if (s >= total) return;
+    const float xn[3] = {xn3[s * ldx + 0], xn3[s * ldx + 1], xn3[s * ldx + 2]};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const VmTaps tp = vm_taps(t, i, xn);
+        for (int c4 = q * 4; c4 < t.comps; c4 += 16) acc += f4_hsum(f4_mul(vm_plane4(t, i, tp, c4), vm_line4(t, i, tp, c4)));
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (q == 0) {
+        const float x = acc + shift;
+        out[s] = activation ? ((x > 20.f) ? x : log1pf(expf(x))) : x;
+    }
+}
+
+extern "C" int clift_density_points(const clift_vm_t* h_dens, const float* xn, int ldx, long n, float shift, int activation, float* out,
+                                    clift_stream_t s) {
+    CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_density_points: comps must be a multiple of 4");
+    CLIFT_REQUIRE(ldx >= 3, "clift_density_points: ldx must be >= 3");
+    if (n <= 0) return 0;
+    k_density_points<<<cdiv(n * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_dens), xn, ldx, n, shift, activation, out);
+    return clift_check_launch("clift_density_points");
+}
+
 // ============================================================================ density backward
 // Persistent blocks (grid-stride over samples), `comps` lanes per sample with ONE CHANNEL PER LANE (comps = 4..64,
 // power of two; 16 in the reference configs => 4 samples per wave): every atomic instruction covers whole 64-byte

@@ -465,25 +465,70 @@ def feature_backward(model, ctx, gviews, g_out, slow_grad=False):
 
 
 # ----------------------------------------------------------------------------- point-wise utilities (reference field API)
+def _points(xyz):
+    x = _lib.f32(xyz, "xyz").reshape(-1, xyz.shape[-1]).contiguous()
+    if x.shape[1] < 3:
+        raise ValueError("xyz must have >= 3 columns")
+    return x
+
+
+@torch.no_grad()
 def density_points(model, xyz, activation=True):
-    raise NotImplementedError("clift: point-wise density evaluation lands with the alpha-mask shrink (SURVEY 8f rank 1)")
+    """TensorVMSplit.compute_density / compute_density_without_activation on normalised points (no gradient)."""
+    x = _points(xyz)
+    views = model.named_views()
+    vd = vm_struct(views, "density", grid_res(views))
+    out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    call("clift_density_points", C.byref(vd), ptr(x), x.shape[1], x.shape[0], float(model.splus_density_shift), int(bool(activation)),
+         ptr(out), stream())
+    return out
 
 
+@torch.no_grad()
 def appearance_feature_points(model, xyz):
-    raise NotImplementedError("clift: point-wise appearance features land with the alpha-mask shrink (SURVEY 8f rank 1)")
+    """TensorVMSplit.compute_appearance_feature: VM products + basis Linear (no gradient)."""
+    x = _points(xyz)
+    n = x.shape[0]
+    views = model.named_views()
+    va = vm_struct(views, "appearance", grid_res(views))
+    nc = 3 * va.comps
+    F = torch.empty((n, nc), dtype=torch.float32, device=x.device)
+    call("clift_vm_products_points", C.byref(va), ptr(x), x.shape[1], n, ptr(F), stream())
+    Wb = views["appearance_basis_mat.weight"]
+    out = torch.empty((n, Wb.shape[0]), dtype=torch.float32, device=x.device)
+    gemm(n, Wb.shape[0], nc, F, nc, Wb, _pitch(Wb), out, out.shape[1])
+    return out
 
 
+@torch.no_grad()
 def xyz_mlp_points(seq, xyz):
     """Evaluate an xyz MLP head on arbitrary points (inference utility, no gradient)."""
-    xyz = _lib.f32(xyz, "xyz").reshape(-1, xyz.shape[-1])
-    M = xyz.shape[0]
-    xa = torch.zeros((M, 4), dtype=torch.float32, device=xyz.device)
-    xa[:, :3] = xyz[:, :3]
+    x = _points(xyz)
+    M = x.shape[0]
+    xa = torch.zeros((M, 4), dtype=torch.float32, device=x.device)
+    xa[:, :3] = x[:, :3]
     layers = [(m.weight, m.bias) for m in seq if isinstance(m, torch.nn.Linear)]
-    out = torch.empty((M, layers[-1][0].shape[0]), dtype=torch.float32, device=xyz.device)
+    out = torch.empty((M, layers[-1][0].shape[0]), dtype=torch.float32, device=x.device)
     xyz_mlp_fwd(layers, xa, M, out, out.shape[1])
     return out
 
 
+@torch.no_grad()
 def appearance_mlp_points(module, viewdirs, features):
-    raise NotImplementedError("clift: stand-alone appearance MLP evaluation is not exposed yet; use the renderer")
+    """MLPRenderFeature.forward(viewdirs, features) (tensoRF.py:400-411), no gradient."""
+    f = _lib.f32(features, "features").reshape(-1, features.shape[-1]).contiguous()
+    d = _lib.f32(viewdirs, "viewdirs").reshape(-1, 3).contiguous()
+    n, nf = f.shape
+    (W1, b1), (W2, b2), (W3, b3) = [(m.weight, m.bias) for m in module.mlp if isinstance(m, torch.nn.Linear)]
+    ldx = _pitch(W1)
+    X = torch.empty((n, ldx), dtype=torch.float32, device=f.device)
+    call("clift_app_encode_points", ptr(f), nf, nf, module.pe_feat, module.pe_view, ptr(d), 3, n, ptr(X), ldx, stream())
+    H1 = torch.empty((n, W1.shape[0]), dtype=torch.float32, device=f.device)
+    gemm(n, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
+    H2 = torch.empty((n, W2.shape[0]), dtype=torch.float32, device=f.device)
+    gemm(n, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
+    pre = torch.empty((n, 3), dtype=torch.float32, device=f.device)
+    gemm(n, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
+    out = torch.empty_like(pre)
+    call("clift_rows_act_fwd", ptr(pre), 3, n, 3, 1, ptr(out), 3, stream())
+    return out

@@ -246,6 +246,40 @@ class TensorVMSplit(nn.Module):
     def compute_instance_feature(self, xyz_sampled):
         return xyz_sampled          # use_instance_mlp (tensoRF.py:152-154)
 
+    # ------------------------------------------------------------------ reference API: grid surgery (tensoRF.py:158-197)
+    def _grid_lists(self):
+        return ((self.density_plane, self.density_line), (self.appearance_plane, self.appearance_line))
+
+    @torch.no_grad()
+    def shrink(self, t_l, b_r):
+        """Crop every plane/line to the voxel range [t_l, b_r) per axis (tensoRF.py:158-177), then re-pack the arena."""
+        t_l = [int(x) for x in t_l]
+        b_r = [int(x) for x in b_r]
+        for planes, lines in self._grid_lists():
+            for i in range(3):
+                v = VECTOR_MODE[i]
+                a, b = MATRIX_MODE[i]
+                lines[i] = nn.Parameter(lines[i].data[..., t_l[v]:b_r[v], :].clone())
+                planes[i] = nn.Parameter(planes[i].data[..., t_l[b]:b_r[b], t_l[a]:b_r[a]].clone())
+        self.pack()
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """Bilinear (align_corners=True) resize of every plane/line to res_target = (Rx,Ry,Rz) (tensoRF.py:179-197).
+        Runs 3-4 times per training: done with torch's interpolate on the device, then the arena is re-packed (which
+        also makes the new tensors the ones the optimizer and the gradient all-reduce see)."""
+        import torch.nn.functional as F
+        res_target = [int(x) for x in res_target]
+        for planes, lines in self._grid_lists():
+            for i in range(3):
+                v = VECTOR_MODE[i]
+                a, b = MATRIX_MODE[i]
+                src_p = planes[i].data.contiguous(memory_format=torch.contiguous_format)
+                src_l = lines[i].data.contiguous(memory_format=torch.contiguous_format)
+                planes[i] = nn.Parameter(F.interpolate(src_p, size=(res_target[b], res_target[a]), mode='bilinear', align_corners=True))
+                lines[i] = nn.Parameter(F.interpolate(src_l, size=(res_target[v], 1), mode='bilinear', align_corners=True))
+        self.pack()
+
     # ------------------------------------------------------------------ reference API: optimizer groups
     def get_optimizable_parameters(self, lr_grid, lr_net, weight_decay=0):
         """tensoRF.py:199-213 (MLP-heads configuration)."""

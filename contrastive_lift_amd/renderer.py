@@ -173,6 +173,58 @@ class TensoRFRenderer(nn.Module):
         params = [tensorf.get_parameter(n) for n in names]
         return _FeatureFn.apply(tensorf, self, rays, jitter, "semantic", names, *params)
 
+    # ------------------------------------------------------------------ alpha-mask shrink (renderer.py:669-754)
+    @torch.no_grad()
+    def compute_alpha(self, tensorf, xyz_locs, step_size):
+        xyz_sampled = self.normalize_coordinates(xyz_locs)
+        sigma = tensorf.compute_density(xyz_sampled.reshape(-1, 3)).reshape(xyz_locs.shape[:-1])
+        return 1 - torch.exp(-sigma * step_size)
+
+    @torch.no_grad()
+    def get_dense_alpha(self, tensorf):
+        """alpha on the (Rx,Ry,Rz) lattice of the current box (renderer.py:717-729): one clift_density_points launch
+        over the whole lattice instead of a Python loop over x-slabs."""
+        dev = self.bbox_aabb.device
+        g = [int(x) for x in self.grid_dim.tolist()]
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, g[0]), torch.linspace(0, 1, g[1]), torch.linspace(0, 1, g[2]),
+                                             indexing='ij'), -1).to(dev)
+        dense_xyz = self.bbox_aabb[0] * (1 - samples) + self.bbox_aabb[1] * samples
+        alpha = self.compute_alpha(tensorf, dense_xyz.reshape(-1, 3), self.step_size.to(dev)).view(g[0], g[1], g[2])
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def update_bbox_aabb_and_shrink(self, tensorf, fractional_lenience=1.0):
+        """renderer.py:668-715: dense alpha -> 3^3 max-pool -> threshold -> tight box -> crop the grids."""
+        import torch.nn.functional as F
+        alpha, dense_xyz = self.get_dense_alpha(tensorf)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(self.grid_dim.tolist()[::-1])
+        alpha = (alpha >= self.alpha_mask_threshold).to(torch.float32)
+        valid_xyz = dense_xyz[alpha > 0.5]
+        if valid_xyz.shape[0] == 0:
+            return False
+        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
+        extent = xyz_max - xyz_min
+        position = (xyz_min + xyz_max) / 2
+        xyz_min = torch.maximum(self.bbox_aabb[0], position - (extent * fractional_lenience) / 2)
+        xyz_max = torch.minimum(self.bbox_aabb[1], position + (extent * fractional_lenience) / 2)
+        if self.parent_renderer_ref is not None:
+            xyz_min = torch.maximum(self.parent_renderer_ref.bbox_aabb[0], xyz_min)
+            xyz_max = torch.minimum(self.parent_renderer_ref.bbox_aabb[1], xyz_max)
+        new_bbox = torch.stack((xyz_min, xyz_max))
+        t_l = (xyz_min - self.bbox_aabb[0]) / self.units
+        b_r = (xyz_max - self.bbox_aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.grid_dim]).amin(0)
+        new_size = b_r - t_l
+        if bool((new_size > 0).all()):
+            tensorf.shrink(t_l.tolist(), b_r.tolist())
+            self.bbox_aabb.data = new_bbox
+            self.update_step_size(tuple(int(x) for x in new_size.tolist()))
+            return True
+        return False
+
     @staticmethod
     def raw_to_alpha(sigma, dist):
         """renderer.py:626-631 (plain torch; the fused path lives in clift_march_fwd)."""

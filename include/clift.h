@@ -78,6 +78,17 @@ int clift_gen_rays(int H, int W, const float* h_K9, const float* h_c2w16, float 
 int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const float* rays, const float* jitter,
                       int N, float* sigma, clift_stream_t s);
 
+/* Point-wise field API (reference TensorVMSplit.compute_density / compute_density_without_activation,
+ * tensoRF.py:114-125; used by the dense alpha grid of the bbox shrink, renderer.py:717-754).  xn (n, ldx) normalised
+ * coordinates; out (n). */
+int clift_density_points(const clift_vm_t* h_dens, const float* xn, int ldx, long n, float shift, int activation,
+                         float* out, clift_stream_t s);
+/* Plane x line products at arbitrary points, F (n, 3*comps) (compute_appearance_feature before the basis, :127-134). */
+int clift_vm_products_points(const clift_vm_t* h_vm, const float* xn, int ldx, long n, float* F, clift_stream_t s);
+/* Appearance-MLP input assembly from explicit view directions (render_appearance_mlp(viewdirs, features), :400-408). */
+int clift_app_encode_points(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* dirs, int ldd,
+                            long n, float* X, int ldx, clift_stream_t s);
+
 /* ---- a7-a8: renderer.py:83-84,100-103,137,173-174,626-631 + eff_distloss (renderer.py:101).
  * Per sample alpha, T (transmittance before the sample), w = alpha*T, all (N, S).
  * ray_out (N, 8) = [opacity, depth, bg, w_total, wm_total, dist_loss, t_min, 0]; n_active (N) = #(w > thres). */

@@ -373,8 +373,8 @@ def g10_grid_ops():
         alpha, dense_xyz = rr.get_dense_alpha(m)
         out["dense_alpha"] = alpha
         rr.update_bbox_aabb_and_shrink(m)
-        out["shrunk_aabb"] = rr.bbox_aabb
-        out["shrunk_grid"] = rr.grid_dim
+        out["shrunk_aabb"] = rr.bbox_aabb.clone()      # clone: update_step_size later swaps .data of these buffers in place
+        out["shrunk_grid"] = rr.grid_dim.clone()
         out["shrunk_n_samples"] = rr.n_samples
         out["shrunk_step"] = rr.step_size
         out["shrunk_density_plane0"] = m.density_plane[0]

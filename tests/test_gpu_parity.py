@@ -506,3 +506,51 @@ def test_training_step_vs_oracle():
         lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
         diff = float((sd[k].detach().cpu() - pref.detach()).abs().max())
         assert diff <= 0.1 * lr * 2 + 1e-7, f"param {k}: max |diff| {diff:.3e} vs lr {lr}"   # elements with |g| ~ eps amplify gradient round-off
+
+
+# ============================================================================ field point API + grid surgery (8f rank 1)
+def test_field_point_api_golden_g3():
+    cl, op, *_ = _import()
+    g = load_golden("g3_field")
+    res = tuple(int(x) for x in g["res"])
+    P = op.make_params(int(g["seed"]), res, int(g["C"]), int(g["E"]))
+    m = build_model(cl, P, res, int(g["C"]), int(g["E"]), -10.0)
+    xn, vd = T(g["xn"]).to(DEV), T(g["viewdirs"]).to(DEV)
+    rel_close(m.compute_density_without_activation(xn), g["density_raw"], 1e-4, what="density_raw")
+    rel_close(m.compute_density(xn), g["density"], 1e-3, what="density")
+    feat = m.compute_appearance_feature(xn)
+    rel_close(feat, g["app_feat"], 1e-3, what="app_feat")
+    rel_close(m.render_appearance_mlp(vd, feat), g["rgb"], 1e-3, what="rgb")
+    rel_close(m.render_semantic_mlp(None, m.compute_semantic_feature(xn)), g["sem"], 1e-3, what="sem")
+    rel_close(m.render_instance_mlp(None, m.compute_instance_feature(xn)), g["inst"], 1e-3, what="inst")
+
+
+def test_shrink_and_upsample_golden_g10():
+    cl, op, *_ = _import()
+    g = load_golden("g10_grid_ops")
+    res = tuple(int(x) for x in g["res"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, 2, 3), res, amplitude=2.5, sigma_g=0.3)
+    m = build_model(cl, P, res, 2, 3, float(g["shift"]))
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+    alpha, _ = r.get_dense_alpha(m)
+    rel_close(alpha, g["dense_alpha"], 1e-3, atol=1e-6, what="dense alpha")
+    assert r.update_bbox_aabb_and_shrink(m)
+    rel_close(r.bbox_aabb, g["shrunk_aabb"], 1e-6, what="shrunk aabb")
+    assert r.grid_dim.tolist() == [int(x) for x in g["shrunk_grid"]]
+    assert r.n_samples == int(g["shrunk_n_samples"])
+    rel_close(r.step_size, g["shrunk_step"], 1e-6, what="step after shrink")
+    rel_close(m.density_plane[0], g["shrunk_density_plane0"], 1e-6, what="cropped density plane 0")
+    rel_close(m.density_line[0], g["shrunk_density_line0"], 1e-6, what="cropped density line 0")
+    rel_close(m.appearance_plane[2][:, ::7], g["shrunk_appearance_plane2"], 1e-6, what="cropped appearance plane 2")
+    target = r.get_target_resolution(4000)
+    assert list(target) == [int(x) for x in g["target_res"]]
+    m.upsample_volume_grid(target)
+    r.update_step_size(target)
+    rel_close(m.density_plane[1], g["up_density_plane1"], 1e-4, atol=1e-6, what="upsampled density plane 1")
+    rel_close(m.density_line[2], g["up_density_line2"], 1e-4, atol=1e-6, what="upsampled density line 2")
+    assert r.n_samples == int(g["up_n_samples"])
+    # the re-packed arena is live: a forward/backward still works and parameters are arena views
+    assert m.get_parameter("density_plane.1").data_ptr() >= m.param_flat.data_ptr()
+    rays = torch.tensor([[0.0, 0.0, -0.9, 0.0, 0.0, 1.0, 0.01, 1.9]], device=DEV)
+    rgb, *_ = r.forward(m, rays, 0, False, False)
+    assert bool(torch.isfinite(rgb).all())
