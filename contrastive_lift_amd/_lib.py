@@ -75,6 +75,7 @@ _SIGNATURES = {
     "clift_pixel_losses": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
     "clift_contrastive": ([_P, _P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
     "clift_slow_fast": ([_P, _P, _P, _I, _I, _P, _P, _P, _P], C.c_int),
+    "clift_nearest_centroid": ([_P, _I, _I, _P, _I, _P, _L, _P, _P], C.c_int),
     "clift_adam": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P], C.c_int),
     "clift_ema": ([_P, _P, _L, _F, _P], C.c_int),
 }

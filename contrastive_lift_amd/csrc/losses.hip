@@ -322,3 +322,29 @@ extern "C" int clift_ema(float* slow, const float* fast, long n, float momentum,
     k_ema<<<blocks, 256, 0, as_stream(s)>>>(slow, fast, n, momentum);
     return clift_check_launch("clift_ema");
 }
+
+// ============================================================================ nearest-centroid assignment (RP:371-419)
+// labels[i] = argmin_c |feat_i - centroid_c|  for points with valid[i] != 0 (else -1); K, E small (tens, 3).
+__global__ __launch_bounds__(256) void k_nearest_centroid(const float* __restrict__ feat, int ldf, int E, const float* __restrict__ cent, int K,
+                                                           const unsigned char* __restrict__ valid, long n, int* __restrict__ labels) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (valid && !valid[i]) { labels[i] = -1; return; }
+    const float* f = feat + i * ldf;
+    float best = INFINITY;
+    int arg = -1;
+    for (int c = 0; c < K; ++c) {
+        float d2 = 0.f;
+        for (int e = 0; e < E; ++e) { const float d = f[e] - cent[c * E + e]; d2 = fmaf(d, d, d2); }
+        if (d2 < best) { best = d2; arg = c; }
+    }
+    labels[i] = arg;
+}
+
+extern "C" int clift_nearest_centroid(const float* feat, int ldf, int E, const float* centroids, int K, const unsigned char* valid, long n,
+                                      int* labels, clift_stream_t s) {
+    CLIFT_REQUIRE(K >= 1 && E >= 1, "clift_nearest_centroid: need K >= 1 and E >= 1");
+    if (n <= 0) return 0;
+    k_nearest_centroid<<<cdiv(n, 256), 256, 0, as_stream(s)>>>(feat, ldf, E, centroids, K, valid, n, labels);
+    return clift_check_launch("clift_nearest_centroid");
+}

@@ -1,0 +1,159 @@
+"""Messy-Rooms ("MOS") scene reader -- the on-disk layout of reference dataset/many_object_scenes.py:22-207 feeding the
+ray / label tables the hot path consumes (SURVEY 8b 'Batch dict', 8f rank 4).
+
+Layout: ``color/<frame>.png``, ``metadata.json`` (camera K normalised by image size, positions, quaternions in Blender
+convention), ``detic_semantic/<frame>.npy``, ``detic_instance/<frame>.npy``, ``detic_probabilities/<frame>.npy``
+(optional GT ``semantic/``, ``instance/``).  The last 20 % of the sorted frames are the val/test split (:72).
+
+MI355X-first difference to the reference: rays are NOT precomputed on the host and shipped as 8 floats per pixel;
+``rays_for`` generates a frame's ray table on the device (clift_gen_rays) from 16 + 9 floats per camera, and the training
+tables live in HBM.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..rays import generate_ray_table
+
+
+def quat_to_rot(q):
+    """(w, x, y, z) unit quaternion -> 3x3 rotation (what pyquaternion.Quaternion(*q).rotation_matrix returns, :33)."""
+    w, x, y, z = [float(v) for v in q]
+    n = (w * w + x * x + y * y + z * z) ** 0.5
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def read_cameras(meta, H, W):
+    """:22-40: K rows scaled by (W, H), absolute value; pose = [R|t] @ diag(1,-1,-1,1) (Blender -> OpenCV)."""
+    K = np.array(meta["camera"]["K"], dtype=np.float64)
+    K[0] *= W
+    K[1] *= H
+    K = np.abs(K)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    poses = []
+    for t, q in zip(meta["camera"]["positions"], meta["camera"]["quaternions"]):
+        P = np.eye(4)
+        P[:3, :3] = quat_to_rot(q)
+        P[:3, 3] = np.array(t)
+        poses.append(P @ flip)
+    return K, poses
+
+
+def world_to_normscene(dims, intrinsics, cam2worlds, max_depth, rescale_factor=1.0):
+    """util/camera.py:10-73: bounding sphere of three frustum corners per camera at depths max_depth and 0.01
+    (centre = mean of the corner cloud, radius = farthest corner) mapped to the unit sphere."""
+    corners_hw = np.array([[0, 1, 1], [1, 0, 1], [1, 1, 1]], dtype=np.float64)
+    pts = []
+    for (h, w), K, c2w in zip(dims, intrinsics, cam2worlds):
+        Kinv = np.linalg.inv(np.asarray(K, np.float64)[[1, 0, 2]])       # K in (h, w) order
+        for depth in (max_depth, 0.01):
+            for c in corners_hw:
+                cam = Kinv @ (c * np.array([h, w, 1.0])) * depth
+                pts.append((np.asarray(c2w, np.float64) @ np.append(cam, 1.0))[:3])
+    pts = np.stack(pts)
+    center = pts.mean(0)
+    radius = np.linalg.norm(pts - center, axis=1).max()
+    s = 1.0 / (rescale_factor * radius)
+    M = np.eye(4)
+    M[:3, :3] *= s
+    M[:3, 3] = -center * s
+    return M
+
+
+class MOSScene:
+    def __init__(self, root_dir, split, image_dim, max_depth, subsample_frames=1, device="cuda",
+                 semantics_dir="detic_semantic", instance_dir="detic_instance"):
+        self.root = str(root_dir)
+        self.split = split
+        self.image_dim = (int(image_dim[0]), int(image_dim[1]))
+        self.device = torch.device(device)
+        self.semantics_dir, self.instance_dir = semantics_dir, instance_dir
+        names = [os.path.splitext(f)[0] for f in os.listdir(os.path.join(self.root, "color")) if f.endswith(".png")]
+        self.all_frame_names = sorted(names, key=lambda y: int(y) if y.isnumeric() else y)
+        n = len(self.all_frame_names)
+        idx = list(range(n))
+        self.val_indices = idx[int(n * 0.8):][::subsample_frames]
+        vs = set(idx[int(n * 0.8):])
+        self.train_indices = [i for i in idx if i not in vs][::subsample_frames]
+        img = np.array(Image.open(os.path.join(self.root, "color", f"{self.all_frame_names[0]}.png")))
+        img_h, img_w = img.shape[:2]
+        meta = json.load(open(os.path.join(self.root, "metadata.json")))
+        K, poses = read_cameras(meta, img_h, img_w)
+        self.scene2normscene = world_to_normscene([[img_h, img_w]] * n, [K] * n, poses, max_depth, 1.0)
+        self.normscene_scale = float(self.scene2normscene[0, 0])
+        scale = np.diag([self.image_dim[1] / img_w, self.image_dim[0] / img_h, 1.0])
+        self.intrinsics = {i: torch.from_numpy(scale @ K).float() for i in idx}
+        self.cam2normscene = {i: torch.from_numpy(self.scene2normscene @ poses[i]).float() for i in idx}
+        self.scene_bounds = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+        self.white_bg = False
+        self.segmentation_data = type("Seg", (), dict(fg_classes=[1], bg_classes=[0], num_semantic_classes=2, num_instances=1))()
+        self.num_semantics = 2
+
+    def __len__(self):
+        return len(self.train_indices if self.split == "train" else self.val_indices)
+
+    def frame_index(self, i):
+        return (self.train_indices if self.split == "train" else self.val_indices)[i]
+
+    def rays_for(self, sample_index):
+        H, W = self.image_dim
+        return generate_ray_table(H, W, self.intrinsics[sample_index], self.cam2normscene[sample_index], near=0.01, device=self.device)
+
+    def load_targets(self, sample_index):
+        """:146-207 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,2), confidences (HW,)."""
+        H, W = self.image_dim
+        name = self.all_frame_names[sample_index]
+        image = Image.open(os.path.join(self.root, "color", f"{name}.png"))
+        rgb = torch.from_numpy(np.array(image.resize((W, H), Image.LANCZOS)) / 255).float()[..., :3]
+        sem = np.load(os.path.join(self.root, self.semantics_dir, f"{name}.npy"))
+        inst = np.load(os.path.join(self.root, self.instance_dir, f"{name}.npy"))
+        prefix = self.semantics_dir.split("_")[0]
+        if prefix != "semantic":
+            conf = np.load(os.path.join(self.root, f"{prefix}_probabilities", f"{name}.npy")).astype(np.float32)
+            conf[sem == 0] = 1.0
+        else:
+            conf = np.ones_like(sem).astype(np.float32)
+        sem_t = torch.from_numpy(np.array(Image.fromarray(sem.astype(np.uint8)).resize((W, H), Image.NEAREST))).long()
+        inst_t = torch.from_numpy(np.array(Image.fromarray(inst.astype(np.int16)).resize((W, H), Image.NEAREST))).long()
+        conf_t = torch.nn.functional.interpolate(torch.from_numpy(conf).float()[None, None], size=(H, W), mode="bilinear",
+                                                 align_corners=False)[0, 0]
+        probs = torch.nn.functional.one_hot(sem_t, num_classes=self.num_semantics).float()
+        return dict(rgbs=rgb.reshape(-1, 3), semantics=sem_t.reshape(-1), instances=inst_t.reshape(-1),
+                    probabilities=probs.reshape(-1, self.num_semantics), confidences=conf_t.reshape(-1))
+
+    def build_train_tables(self):
+        """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
+        rays, tg = [], []
+        for i in self.train_indices:
+            rays.append(self.rays_for(i))
+            tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items()})
+        self.tables = dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]})
+        self.tables["mask"] = torch.ones(self.tables["rays"].shape[0], dtype=torch.bool, device=self.device)
+        hw = self.image_dim[0] * self.image_dim[1]
+        self.instance_images = []
+        for j in range(len(self.train_indices)):
+            sl = slice(j * hw, (j + 1) * hw)
+            m = self.tables["instances"][sl] != 0
+            if bool(m.any()):
+                self.instance_images.append(dict(rays=self.tables["rays"][sl][m], instances=self.tables["instances"][sl][m],
+                                                 confidences=self.tables["confidences"][sl][m]))
+        return self.tables
+
+    def pixel_batch(self, batch_size, generator=None):
+        n = self.tables["rays"].shape[0]
+        idx = torch.randint(0, n, (batch_size,), device=self.device, generator=generator)
+        return {k: v[idx] for k, v in self.tables.items()}
+
+    def instance_batch(self, max_rays, image_index):
+        img = self.instance_images[image_index % len(self.instance_images)]
+        n = img["rays"].shape[0]
+        if n > max_rays:
+            sel = torch.randperm(n, device=self.device)[:max_rays]
+            img = {k: v[sel] for k, v in img.items()}
+        return [dict(rays=img["rays"].contiguous(), instances=img["instances"], confidences=img["confidences"].contiguous())]

@@ -1,0 +1,128 @@
+"""Inference render loop and post-processing -- mirror of reference inference/render_panopli.py:108-140 (per-frame
+chunked rendering with is_train=False and the halved step ratio), util/camera.py:86-104 (distance_to_depth),
+RP:422-427 (create_instances_from_semantics), RP:371-419 (assign_clusters) and RP:196-263 (MeanShift clustering, which
+stays sklearn on the CPU exactly like the reference).
+"""
+import numpy as np
+import torch
+
+from . import _lib, engine
+
+
+@torch.no_grad()
+def render_rays(model, renderer, rays, chunk, white_bg=False):
+    """Chunked renderer(model, rays[i:i+chunk], perturb, white_bg, is_train=False) (RP:114-120): returns
+    rgb (P,3), semantics (P,C), instances (P,D), distance (P,)."""
+    outs = [[], [], [], []]
+    chunk = int(chunk) if chunk and int(chunk) > 0 else rays.shape[0]
+    for i in range(0, rays.shape[0], chunk):
+        o, ctx = engine.render_forward(model, renderer, rays[i:i + chunk], None, bool(white_bg))
+        outs[0].append(o["rgb"]); outs[1].append(o["semantics"]); outs[2].append(o["instances"]); outs[3].append(o["depth"].clone())
+        del ctx
+    return tuple(torch.cat(x, 0) for x in outs)
+
+
+def distance_to_depth(K, dist):
+    """util/camera.py:86-104 for a (H,W) distance image on the device: z = dist / |K^-1 [u, v, 1]|."""
+    H, W = dist.shape
+    dev = dist.device
+    u, v = torch.meshgrid(torch.arange(W, device=dev), torch.arange(H, device=dev), indexing="xy")
+    uvh = torch.stack([u.reshape(-1), v.reshape(-1), torch.ones(H * W, device=dev, dtype=torch.long)], -1).to(dist.dtype)
+    tmp = uvh @ torch.inverse(torch.as_tensor(K, dtype=dist.dtype, device=dev)).T
+    return dist.reshape(-1) / torch.linalg.norm(tmp, dim=1)
+
+
+def create_instances_from_semantics(instances, semantics, thing_classes):
+    """RP:422-427: prepend a column that is +inf for stuff pixels and -inf for thing pixels."""
+    stuff = ~torch.isin(semantics.argmax(dim=1), torch.tensor(list(thing_classes), device=semantics.device))
+    padded = torch.full((instances.shape[0], instances.shape[1] + 1), -float("inf"), device=instances.device)
+    padded[:, 1:] = instances
+    padded[stuff, 0] = float("inf")
+    return padded
+
+
+def _one_hot(all_labels, num_images, device):
+    all_labels = all_labels + 1                                  # -1,0,..,K-1 -> 0,1,..,K
+    n_lab = int(all_labels.max()) + 1
+    onehot = torch.zeros((all_labels.shape[0], n_lab), dtype=torch.float64, device=device)
+    onehot[torch.arange(all_labels.shape[0], device=device), all_labels] = 1
+    return onehot.view(num_images, -1, n_lab)
+
+
+@torch.no_grad()
+def assign_clusters(all_thing_features, all_points_semantics, all_centroids, device, num_images):
+    """RP:371-419: per thing class, nearest cached centroid (clift_nearest_centroid on the device); stuff pixels get
+    label -1; labels of successive classes are offset so they stay disjoint; returns one-hot (num_images, P, K+1)."""
+    feats = torch.as_tensor(all_thing_features, dtype=torch.float32, device=device)
+    sem = torch.cat([s.to(device) for s in all_points_semantics], 0).argmax(-1)
+    thing = feats[:, 0] == -float("inf")
+    f = feats[:, 1:].contiguous()
+    labels = torch.full((f.shape[0],), -1, dtype=torch.int64, device=device)
+    max_label = 0
+    for cls in torch.unique(sem[thing]).tolist():
+        cent = torch.as_tensor(np.asarray(all_centroids[cls]), dtype=torch.float32, device=device).contiguous()
+        valid = (thing & (sem == cls)).to(torch.uint8).contiguous()
+        lab = torch.empty((f.shape[0],), dtype=torch.int32, device=device)
+        _lib.call("clift_nearest_centroid", _lib.ptr(f), f.shape[1], f.shape[1], _lib.ptr(cent), cent.shape[0], _lib.ptr(valid),
+                  f.shape[0], _lib.ptr(lab), _lib.stream())
+        sel = valid.bool()
+        labels[sel] = lab[sel].long() + max_label
+        if bool(sel.any()):
+            max_label = int(labels[sel].max()) + 1
+    return _one_hot(labels, num_images, device)
+
+
+def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000, seed=None):
+    """RP:196-263 (MeanShift branch): outlier filter, per-axis rescale, subsample, sklearn MeanShift, predict all."""
+    from sklearn.cluster import MeanShift
+    feats = np.asarray(all_thing_features)
+    thing = feats[..., 0] == -float("inf")
+    f_th = feats[thing][:, 1:]
+    f_all = feats[:, 1:]
+    mu, sd = f_th.mean(0), f_th.std(0)
+    keep = np.all(np.abs(f_th - mu) < 3 * sd, axis=1)
+    cf = f_th[keep]
+    bias = cf.min(0)
+    factor = 1 / (cf.max(0) - cf.min(0))
+    cr = (cf - bias) * factor
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(cr.shape[0], min(num_points, cr.shape[0]), replace=False)
+    ms = MeanShift(bandwidth=bandwidth, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(cr[idx])
+    all_labels = ms.predict((f_all.reshape(-1, f_all.shape[-1]) - bias) * factor)
+    all_labels[~thing] = -1
+    return _one_hot(torch.as_tensor(all_labels, dtype=torch.int64, device=device), num_images, device), ms.cluster_centers_ / factor + bias
+
+
+def psnr(image_pred, image_gt):
+    """util/metrics.py:25-26."""
+    return -10 * torch.log10(torch.mean((image_pred.detach() - image_gt) ** 2))
+
+
+class ConfusionMatrix:
+    """util/metrics.py:29-75: confusion counts + robust mIoU (classes that are rare in both marginals are ignored)."""
+
+    def __init__(self, num_classes, ignore_class=None, robust=0.005):
+        self.n, self.ignore, self.robust = num_classes, list(ignore_class or []), robust
+        self.cm = np.zeros((num_classes, num_classes))
+
+    def _matrix(self, gt, pred):
+        m = (gt >= 0) & (gt < self.n)
+        return np.bincount(self.n * gt[m].astype(int) + pred[m], minlength=self.n ** 2).reshape(self.n, self.n)
+
+    def _miou(self, cm):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = np.diag(cm) / (cm.sum(1) + cm.sum(0) - np.diag(cm))
+        a0, a1, tot = cm.sum(0), cm.sum(1), cm.sum()
+        nonrobust = np.where((a0 / tot < self.robust) & (a1 / tot < self.robust))[0].tolist()
+        for i in self.ignore + nonrobust:
+            iou[i] = np.nan
+        return np.nanmean(iou)
+
+    def add_batch(self, gt_image, pre_image, return_miou=False):
+        cm = self._matrix(np.asarray(gt_image), np.asarray(pre_image))
+        self.cm += cm
+        if return_miou:
+            return self._miou(cm)
+
+    def get_miou(self):
+        return self._miou(self.cm)

@@ -25,7 +25,7 @@ def default_config(**over):
              late_semantic_optimization=1, instance_optimization_epoch=3, chunk=2048, perturb=1.0, batch_size=2048,
              max_rays_instances=1024, max_instances=3, instance_loss_mode="slow_fast", use_DINO_style=True,
              semantic_weight_mode="softmax", stop_semantic_grad=True, probabilistic_ce_mode="TTAConf", weight_class_0=0.0,
-             decay_step=[9, 10], decay_gamma=0.5, temperature=100.0, white_bg=False)
+             decay_step=[9, 10], decay_gamma=0.5, temperature=100.0)
     c.update(over)
     return types.SimpleNamespace(**c)
 
@@ -53,8 +53,9 @@ class ArenaAdam:
 class HotPathTrainer:
     """Owns field + renderer + the two Adam optimizers; ``training_step`` = main pass + instance pass."""
 
-    def __init__(self, model, renderer, config, class_weights=None, current_epoch=0):
+    def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
+        self.white_bg = bool(white_bg)            # dataset attribute in the reference (train_set.white_bg, T:109)
         self.device = model.param_flat.device
         self.current_epoch = current_epoch
         C = model.num_semantic_classes
@@ -103,7 +104,7 @@ class HotPathTrainer:
         ctxs, outs = [], []
         for i in range(0, B, chunk):
             if white_bg is None:
-                wb = bool(c.white_bg) or bool(torch.rand((1,)) < 0.5)       # renderer.py:164
+                wb = self.white_bg or bool(torch.rand((1,)) < 0.5)       # renderer.py:164
             else:
                 wb = bool(white_bg)
             o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,

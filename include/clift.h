@@ -205,6 +205,11 @@ int clift_contrastive(const float* feat, const int* labels, int B, int E, float 
 int clift_slow_fast(const float* inst, const int* labels, const float* conf, int B, int E, float* loss,
                     float* g_inst, float* work, clift_stream_t s);
 
+/* ---- inference post-processing: inference/render_panopli.py:371-419 (assign_clusters: per-class cdist + argmin against
+ * cached centroids).  labels[i] = argmin_c |feat_i - centroid_c| where valid[i] != 0 (NULL = all), else -1. */
+int clift_nearest_centroid(const float* feat, int ldf, int E, const float* centroids, int K, const unsigned char* valid,
+                           long n, int* labels, clift_stream_t s);
+
 /* ---- optimiser plumbing on flat fp32 ranges: torch.optim.Adam semantics (L2 weight decay folded into the
  * gradient; bias correction with step >= 1) and the slow-net EMA (trainer T:325-329). */
 int clift_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

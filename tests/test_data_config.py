@@ -1,0 +1,45 @@
+"""CPU checks of the config-tree loader and the MOS reader's camera conventions (no kernels)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from conftest import REPO
+
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+
+def test_config_tree_matches_reference_interface():
+    from contrastive_lift_amd.config import load_config, save_config, load_run_config
+    c = load_config(os.path.join(REPO, "config"), overrides=["+experiment=contrastive_lift_MOS", "template.lr=1e-3", "dataset_root=/x/scene_1"])
+    assert c.dataset_class == "mos" and c.instance_loss_mode == "slow_fast" and c.use_DINO_style is True and c.max_instances == 3
+    assert isinstance(c.lr, float) and c.lr == 1e-3 and isinstance(c.weight_decay, float) and c.weight_decay == 1e-8
+    assert c.batch_size == 2048 and c.chunk == 2048 and c.max_rays_instances == 1024 and c.min_grid_dim == 128 and c.max_grid_dim == 192
+    assert c.bbox_aabb_reset_epochs == [1, 2, 3] and c.grid_upscale_epochs == [1, 2, 3, 4] and c.late_semantic_optimization == 2
+    d = load_config(os.path.join(REPO, "config"))
+    assert d.instance_loss_mode == "linear_assignment" and d.max_instances == 25 and d.dataset_class == "panopli"
+    p = os.path.join("/tmp", "clift_cfg_test", "config.yaml")
+    save_config(c, p)
+    assert load_run_config(p).dataset_root == "/x/scene_1"
+
+
+def test_mos_camera_conventions(tmp_path):
+    import make_synthetic_mos as gen
+    from contrastive_lift_amd.data.mos import read_cameras, quat_to_rot, world_to_normscene
+    out = gen.make_scene(str(tmp_path / "scene"), n_frames=6, size=16)
+    meta = json.load(open(os.path.join(out, "metadata.json")))
+    K, poses = read_cameras(meta, 16, 16)
+    assert abs(K[0, 0] - 1.1 * 16) < 1e-9 and abs(K[0, 2] - 8) < 1e-9
+    for P, pos in zip(poses, meta["camera"]["positions"]):
+        R = P[:3, :3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(R) - 1) < 1e-9
+        fwd = R[:, 2]                                   # OpenCV: +z looks at the scene centre
+        to_c = np.array([0, 0, 0.25]) - np.array(pos)
+        assert np.dot(fwd, to_c / np.linalg.norm(to_c)) > 0.999
+    q = np.array([0.5, 0.5, 0.5, 0.5])
+    assert np.allclose(quat_to_rot(q), np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]]), atol=1e-12)
+    M = world_to_normscene([[16, 16]] * 6, [K] * 6, poses, max_depth=5.0)
+    for P in poses:                                     # every camera ends up inside the unit sphere
+        assert np.linalg.norm((M @ P)[:3, 3]) < 1.0

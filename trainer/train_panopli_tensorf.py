@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Drop-in for reference trainer/train_panopli_tensorf.py (T:473-489): same config tree and Hydra-style overrides, same
+run directory (runs/<experiment>/config.yaml, runs/<experiment>/checkpoints/*.ckpt in the Lightning layout).
+
+    python trainer/train_panopli_tensorf.py +experiment=contrastive_lift_MOS dataset_root=data/mos/<scene> [key=value ...]
+    python -m torch.distributed.run --nproc-per-node 8 trainer/train_panopli_tensorf.py ...     # one process per GPU (RCCL)
+
+Epoch schedule of the reference (T:446-459): dist-reg ramp, bbox shrink at ``bbox_aabb_reset_epochs``, log-spaced grid
+upsampling at ``grid_upscale_epochs`` (after which the optimizers are rebuilt and weight decay drops to 0), LR decay at
+``decay_step``; instance pass from ``instance_optimization_epoch + late_semantic_optimization`` on (T:46).
+"""
+import datetime
+import math
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import contrastive_lift_amd as cl                                        # noqa: E402
+from contrastive_lift_amd.config import load_config, save_config          # noqa: E402
+from contrastive_lift_amd.data import MOSScene                            # noqa: E402
+from contrastive_lift_amd.inference import psnr                           # noqa: E402
+from contrastive_lift_amd.trainer import HotPathTrainer                   # noqa: E402
+
+
+def experiment_name(config):
+    """trainer/__init__.py:48-58 without the random-name dependency."""
+    if config.get("resume"):
+        return Path(config.resume).parents[1].name
+    if os.environ.get("experiment"):
+        return os.environ["experiment"]
+    return f"{datetime.datetime.now().strftime('%m%d%H%M')}_MOS_{Path(config.dataset_root).stem}_{config.experiment}"
+
+
+def main(argv):
+    config_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config")
+    for a in list(argv):
+        if a.startswith("--config-dir="):
+            config_dir = a.split("=", 1)[1]
+            argv.remove(a)
+    cfg = load_config(config_dir, overrides=argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise ValueError("No GPU found")                                   # trainer/__init__.py:121-122
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if isinstance(cfg.image_dim, int):
+        cfg.image_dim = [cfg.image_dim, cfg.image_dim]
+    cfg.experiment = experiment_name(cfg)
+    seed = cfg.seed if cfg.seed is not None else 0
+    torch.manual_seed(seed)                                                # identical initial weights on every rank
+    cfg.instance_optimization_epoch = cfg.instance_optimization_epoch + cfg.late_semantic_optimization     # T:46
+    cfg.segment_optimization_epoch = cfg.segment_optimization_epoch + cfg.late_semantic_optimization       # T:47
+    if cfg.dataset_class != "mos":
+        raise NotImplementedError("only the MOS (Messy-Rooms) on-disk layout is wired in this round (SURVEY 8f rank 4)")
+    scene = MOSScene(cfg.dataset_root, "train", cfg.image_dim, cfg.max_depth, subsample_frames=cfg.subsample_frames, device=dev)
+    scene.build_train_tables()
+    val = MOSScene(cfg.dataset_root, "val", cfg.image_dim, cfg.max_depth, subsample_frames=cfg.subsample_frames, device=dev)
+    total_classes = 2
+    slow_fast = cfg.instance_loss_mode == "slow_fast"
+    g = int(cfg.min_grid_dim)
+    model = cl.TensorVMSplit([g, g, g], num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=total_classes,
+                             dim_feature_instance=2 * cfg.max_instances if slow_fast else cfg.max_instances,
+                             output_mlp_semantics=torch.nn.Identity() if cfg.semantic_weight_mode != "softmax" else torch.nn.Softmax(dim=-1),
+                             use_semantic_mlp=cfg.use_mlp_for_semantics, use_instance_mlp=cfg.use_mlp_for_instances,
+                             pe_sem=cfg.pe_sem, pe_ins=cfg.pe_ins, slow_fast_mode=slow_fast, use_proj=cfg.use_proj, device=dev)
+    renderer = cl.TensoRFRenderer(scene.scene_bounds, [g, g, g], semantic_weight_mode=cfg.semantic_weight_mode,
+                                  stop_semantic_grad=cfg.stop_semantic_grad).to(dev)
+    cw = torch.ones(total_classes)
+    cw[0] = cfg.weight_class_0
+    tr = HotPathTrainer(model, renderer, cfg, class_weights=cw, current_epoch=0)
+    run_dir = Path("runs") / cfg.experiment
+    if rank == 0:
+        (run_dir / "checkpoints").mkdir(parents=True, exist_ok=True)
+        save_config(cfg, str(run_dir / "config.yaml"))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 9973 + rank)                                    # every rank draws its own pixels (DistributedSampler role)
+    per_rank = max(1, int(cfg.batch_size) // world)
+    steps_per_epoch = int(cfg.get("steps_per_epoch") or max(1, scene.tables["rays"].shape[0] // int(cfg.batch_size)))
+    voxels = torch.round(torch.exp(torch.linspace(np.log(cfg.min_grid_dim ** 3), np.log(cfg.max_grid_dim ** 3),
+                                                  len(cfg.grid_upscale_epochs) + 1))).long().tolist()[1:]           # T:451
+    gstep = 0
+    for epoch in range(int(cfg.max_epoch)):
+        tr.current_epoch = epoch
+        tr.on_train_epoch_start()
+        if epoch in list(cfg.bbox_aabb_reset_epochs):
+            renderer.update_bbox_aabb_and_shrink(model)
+            tr.setup_optimizers()
+        if epoch in list(cfg.grid_upscale_epochs):
+            target = renderer.get_target_resolution(voxels[list(cfg.grid_upscale_epochs).index(epoch)])
+            cfg.weight_decay = 0
+            model.upsample_volume_grid(target)
+            renderer.update_step_size(target)
+            tr.setup_optimizers()
+        lr_scale = float(cfg.decay_gamma) ** sum(1 for m in cfg.decay_step if epoch >= m)                           # MultiStepLR, stepped per epoch
+        tr.opt_main.lr_scale = tr.opt_inst.lr_scale = lr_scale
+        for it in range(steps_per_epoch):
+            batch = {0: scene.pixel_batch(per_rank, gen)}
+            if epoch >= cfg.instance_optimization_epoch and scene.instance_images:
+                batch[1] = scene.instance_batch(int(cfg.max_rays_instances), gstep * world + rank)
+            tr.training_step(batch)
+            gstep += 1
+            if rank == 0 and gstep % int(cfg.save_every_n_train_steps) == 0:
+                tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep)
+            if rank == 0 and (it % 50 == 0 or it == steps_per_epoch - 1):
+                l = tr.losses.tolist()
+                print(f"epoch {epoch} it {it}/{steps_per_epoch} loss_rgb {l[0]:.5f} (psnr {-10 * math.log10(max(l[0], 1e-12)):.2f}) "
+                      f"loss_sem {l[1]:.4f} tv {l[2]:.5f} clustering {l[3]:.4f} S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
+        if rank == 0:
+            tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep)
+            from contrastive_lift_amd.inference import render_rays
+            ps = []
+            for i in val.val_indices[:4]:
+                rgb, *_ = render_rays(model, renderer, val.rays_for(i), 8192, False)
+                ps.append(float(psnr(rgb, val.load_targets(i)["rgbs"].to(dev))))
+            print(f"epoch {epoch} val psnr {np.mean(ps):.2f}", flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return str(run_dir)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
