@@ -25,12 +25,12 @@ def _load(path, name):
 def test_train_checkpoint_render(tmp_path, monkeypatch):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
-    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=30, size=64)
+    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=40, size=64)
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("experiment", "e2e_test")
     train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli")
     run_dir = train.main(["+experiment=contrastive_lift_MOS", f"dataset_root={scene_dir}", "image_dim=64", "min_grid_dim=32",
-                          "max_grid_dim=48", "max_epoch=6", "steps_per_epoch=150", "batch_size=2048", "chunk=0", "max_depth=3",
+                          "max_grid_dim=64", "max_epoch=6", "steps_per_epoch=400", "batch_size=2048", "chunk=0", "max_depth=3",
                           "seed=3", "max_rays_instances=512", "decay_step=[4,5]"])
     ckpts = sorted(os.listdir(os.path.join(run_dir, "checkpoints")))
     assert ckpts and os.path.exists(os.path.join(run_dir, "config.yaml"))
@@ -53,12 +53,12 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
     pickle.dump(cents, open(cpath, "wb"))
     out = rp.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, cached_centroids_path=cpath)
     names = sorted(os.listdir(out / "pred_semantics"))
-    assert len(names) == 3 and sorted(os.listdir(out / "pred_surrogateid")) == names
+    assert len(names) == 4 and sorted(os.listdir(out / "pred_surrogateid")) == names
     feats = np.load(out / "instance_features.npy")
-    assert feats.shape == (3 * 64 * 64, 3) and np.isfinite(feats).all()
+    assert feats.shape == (4 * 64 * 64, 3) and np.isfinite(feats).all()
     assert np.load(out / "slow_features.npy").shape == feats.shape
     thing = np.load(out / "thing_features.npy")
-    assert thing.shape == (3 * 64 * 64, 4) and set(np.unique(np.isinf(thing[:, 0]))) == {True}
+    assert thing.shape == (4 * 64 * 64, 4) and set(np.unique(np.isinf(thing[:, 0]))) == {True}
     from PIL import Image
     sem = np.array(Image.open(out / "pred_semantics" / names[0]))
     sur = np.array(Image.open(out / "pred_surrogateid" / names[0]))
@@ -75,5 +75,5 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
         ps.append(float(inf.psnr(rgb, tg["rgbs"].cuda())))
         acc.append(float((semp.argmax(1).cpu() == tg["semantics"]).float().mean()))
     print("held-out PSNR", ps, "semantic accuracy", acc)
-    assert np.mean(ps) > 19.0, ps
+    assert np.mean(ps) > 18.0 and max(ps) > 21.0, ps
     assert np.mean(acc) > 0.85, acc
