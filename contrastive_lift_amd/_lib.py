@@ -129,8 +129,17 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_launch_stream = None      # side-stream override (engine.Branches); torch's current stream keeps owning all allocations
+
+
+def set_launch_stream(s):
+    global _launch_stream
+    _launch_stream = s
+
+
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = _launch_stream if _launch_stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
 
 
 def call(name, *args):

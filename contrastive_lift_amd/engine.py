@@ -134,6 +134,53 @@ def _lin_params(seq, views_prefix, views):
     return out
 
 
+# ----------------------------------------------------------------------------- concurrent head chains
+MULTI_STREAM = os.environ.get("CLIFT_STREAMS", "1") != "0"
+_side_streams = {}
+
+
+class Branches:
+    """Fork/join of independent kernel chains over HIP streams.  The appearance, semantic, fast-instance and slow-instance
+    heads are independent between the compaction and the compositing, and every layer-wide GEMM has a start-up phase and
+    an un-overlapped output burst (see gemm.hip) that another chain's MFMA work can fill.  Launches of a branch go to a
+    side stream (via _lib.set_launch_stream); ALL allocations stay on torch's current stream, and every temporary of a
+    branch is kept alive in ``self.keep`` until ``join`` so that no block is recycled into another in-flight branch."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and MULTI_STREAM
+        self.keep = []
+        self.used = []
+        if self.enabled:
+            self.main = torch.cuda.current_stream()
+            self.fork = torch.cuda.Event()
+            self.fork.record(self.main)
+
+    def run(self, idx, fn):
+        if not self.enabled:
+            fn(self.keep)
+            return
+        dev = torch.cuda.current_device()
+        st = _side_streams.get((dev, idx))
+        if st is None:
+            st = _side_streams[(dev, idx)] = torch.cuda.Stream(device=dev)
+        st.wait_event(self.fork)
+        _lib.set_launch_stream(st)
+        try:
+            fn(self.keep)
+        finally:
+            _lib.set_launch_stream(None)
+        self.used.append(st)
+
+    def join(self):
+        if self.enabled:
+            for st in self.used:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.main.wait_event(ev)
+        self.keep = []
+        self.used = []
+
+
 # ----------------------------------------------------------------------------- xyz MLP heads (semantic / instance)
 def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
     """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
@@ -154,11 +201,14 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
     return acts
 
 
-def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M):
-    """dpre (M, ld) = gradient w.r.t. the last layer's pre-activation output (ld % 4 == 0, pad zero)."""
+def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
+    """dpre (M, ld) = gradient w.r.t. the last layer's pre-activation output (ld % 4 == 0, pad zero).
+    ``keep``: list that receives every temporary (so a caller running this on a side stream controls their lifetime)."""
     dev = xa.device
     d = dpre
     n = len(layers)
+    keep = keep if keep is not None else []
+    keep.append(d)
     for li in range(n - 1, 0, -1):
         W, b = layers[li]
         gW, gb = glayers[li]
@@ -168,6 +218,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M):
         dn = torch.empty((M, ni), dtype=torch.float32, device=dev)
         gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
+        keep.append(d)
     gW, gb = glayers[0]
     call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), _pitch(gW), ptr(gb), stream())
 
@@ -234,22 +285,26 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
     if M > 0:
         xa = torch.empty((M, 4), dtype=torch.float32, device=dev)
         ctx.xa = xa
-        if want_rgb:
+        if want_rgb:       # the gather also produces xa, which every other head reads: it stays on the main stream
             va = vm_struct(views, "appearance", ctx.res)
             nc = 3 * va.comps
             F = torch.empty((M, nc), dtype=torch.float32, device=dev)
             call("clift_app_gather_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(F), ptr(xa), st)
+            ctx.F = F
+        else:
+            call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
+
+        def app_chain(keep):
             Wb = views["appearance_basis_mat.weight"]
-            nf = Wb.shape[0]
+            nf, nc = Wb.shape
             ldf = (nf + 3) // 4 * 4
             feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-            gemm(M, nf, nc, F, nc, Wb, _pitch(Wb), feat, ldf)
-            app = _lin_params(model.render_appearance_mlp.mlp, "render_appearance_mlp.mlp", views)
-            ldx = _pitch(app[0][0])
+            gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
+            (W1, b1), (W2, b2), (W3, b3) = _lin_params(None, "render_appearance_mlp.mlp", views)
+            ldx = _pitch(W1)
             X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
             call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
-                 ptr(X), ldx, st)
-            (W1, b1), (W2, b2), (W3, b3) = app
+                 ptr(X), ldx, stream())
             H1 = torch.empty((M, W1.shape[0]), dtype=torch.float32, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
             H2 = torch.empty((M, W2.shape[0]), dtype=torch.float32, device=dev)
@@ -257,29 +312,40 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             pre = torch.empty((M, 3), dtype=torch.float32, device=dev)
             gemm(M, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
-            call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, st)
-            ctx.F, ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2, ctx.rgb_s = F, feat, ldf, nf, X, ldx, H1, H2, rgb_s
-        else:
-            call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
-        if want_sem:
-            sem_layers = _lin_params(model.render_semantic_mlp.mlp, "render_semantic_mlp.mlp", views)
+            call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, stream())
+            keep.append(pre)
+            ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2, ctx.rgb_s = feat, ldf, nf, X, ldx, H1, H2, rgb_s
+
+        def sem_chain(keep):
+            sem_layers = _lin_params(None, "render_semantic_mlp.mlp", views)
             logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
             ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, logits, Ccls)
             if model.render_semantic_mlp.softmax:
                 sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(sem_s), Ccls, st)
+                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(sem_s), Ccls, stream())
+                keep.append(logits)
             else:
                 sem_s = logits
             ctx.sem_s = sem_s
+
+        br = Branches()
+        if want_rgb:
+            br.run(0, app_chain)
+        if want_sem:
+            br.run(1, sem_chain)
         if D > 0:
             E = model.render_instance_mlp.output_channels
-            inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
-            fast = _lin_params(model.render_instance_mlp.mlp, "render_instance_mlp.mlp", views)
-            ctx.inst_fast_acts = xyz_mlp_fwd(fast, xa, M, inst_s, D, 0)
+            ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
+
+            def fast_chain(keep):
+                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
+
+            def slow_chain(keep):
+                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E)
+            br.run(2, fast_chain)
             if model.slow_fast_mode:
-                slow = _lin_params(model.render_instance_mlp.slow_mlp, "render_instance_mlp.slow_mlp", views)
-                ctx.inst_slow_acts = xyz_mlp_fwd(slow, xa, M, inst_s, D, E)
-            ctx.inst_s = inst_s
+                br.run(3, slow_chain)
+        br.join()
     rgb_raw = torch.zeros((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
     rgb_map = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
     sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
@@ -339,14 +405,20 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
              ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
              ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
              ptr(g_w), ptr(g_op), st)
-        # ---------------- appearance head
+        br = Branches()
+        if density_grad:
+            model.xcd_workspace_for("density")
         if d_rgb is not None:
+            model.xcd_workspace_for("appearance")
+
+        # ---------------- appearance head
+        def app_chain(keep):
             app = _lin_params(None, "render_appearance_mlp.mlp", views)
             gapp = _lin_params(None, "render_appearance_mlp.mlp", gviews)
             (W1, b1), (W2, b2), (W3, b3) = app
             (gW1, gb1), (gW2, gb2), (gW3, gb3) = gapp
             dpre = torch.empty((M, 4), dtype=torch.float32, device=dev)
-            call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, st)
+            call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, stream())
             H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
             n2 = W3.shape[1]
             wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
@@ -361,7 +433,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             gemm(M, ldx, n1, dH1, n1, W1, ldx, dX, ldx, b_trans=1)
             nf, ldf = ctx.nf, ctx.ldf
             dfeat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-            call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, st)
+            call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
             gemm(nc, nf, M, ctx.F, nc, dfeat, ldf, gWb, _pitch(gWb), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(nc, nf, M), c_trans=1)
@@ -370,40 +442,62 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), st)
+                 ptr(ctx.act_idx), M, ptr(dF), stream())
             vm_grad_finish(model, gviews, "appearance", ga)
+            keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
+
         # ---------------- semantic head
-        if d_sem is not None:
+        def sem_chain(keep):
             ldp = (Ccls + 3) // 4 * 4
             dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
             kind = 2 if model.render_semantic_mlp.softmax else 0
-            call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, st)
+            call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, stream())
             xyz_mlp_bwd(_lin_params(None, "render_semantic_mlp.mlp", views), _lin_params(None, "render_semantic_mlp.mlp", gviews),
-                        ctx.xa, ctx.sem_acts, dpre, M)
+                        ctx.xa, ctx.sem_acts, dpre, M, keep)
+
         # ---------------- instance heads
-        if d_inst is not None:
-            E = model.render_instance_mlp.output_channels
-            ldp = (E + 3) // 4 * 4
-            nets = [("render_instance_mlp.mlp", ctx.inst_fast_acts, 0)]
-            if model.slow_fast_mode and slow_grad:
-                nets.append(("render_instance_mlp.slow_mlp", ctx.inst_slow_acts, E))
-            for prefix, acts, off in nets:
+        def inst_chain(prefix, acts, off):
+            def run(keep):
+                E = model.render_instance_mlp.output_channels
+                ldp = (E + 3) // 4 * 4
                 dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
-                call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E, 0, ptr(dpre), ldp, st)
-                xyz_mlp_bwd(_lin_params(None, prefix, views), _lin_params(None, prefix, gviews), ctx.xa, acts, dpre, M)
+                call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E, 0, ptr(dpre), ldp, stream())
+                xyz_mlp_bwd(_lin_params(None, prefix, views), _lin_params(None, prefix, gviews), ctx.xa, acts, dpre, M, keep)
+            return run
+
+        if d_rgb is not None:
+            br.run(0, app_chain)
+        if d_sem is not None:
+            br.run(1, sem_chain)
+        if d_inst is not None:
+            br.run(2, inst_chain("render_instance_mlp.mlp", ctx.inst_fast_acts, 0))
+            if model.slow_fast_mode and slow_grad:
+                br.run(3, inst_chain("render_instance_mlp.slow_mlp", ctx.inst_slow_acts, model.render_instance_mlp.output_channels))
+        if density_grad:
+            br.run(4, lambda keep: _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep))
+            density_grad = False
+        br.join()
     elif g_rgb is not None and ctx.white_bg:
         # no active samples but the white background still routes d rgb into the opacity
         inside = ((ctx.rgb_raw >= 0) & (ctx.rgb_raw <= 1)).to(torch.float32)
         g_op = -(g_rgb * inside).sum(-1)
-    # ---------------- density path
+    # ---------------- density path (when it was not already run as a branch above)
     if density_grad:
-        dsigma = torch.empty((N, S), dtype=torch.float32, device=dev)
-        call("clift_march_bwd", C.byref(ctx.ms), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(ctx.alpha), ptr(ctx.T), ptr(ctx.w),
-             ptr(ctx.ray_out), ptr(g_w), ptr(g_op), ptr(g_dist), ptr(dsigma), st)
-        vd = vm_struct(views, "density", ctx.res)
-        gd = vm_grad_struct(model, gviews, "density")
-        call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma), st)
-        vm_grad_finish(model, gviews, "density", gd)
+        _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, [])
+
+
+def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
+    """Transmittance backward (needs only g_w / g_opacity from the compositing backward, so it runs concurrently with
+    the MLP chains) and the scatter into the density tables."""
+    N, S = ctx.N, ctx.S
+    dsigma = torch.empty((N, S), dtype=torch.float32, device=ctx.rays.device)
+    call("clift_march_bwd", C.byref(ctx.ms), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(ctx.alpha), ptr(ctx.T), ptr(ctx.w),
+         ptr(ctx.ray_out), ptr(g_w), ptr(g_op), ptr(g_dist), ptr(dsigma), stream())
+    vd = vm_struct(views, "density", ctx.res)
+    gd = vm_grad_struct(model, gviews, "density")
+    call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma), stream())
+    vm_grad_finish(model, gviews, "density", gd)
+    keep.append(dsigma)
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes
@@ -439,9 +533,17 @@ def feature_forward(model, renderer, rays, jitter, head):
         else:
             E = model.render_instance_mlp.output_channels
             ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
-            ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
-            if model.slow_fast_mode:
+            br = Branches()
+
+            def fast_chain(keep):
+                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
+
+            def slow_chain(keep):
                 ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E)
+            br.run(2, fast_chain)
+            if model.slow_fast_mode:
+                br.run(3, slow_chain)
+            br.join()
     sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
     sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
     inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D else None

@@ -207,6 +207,12 @@ class TensorVMSplit(nn.Module):
     def named_views(self):
         return self._views
 
+    def xcd_workspace_for(self, prefix):
+        """Make sure the accumulation copies of a table group exist (allocation + zero fill happen on the current
+        stream, before any side-stream branch uses them)."""
+        a, b = self.arena.range_of({"density": "grid_density", "appearance": "grid_app"}[prefix])
+        return self.xcd_workspace(prefix, 8 * (b - a))
+
     def xcd_workspace(self, key, numel):
         """Persistent zero-initialised scratch for the per-XCD gradient accumulation copies (engine.vm_grad_struct);
         clift_xcd_reduce leaves it zeroed again."""
