@@ -65,6 +65,7 @@ _SIGNATURES = {
     "clift_gemm": ([_P, _P], C.c_int),
     "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _P], C.c_int),
     "clift_linear_k3_bwd": ([_P, _P, _I, _I, _I, _P, _I, _P, _P], C.c_int),
+    "clift_wgrad_narrow": ([_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P], C.c_int),
     "clift_colsum": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "clift_rows_act_fwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "clift_rows_act_bwd": ([_P, _I, _P, _I, _I, _I, _I, _P, _I, _P], C.c_int),

@@ -314,6 +314,75 @@ extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, in
     return clift_check_launch("clift_linear_k3_bwd");
 }
 
+// ============================================================================ narrow wgrad (out_features <= 32)
+// gW[c][j] += sum_s dY[s][c] X[s][j],  gb[c] += sum_s dY[s][c]   for c < NO <= 32, j < ni.
+// A 22 x 256 output over 265 k samples is a streaming reduction (it reads X once: 271 MB), not matrix-core work: an MFMA
+// tile would be 83 % padding.  Thread = input feature j (coalesced 1 KB rows of X), the NO partial sums live in
+// registers, dY rows are broadcast from LDS; one atomic per (c, j) per block.
+template <int NO>
+__global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ dY, int ldd, int no, const float* __restrict__ X, int ldx, int ni,
+                                                       int M, int rows_per_block, float* __restrict__ gW, int ldw, float* __restrict__ gb) {
+    __shared__ __attribute__((aligned(16))) float ds[64 * NO];
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
+    float acc[NO];
+#pragma unroll
+    for (int c = 0; c < NO; ++c) acc[c] = 0.f;
+    float bsum = 0.f;      // thread c < no of blockIdx.y == 0 also accumulates the bias gradient
+    for (int mc = mb; mc < me; mc += 64) {
+        const int lim = min(64, me - mc);
+        __syncthreads();
+        for (int e = threadIdx.x; e < lim * NO; e += 256) {
+            const int r = e / NO, c = e - r * NO;
+            ds[e] = (c < no) ? dY[(size_t)(mc + r) * ldd + c] : 0.f;
+        }
+        __syncthreads();
+        if (j < ni) {
+            int r = 0;
+            for (; r + 4 <= lim; r += 4) {        // 4 rows in flight per thread: independent 1 KB-per-wave loads
+                float x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = X[(size_t)(mc + r + q) * ldx + j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < NO; c += 4) {
+                        const float4 d = *reinterpret_cast<const float4*>(ds + (r + q) * NO + c);   // LDS broadcast
+                        acc[c] = fmaf(d.x, x[q], acc[c]); acc[c + 1] = fmaf(d.y, x[q], acc[c + 1]);
+                        acc[c + 2] = fmaf(d.z, x[q], acc[c + 2]); acc[c + 3] = fmaf(d.w, x[q], acc[c + 3]);
+                    }
+            }
+            for (; r < lim; ++r) {
+                const float xv = X[(size_t)(mc + r) * ldx + j];
+#pragma unroll
+                for (int c = 0; c < NO; ++c) acc[c] = fmaf(ds[r * NO + c], xv, acc[c]);
+            }
+        }
+        if (blockIdx.y == 0 && threadIdx.x < no && gb)
+            for (int r = 0; r < lim; ++r) bsum += ds[r * NO + threadIdx.x];
+    }
+    if (j < ni) {
+#pragma unroll
+        for (int c = 0; c < NO; ++c)
+            if (c < no) unsafeAtomicAdd(gW + (size_t)c * ldw + j, acc[c]);
+    }
+    if (blockIdx.y == 0 && threadIdx.x < no && gb) unsafeAtomicAdd(gb + threadIdx.x, bsum);
+}
+
+extern "C" int clift_wgrad_narrow(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw, float* gb,
+                                  clift_stream_t s) {
+    CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_wgrad_narrow: out_features must be in [1,32] (got %d)", no);
+    if (M <= 0 || ni <= 0) return 0;
+    const int rpb = 128;
+    const dim3 grid(cdiv(M, rpb), cdiv(ni, 256));
+    hipStream_t st = as_stream(s);
+    if (no <= 4) k_wgrad_narrow<4><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
+    else if (no <= 8) k_wgrad_narrow<8><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
+    else if (no <= 16) k_wgrad_narrow<16><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
+    else k_wgrad_narrow<32><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
+    return clift_check_launch("clift_wgrad_narrow");
+}
+
 // db[n] += sum_m dY[m][n]
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, int ld, int M, int N, int rows_per_block,
                                                  float* __restrict__ db) {

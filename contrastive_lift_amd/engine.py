@@ -108,14 +108,13 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
 
 
 def wgrad(no, ni, M, dY, ldd, X, ldx, gW, gb):
-    """gW (no, ni) += dY^T X over the M samples; gb (no) += column sums of dY.  Wide layers: the bias sum is fused
-    into the GEMM (read from the A tile already staged in LDS).  Narrow layers (no <= 32): solved as the transposed
-    problem gW^T = X^T dY so that the narrow dimension is the 32-wide N tile instead of wasting a 128-row M tile."""
+    """gW (no, ni) += dY^T X over the M samples; gb (no) += column sums of dY.  Wide layers: matrix cores, the bias sum
+    fused into the GEMM (read from the A tile already staged in LDS).  Narrow layers (no <= 32): a streaming VALU
+    reduction at HBM rate (clift_wgrad_narrow)."""
     if no > 32:
         gemm(no, ni, M, dY, ldd, X, ldx, gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(no, ni, M), colsum=gb)
     else:
-        gemm(ni, no, M, X, ldx, dY, ldd, gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(ni, no, M), c_trans=1)
-        call("clift_colsum", ptr(dY), ldd, M, no, ptr(gb), stream())
+        call("clift_wgrad_narrow", ptr(dY), ldd, no, ptr(X), ldx, ni, M, ptr(gW), _pitch(gW), ptr(gb), stream())
 
 
 def _splits(out_rows, out_cols, K):
@@ -135,7 +134,7 @@ def _lin_params(seq, views_prefix, views):
 
 
 # ----------------------------------------------------------------------------- concurrent head chains
-MULTI_STREAM = os.environ.get("CLIFT_STREAMS", "1") != "0"
+MULTI_STREAM = os.environ.get("CLIFT_STREAMS", "0") == "1"   # opt-in: +4 % step throughput, but kernels then overlap in profiles
 _side_streams = {}
 
 
@@ -436,7 +435,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
-            gemm(nc, nf, M, ctx.F, nc, dfeat, ldf, gWb, _pitch(gWb), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(nc, nf, M), c_trans=1)
+            call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, stream())
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
             gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             va = vm_struct(views, "appearance", ctx.res)

@@ -157,6 +157,11 @@ int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         clift_stream_t s);
+/* Narrow weight gradient (out_features no <= 32: the last layer of every head, tensoRF.py:395,480,581, and the basis
+ * Linear :65 seen from its narrow side): gW (no, ni; pitch ldw) += dY^T X over M samples, gb (no; nullable) += colsum(dY).
+ * A streaming VALU reduction at HBM rate instead of a mostly-padding matrix-core tile. */
+int clift_wgrad_narrow(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw,
+                       float* gb, clift_stream_t s);
 /* db (N) += colsum(dY (M,N)). */
 int clift_colsum(const float* dY, int ld, int M, int N, float* db, clift_stream_t s);
 
