@@ -393,6 +393,52 @@ def g10_grid_ops():
     npz("g10_grid_ops", **out)
 
 
+def g11_metrics():
+    """psnr / ConfusionMatrix mIoU / panoptic_quality on hand-made and random label maps."""
+    from util.metrics import psnr, ConfusionMatrix
+    from util.panoptic_quality import panoptic_quality
+    rng = np.random.default_rng(111)
+    out = {}
+    a = torch.from_numpy(rng.uniform(0, 1, (50, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.uniform(0, 1, (50, 3)).astype(np.float32))
+    out["psnr_a"], out["psnr_b"], out["psnr"] = a, b, psnr(a, b)
+    gt = rng.integers(0, 6, 4000)
+    pr = np.where(rng.uniform(size=4000) < 0.7, gt, rng.integers(0, 6, 4000))
+    pr[gt == 5] = 5
+    cm = ConfusionMatrix(6, ignore_class=[0])
+    out["cm_gt"], out["cm_pred"] = gt, pr
+    out["cm_batch_miou"] = cm.add_batch(pr, gt, return_miou=True)      # reference call order: (pred, gt) at T:207
+    out["cm_miou"] = cm.get_miou()
+    cases = []
+    H = W = 40
+    for k in range(6):
+        yy, xx = np.mgrid[0:H, 0:W]
+        tgt_cat = np.zeros((H, W), np.int64)
+        tgt_inst = np.zeros((H, W), np.int64)
+        n_obj = 3 + k
+        for o in range(n_obj):
+            cy, cx, r = rng.integers(5, 35), rng.integers(5, 35), rng.integers(3, 9)
+            m = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+            tgt_cat[m] = 1 + (o % 2)            # two thing classes
+            tgt_inst[m] = o + 1
+        tgt_cat[(tgt_cat == 0) & (yy > 28)] = 3   # a stuff class; 0 = another stuff/background
+        prd_cat, prd_inst = tgt_cat.copy(), tgt_inst.copy()
+        flip = rng.uniform(size=(H, W)) < 0.15 * (k + 1) / 3
+        prd_cat[flip] = rng.integers(0, 5, flip.sum())     # includes an unknown category (4)
+        prd_inst[flip] = rng.integers(0, n_obj + 2, flip.sum())
+        if k == 4:
+            prd_inst = (prd_inst * 7 + 3) % 11             # relabelled instances
+        if k == 5:
+            prd_cat[:] = 0; prd_inst[:] = 0                # nothing predicted
+        preds = torch.from_numpy(np.stack([prd_cat, prd_inst], -1).reshape(-1, 2))
+        target = torch.from_numpy(np.stack([tgt_cat, tgt_inst], -1).reshape(-1, 2))
+        pq, sq, rq = panoptic_quality(preds.clone(), target.clone(), {1, 2}, {0, 3}, allow_unknown_preds_category=True)
+        out[f"pq{k}.preds"], out[f"pq{k}.target"] = preds, target
+        out[f"pq{k}.out"] = torch.stack([torch.as_tensor(pq, dtype=torch.float64), torch.as_tensor(sq, dtype=torch.float64),
+                                         torch.as_tensor(rq, dtype=torch.float64)])
+    npz("g11_metrics", **out)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}: golden vectors can only be regenerated in the build container")
@@ -407,6 +453,7 @@ def main():
     g8_losses()
     g9_tv()
     g10_grid_ops()
+    g11_metrics()
 
 
 if __name__ == "__main__":

@@ -174,3 +174,20 @@ def test_g9_tv():
     rel_close(Lt, g["total_tv"], TIGHT, what="total tv")
     Lt.backward()
     _digest_check(g, "tv.g", {k: v.grad for k, v in P.items() if v.grad is not None})
+
+
+def test_g11_metrics_vs_reference():
+    """psnr, robust mIoU and panoptic quality of the product's host-side metrics against the reference's own functions."""
+    from contrastive_lift_amd.inference import psnr, ConfusionMatrix
+    from contrastive_lift_amd.metrics import panoptic_quality
+    g = load_golden("g11_metrics")
+    rel_close(psnr(T(g["psnr_a"]), T(g["psnr_b"])), g["psnr"], 1e-6, what="psnr")
+    cm = ConfusionMatrix(6, ignore_class=[0])
+    rel_close(cm.add_batch(g["cm_pred"], g["cm_gt"], return_miou=True), g["cm_batch_miou"], 1e-9, what="batch miou")
+    rel_close(cm.get_miou(), g["cm_miou"], 1e-9, what="miou")
+    for k in range(6):
+        pq, sq, rq = panoptic_quality(T(g[f"pq{k}.preds"]), T(g[f"pq{k}.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=True)
+        # the reference divides integer tensors, i.e. each IoU is rounded to fp32 before the fp64 sum -> 1e-6
+        rel_close(torch.stack([pq, sq, rq]), g[f"pq{k}.out"], 1e-6, atol=1e-9, what=f"pq case {k}")
+    with pytest.raises(ValueError):
+        panoptic_quality(T(g["pq0.preds"]), T(g["pq0.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=False)
