@@ -77,3 +77,8 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
     print("held-out PSNR", ps, "semantic accuracy", acc)
     assert np.mean(ps) > 18.0 and max(ps) > 21.0, ps
     assert np.mean(acc) > 0.85, acc
+    # scene-level evaluation of the written folders (inference/evaluate.py): mIoU and PQ_scene are finite and sane
+    ev = _load(os.path.join(REPO, "inference", "evaluate.py"), "clift_eval_cli")
+    iou, pq, sq, rq = ev.evaluate_mos(str(out), scene_dir, (64, 64))
+    print("scene mIoU", iou, "PQ_scene", pq, "SQ", sq, "RQ", rq)
+    assert 0.5 < iou <= 1.0 and 0.0 <= pq <= 1.0 and 0.0 <= sq <= 1.0 and 0.0 <= rq <= 1.0
