@@ -171,6 +171,8 @@ def roofline(tr, batch, lean, engine):
     ach = tf(dom_f, dom_ms)
     return {"bound": "mfma", "kernel": "k_gemm<128,256,2,4,false,false> (fp32 v_mfma_f32_32x32x2_f32; 256x256 forward MLP layers)",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "traffic_note": "not collected live (needs rocprofv3 --pmc passes); profiles/r01_gemm_pmc_notes.txt: FETCH_SIZE x2 + WRITE_SIZE = "
+                            "541 MB per M=265k launch vs 543 MB algorithmic (A read + C written, weights L2-resident)",
             "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
             "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec),
                          "ms_per_step": tot_ms, "gflop_per_step": tot_f / 1e9,
