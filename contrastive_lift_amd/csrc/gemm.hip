@@ -8,9 +8,10 @@
 // are staged global -> registers -> LDS in k-major order ([k][m], so a fragment read is 32 consecutive
 // floats per half-wave: conflict-free ds_read_b32) with the next k-tile's global loads in flight under the
 // MFMAs of the current one; interior tiles load without any bounds checks (rows clamped, never stored).
-// Measured (profiles/, tools/ksweep.py): the k-loop itself sustains ~128 TFLOP/s (4096^3); at the K = 256 of the
-// MLP layers ~40 % of a launch is K-independent -- the 268 MB output store burst (~65 us, not overlapped: vmcnt is
-// in-order) and block start-up -- which is what fusing consecutive layers will remove (next round).
+// Measured (profiles/r01_gemm_pmc_notes.txt): the k-loop sustains ~128 TFLOP/s (4096^3); at the K = 256 of the MLP
+// layers a large K-independent share remained, traced to the EPILOGUE being store-issue-bound: 64 four-byte stores per
+// lane.  The forward/dgrad kernels therefore issue the MFMAs with swapped operands (SWAP) so that every lane owns four
+// consecutive output columns and stores / mask-loads 16 bytes at a time (+10..20 % per launch).
 //
 // Used for (reference tensoRF.py): basis Linear :65, appearance MLP :393-397, instance MLPs :475-491,
 // semantic MLP :576-582 -- forward (A = activations, B = weight (out,in)), dgrad (B transposed), wgrad
@@ -124,7 +125,7 @@ struct Stager {
     }
 };
 
-template <int BM, int BN, int WM, int WN, bool AT, bool BT>
+template <int BM, int BN, int WM, int WN, bool AT, bool BT, bool SWAP>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(GemmP g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -181,38 +182,91 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
 #pragma unroll
             for (int x = 0; x < TM; ++x)
 #pragma unroll
-                for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < TN; ++y)
+                    acc[x][y] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[y], a[x], acc[x][y], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // Epilogue.  The MFMAs were issued with swapped operands (weight fragment first), so the accumulator tile is C^T in
+    // the standard C/D layout: lane l owns output ROW m = tile_m + (l & 31) and, per group q = reg >> 2, the four CONSECUTIVE
+    // columns n = tile_n + 8q + 4(l >> 5) + (reg & 3).  That lets every lane move 16 bytes per store / mask load: a
+    // 4-byte-per-lane epilogue is store-ISSUE-bound on this chip (~7 B/clk/CU, MI355X_MICROARCH.md), measured here as
+    // ~16 us of a 97 us block period.
+    // Accumulating launches (split-K wgrad) keep the un-swapped order instead (SWAP = false): there the 32 lanes of a
+    // half-wave own 32 consecutive columns of one row, which is what keeps the fp32 atomics line-coalesced.
+    if (!SWAP) {
 #pragma unroll
-    for (int x = 0; x < TM; ++x)
+        for (int x = 0; x < TM; ++x)
 #pragma unroll
-        for (int y = 0; y < TN; ++y) {
-            const int n = n0 + wn * (BN / WN) + y * 32 + li;
-            if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
+            for (int y = 0; y < TN; ++y) {
+                const int n = n0 + wn * (BN / WN) + y * 32 + li;
+                if (n >= g.N) continue;
+                const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / WM) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= g.M) continue;
-                float v = acc[x][y][r] + bv;
-                if (g.act == 1) v = fmaxf(v, 0.f);
-                if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
-                float* c = g.c_trans ? g.C + (size_t)n * g.ldc + m : g.C + (size_t)m * g.ldc + n;
-                if (g.accumulate) unsafeAtomicAdd(c, v);
-                else *c = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / WM) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= g.M) continue;
+                    float v = acc[x][y][r] + bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
+                    float* c = g.c_trans ? g.C + (size_t)n * g.ldc + m : g.C + (size_t)m * g.ldc + n;
+                    if (g.accumulate) unsafeAtomicAdd(c, v);
+                    else *c = v;
+                }
             }
-        }
+        if (AT && do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
+        return;
+    }
+    const bool vec_ok = !g.accumulate && !g.c_trans && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) &&
+                        (!g.mask || ((g.ldmask % 4 == 0) && (((uintptr_t)g.mask & 15) == 0)));
+#pragma unroll
+    for (int x = 0; x < TM; ++x) {
+        const int m = m0 + wm * (BM / WM) + x * 32 + li;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * (BN / WN) + y * 32 + 8 * q + 4 * lh;
+                if (n >= g.N) continue;
+                float v[4] = {acc[x][y][4 * q + 0], acc[x][y][4 * q + 1], acc[x][y][4 * q + 2], acc[x][y][4 * q + 3]};
+                if (vec_ok && n + 3 < g.N) {
+                    if (g.bias) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                    if (g.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (g.mask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)m * g.ldmask + n);
+                        if (!(mk.x > 0.f)) v[0] = 0.f; if (!(mk.y > 0.f)) v[1] = 0.f; if (!(mk.z > 0.f)) v[2] = 0.f; if (!(mk.w > 0.f)) v[3] = 0.f;
+                    }
+                    *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ne = n + e;
+                        if (ne >= g.N) continue;
+                        float val = v[e] + (g.bias ? g.bias[ne] : 0.f);
+                        if (g.act == 1) val = fmaxf(val, 0.f);
+                        if (g.mask && !(g.mask[(size_t)m * g.ldmask + ne] > 0.f)) val = 0.f;
+                        float* c = g.c_trans ? g.C + (size_t)ne * g.ldc + m : g.C + (size_t)m * g.ldc + ne;
+                        if (g.accumulate) unsafeAtomicAdd(c, val);
+                        else *c = val;
+                    }
+                }
+            }
+    }
     if (AT && do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
 static int launch_one(const GemmP& p, int splits, hipStream_t st) {
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
-    k_gemm<BM, BN, WM, WN, AT, BT><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
+    // swapped-operand (16-byte store) form only where every row can take aligned float4 stores; accumulating, transposed
+    // and odd-pitch (narrow head outputs) launches keep lanes along the output row
+    const bool vec = !p.accumulate && !p.c_trans && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && p.N >= 32 &&
+                     (!p.mask || ((p.ldmask % 4 == 0) && (((uintptr_t)p.mask & 15) == 0)));
+    if (!vec) k_gemm<BM, BN, WM, WN, AT, BT, false><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
+    else k_gemm<BM, BN, WM, WN, AT, BT, true><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
     return clift_check_launch("clift_gemm");
 }
 
