@@ -1,0 +1,104 @@
+"""GPU: equivalence of the trainer's execution modes.
+  * chunked main pass (reference chunk = 2048, T:108) == whole-batch main pass;
+  * ``lean`` main pass (instance heads skipped: their output is discarded by the reference, T:155) == full main pass;
+  * data parallel: two ranks (gloo, sharing the one GPU of the test box) each rendering half of the rays reproduce the
+    single-process full-batch gradients and parameter update (mean-of-means == full mean for equal shards)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import grad_close, rel_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(seed=5, B=1024, Bi=256, chunk=0):
+    import contrastive_lift_amd as cl
+    from contrastive_lift_amd import synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    model, renderer, pool = synthetic.make_scene(grid=48, num_classes=6, max_instances=3, seed=seed, device=DEV, image=96, n_cams=2)
+    cfg = default_config(chunk=chunk, instance_optimization_epoch=0, late_semantic_optimization=0)
+    tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
+    batch = synthetic.make_batches(pool, B, Bi, 6, 9, seed=77, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    jit = torch.rand(B, generator=g).to(DEV)
+    return tr, batch, jit
+
+
+def _grads(tr):
+    return {k: v.detach().clone() for k, v in tr.model.named_grad_views().items()}
+
+
+def test_chunked_and_lean_main_pass_match_whole_batch():
+    tr, batch, jit = _setup(chunk=0)
+    tr.main_pass(batch[0], jitter=jit, white_bg=False)
+    g_whole, l_whole = _grads(tr), tr.losses.clone()
+    tr2, batch2, _ = _setup(chunk=256)          # 4 renderer calls
+    tr2.main_pass(batch2[0], jitter=jit, white_bg=False)
+    g_chunk, l_chunk = _grads(tr2), tr2.losses.clone()
+    tr3, batch3, _ = _setup(chunk=0)
+    tr3.main_pass(batch3[0], jitter=jit, white_bg=False, lean=True)
+    g_lean = _grads(tr3)
+    rel_close(l_chunk[:3], l_whole[:3], 1e-4, what="losses chunked vs whole")
+    for k in g_whole:
+        if k.startswith("render_instance_mlp"):
+            assert float(g_whole[k].abs().max()) == 0.0 and float(g_lean[k].abs().max()) == 0.0     # main pass never trains them
+            continue
+        grad_close(g_chunk[k], g_whole[k], what=f"chunked {k}")
+        grad_close(g_lean[k], g_whole[k], what=f"lean {k}", rtol=1e-4, scale_atol=1e-5)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr, batch, jit = _setup(chunk=0)
+        assert tr.world == world
+        B = batch[0]["rays"].shape[0]
+        h = B // world
+        sl = slice(rank * h, (rank + 1) * h)
+        shard = {k: v[sl].contiguous() for k, v in batch[0].items()}
+        tr.main_pass(shard, jitter=jit[sl].contiguous(), white_bg=False)
+        # numpy (pickled by value): torch tensors would be passed through shared-memory files that vanish with the worker
+        q.put((rank, {k: v.detach().cpu().contiguous().numpy() for k, v in tr.model.named_grad_views().items() if not k.startswith("render_instance")},
+               tr.model.param_flat.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_match_single_process():
+    import torch.multiprocessing as mp
+    tr, batch, jit = _setup(chunk=0)
+    tr.main_pass(batch[0], jitter=jit, white_bg=False)
+    g_ref = {k: v.detach().cpu() for k, v in tr.model.named_grad_views().items()}
+    p_ref = tr.model.param_flat.detach().cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [(r, {k: torch.from_numpy(v) for k, v in g.items()}, torch.from_numpy(p)) for r, g, p in res]
+    for rank, grads, params in res:
+        for k, g in grads.items():
+            grad_close(g, g_ref[k].contiguous(), what=f"rank {rank} all-reduced grad {k}")
+        a, b = tr.main_range
+        # Adam normalises: compare the update in units of lr (grids 1e-2, nets 5e-4)
+        diff = (params[a:b] - p_ref[a:b]).abs()
+        g0, g1 = tr.model.arena.range_of("grid_density", "grid_app")
+        assert float(diff[g0:g1].max()) <= 0.1 * 1e-2 and float(diff[g1:b].max()) <= 0.1 * 5e-4, (float(diff[g0:g1].max()), float(diff[g1:b].max()))
+    assert torch.equal(res[0][2], res[1][2])          # both ranks hold bit-identical parameters after the step
