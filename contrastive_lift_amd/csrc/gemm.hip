@@ -36,8 +36,16 @@ struct GemmP {
 
 constexpr int BK = 32;
 
-template <bool TR>
-__host__ __device__ constexpr int lds_stride(int cols) { return TR ? cols + 4 : cols + 1; }
+// LDS image of one operand tile (ROWS = BM or BN, BK = 32 deep):
+//   trans operand (memory [k][row]):  [k][ROWS + 4]   -- 16-byte stores along the row index, fragment = 4 scalar reads
+//   plain operand (memory [row][k]):  [row][BK + 4]   -- 16-byte stores AND 16-byte fragment reads (pitch 36 floats: the
+//                                                        16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots)
+// Both serve the same k-interleaved MFMA order: within a group of 8 consecutive k, step s (0..3) multiplies k = s on
+// lanes 0-31 and k = 4 + s on lanes 32-63, so a lane's four fragment values are 4 consecutive k of its row.
+// The forward kernel (both operands plain) keeps a third, scalar image -- [k][ROWS + 1], transposing 4-byte stores and
+// 4-byte fragment reads in natural k order -- because the 16-byte-fragment form pushes it past 128 VGPRs (spills).
+template <bool TR, bool LEGACY>
+__host__ __device__ constexpr int lds_floats(int rows) { return LEGACY ? BK * (rows + 1) : TR ? BK * (rows + 4) : rows * (BK + 4); }
 
 // Stage one operand tile (ROWS = BM or BN along m, BK along k) from global into registers.
 //   non-trans: element (m,k) at P[m*ld + k]  -> float4 along k
@@ -105,23 +113,38 @@ struct Stager {
             v[p] = x;
         }
     }
-    // LDS image: [k][m] with row stride lds_stride<TR>(ROWS)
-    __device__ __forceinline__ void store(float* __restrict__ L, int tid) const {
-        constexpr int LS = lds_stride<TR>(ROWS);
+    __device__ __forceinline__ void store_legacy(float* __restrict__ L, int tid) const {   // plain operand -> [k][ROWS+1]
+        constexpr int LS = ROWS + 1;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int e = tid + p * NT;
-            if (e < ROWS * BK / 4) {
+            if ((ROWS * BK / 4) % NT == 0 || e < ROWS * BK / 4) {
+                const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
+                L[(k + 0) * LS + m] = v[p].x; L[(k + 1) * LS + m] = v[p].y;
+                L[(k + 2) * LS + m] = v[p].z; L[(k + 3) * LS + m] = v[p].w;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ L, int tid) const {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int e = tid + p * NT;
+            if ((ROWS * BK / 4) % NT == 0 || e < ROWS * BK / 4) {
                 if (!TR) {
                     const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
-                    L[(k + 0) * LS + m] = v[p].x; L[(k + 1) * LS + m] = v[p].y;
-                    L[(k + 2) * LS + m] = v[p].z; L[(k + 3) * LS + m] = v[p].w;
+                    *reinterpret_cast<float4*>(L + m * (BK + 4) + k) = v[p];
                 } else {
                     const int k = e / (ROWS / 4), m = (e % (ROWS / 4)) * 4;
-                    *reinterpret_cast<float4*>(L + k * LS + m) = v[p];
+                    *reinterpret_cast<float4*>(L + k * (ROWS + 4) + m) = v[p];
                 }
             }
         }
+    }
+    // fragment of row `row` for the 8-k group starting at kk8, lane half h: values for MFMA steps s = 0..3
+    static __device__ __forceinline__ float4 frag(const float* __restrict__ L, int row, int kk8, int h) {
+        if (!TR) return *reinterpret_cast<const float4*>(L + row * (BK + 4) + kk8 + 4 * h);
+        const float* q = L + (kk8 + 4 * h) * (ROWS + 4) + row;
+        return make_float4(q[0], q[ROWS + 4], q[2 * (ROWS + 4)], q[3 * (ROWS + 4)]);
     }
 };
 
@@ -129,10 +152,11 @@ template <int BM, int BN, int WM, int WN, bool AT, bool BT, bool SWAP>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(GemmP g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int LSA = lds_stride<AT>(BM), LSB = lds_stride<BT>(BN);
-    __shared__ __attribute__((aligned(16))) float lds[BK * LSA + BK * LSB];
+    constexpr int LSA = BM + 4;      // k-row pitch of a transposed A image (column sums read it)
+    constexpr bool LEGACY = !AT && !BT;
+    __shared__ __attribute__((aligned(16))) float lds[lds_floats<AT, LEGACY>(BM) + lds_floats<BT, LEGACY>(BN)];
     float* As = lds;
-    float* Bs = lds + BK * LSA;
+    float* Bs = lds + lds_floats<AT, LEGACY>(BM);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -159,8 +183,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
     sa.load_any(g.A, g.lda, m0, g.M, kbeg, kend, tid);
     sb.load_any(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        sa.store(As, tid);
-        sb.store(Bs, tid);
+        if (LEGACY) { sa.store_legacy(As, tid); sb.store_legacy(Bs, tid); }
+        else { sa.store(As, tid); sb.store(Bs, tid); }
         __syncthreads();
         if (AT && do_colsum && tid < BM) {
 #pragma unroll 8
@@ -170,21 +194,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
             sa.load_any(g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
             sb.load_any(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
         }
-        const float* ap = As + lh * LSA + wm * (BM / WM) + li;
-        const float* bp = Bs + lh * LSB + wn * (BN / WN) + li;
+        const int arow = wm * (BM / WM) + li, brow = wn * (BN / WN) + li;
+        if (LEGACY) {
+            const float* ap = As + lh * (BM + 1) + arow;
+            const float* bp = Bs + lh * (BN + 1) + brow;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = ap[kk * LSA + t * 32];
+                for (int t = 0; t < TM; ++t) a[t] = ap[kk * (BM + 1) + t * 32];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = bp[kk * LSB + t * 32];
+                for (int t = 0; t < TN; ++t) b[t] = bp[kk * (BN + 1) + t * 32];
 #pragma unroll
-            for (int x = 0; x < TM; ++x)
+                for (int x = 0; x < TM; ++x)
 #pragma unroll
-                for (int y = 0; y < TN; ++y)
-                    acc[x][y] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[y], a[x], acc[x][y], 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+                    for (int y = 0; y < TN; ++y)
+                        acc[x][y] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[y], a[x], acc[x][y], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+        } else
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 8) {
+            float4 a[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = Stager<BM, NT, AT>::frag(As, arow + t * 32, kk, lh);
+#pragma unroll
+            for (int y = 0; y < TN; ++y) {           // one B fragment live at a time (register pressure)
+                const float4 b = Stager<BN, NT, BT>::frag(Bs, brow + y * 32, kk, lh);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) {
+                        const float av = sidx == 0 ? a[x].x : sidx == 1 ? a[x].y : sidx == 2 ? a[x].z : a[x].w;
+                        const float bv = sidx == 0 ? b.x : sidx == 1 ? b.y : sidx == 2 ? b.z : b.w;
+                        acc[x][y] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[x][y], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
     }
