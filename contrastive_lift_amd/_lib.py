@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -39,7 +39,8 @@ class Gemm(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int),
                 ("bias", C.c_void_p), ("act", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int),
-                ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p)]
+                ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p),
+                ("precision", C.c_int)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long

@@ -16,23 +16,7 @@
 // Used for (reference tensoRF.py): basis Linear :65, appearance MLP :393-397, instance MLPs :475-491,
 // semantic MLP :576-582 -- forward (A = activations, B = weight (out,in)), dgrad (B transposed), wgrad
 // (both transposed, reduction over the sample dimension split over blockIdx.z with atomic accumulation).
-#include "clift_dev.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmP {
-    int M, N, K;
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc;
-    const float* bias;
-    int act;
-    const float* mask; int ldmask;
-    int accumulate;
-    int k_per_split;
-    int c_trans;      // write C[n*ldc + m] instead of C[m*ldc + n]
-    float* colsum;    // nullable: colsum[m] += sum_k A(m,k)   (bias gradient fused into the wgrad, a_trans only)
-};
+#include "gemm_common.h"
 
 constexpr int BK = 32;
 
@@ -235,82 +219,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
         __syncthreads();
     }
 
-    // Epilogue.  The MFMAs were issued with swapped operands (weight fragment first), so the accumulator tile is C^T in
-    // the standard C/D layout: lane l owns output ROW m = tile_m + (l & 31) and, per group q = reg >> 2, the four CONSECUTIVE
-    // columns n = tile_n + 8q + 4(l >> 5) + (reg & 3).  That lets every lane move 16 bytes per store / mask load: a
-    // 4-byte-per-lane epilogue is store-ISSUE-bound on this chip (~7 B/clk/CU, MI355X_MICROARCH.md), measured here as
-    // ~16 us of a 97 us block period.
-    // Accumulating launches (split-K wgrad) keep the un-swapped order instead (SWAP = false): there the 32 lanes of a
-    // half-wave own 32 consecutive columns of one row, which is what keeps the fp32 atomics line-coalesced.
-    if (!SWAP) {
-#pragma unroll
-        for (int x = 0; x < TM; ++x)
-#pragma unroll
-            for (int y = 0; y < TN; ++y) {
-                const int n = n0 + wn * (BN / WN) + y * 32 + li;
-                if (n >= g.N) continue;
-                const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (BM / WM) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= g.M) continue;
-                    float v = acc[x][y][r] + bv;
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
-                    float* c = g.c_trans ? g.C + (size_t)n * g.ldc + m : g.C + (size_t)m * g.ldc + n;
-                    if (g.accumulate) unsafeAtomicAdd(c, v);
-                    else *c = v;
-                }
-            }
-        if (AT && do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
-        return;
-    }
-    const bool vec_ok = !g.accumulate && !g.c_trans && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) &&
-                        (!g.mask || ((g.ldmask % 4 == 0) && (((uintptr_t)g.mask & 15) == 0)));
-#pragma unroll
-    for (int x = 0; x < TM; ++x) {
-        const int m = m0 + wm * (BM / WM) + x * 32 + li;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int y = 0; y < TN; ++y)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * (BN / WN) + y * 32 + 8 * q + 4 * lh;
-                if (n >= g.N) continue;
-                float v[4] = {acc[x][y][4 * q + 0], acc[x][y][4 * q + 1], acc[x][y][4 * q + 2], acc[x][y][4 * q + 3]};
-                if (vec_ok && n + 3 < g.N) {
-                    if (g.bias) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                    if (g.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    if (g.mask) {
-                        const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)m * g.ldmask + n);
-                        if (!(mk.x > 0.f)) v[0] = 0.f; if (!(mk.y > 0.f)) v[1] = 0.f; if (!(mk.z > 0.f)) v[2] = 0.f; if (!(mk.w > 0.f)) v[3] = 0.f;
-                    }
-                    *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ne = n + e;
-                        if (ne >= g.N) continue;
-                        float val = v[e] + (g.bias ? g.bias[ne] : 0.f);
-                        if (g.act == 1) val = fmaxf(val, 0.f);
-                        if (g.mask && !(g.mask[(size_t)m * g.ldmask + ne] > 0.f)) val = 0.f;
-                        float* c = g.c_trans ? g.C + (size_t)ne * g.ldc + m : g.C + (size_t)m * g.ldc + ne;
-                        if (g.accumulate) unsafeAtomicAdd(c, val);
-                        else *c = val;
-                    }
-                }
-            }
-    }
-    if (AT && do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
+    gemm_epilogue<BM, BN, WM, WN, SWAP>(g, acc, m0, n0, wm, wn, li, lh, tid, do_colsum, csum);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
 static int launch_one(const GemmP& p, int splits, hipStream_t st) {
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
-    // swapped-operand (16-byte store) form only where every row can take aligned float4 stores; accumulating, transposed
-    // and odd-pitch (narrow head outputs) launches keep lanes along the output row
-    const bool vec = !p.accumulate && !p.c_trans && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && p.N >= 32 &&
-                     (!p.mask || ((p.ldmask % 4 == 0) && (((uintptr_t)p.mask & 15) == 0)));
+    const bool vec = gemm_vector_epilogue_ok(p);
     if (!vec) k_gemm<BM, BN, WM, WN, AT, BT, false><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
     else k_gemm<BM, BN, WM, WN, AT, BT, true><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
     return clift_check_launch("clift_gemm");
@@ -344,6 +259,8 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (splits < 1) splits = 1;
     p.k_per_split = kper;
     hipStream_t st = as_stream(s);
+    CLIFT_REQUIRE(h->precision == 0 || h->precision == 1, "clift_gemm: precision must be 0 (fp32) or 1 (bf16 operands), got %d", h->precision);
+    if (h->precision == 1) return clift_gemm_bf16_launch(p, h->a_trans, h->b_trans, splits, st);
     if (h->N > 128) {
         return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
     }

@@ -90,6 +90,19 @@ def _pitch(t):
     return t.stride(0) if t.dim() == 2 else 1
 
 
+# MLP operand precision of every matrix-core launch: 0 = fp32 (default, exact fp32 products), 1 = "bf16 mode" (operands
+# rounded to bf16 in the kernel, fp32 accumulate, fp32 tensors in memory) -- BASELINE config 3 / SURVEY 7.9.
+MLP_PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
+
+
+def set_mlp_precision(name):
+    """'fp32' or 'bf16'; returns the previous setting's name."""
+    global MLP_PRECISION
+    prev = "bf16" if MLP_PRECISION else "fp32"
+    MLP_PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}[str(name).lower()]
+    return prev
+
+
 def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=0, mask=None, ldmask=0,
          accumulate=0, split_k=1, a_off=0, c_off=0, c_trans=0, colsum=None):
     g = Gemm()
@@ -104,6 +117,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.accumulate, g.split_k = int(accumulate), int(split_k)
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
+    g.precision = MLP_PRECISION
     call("clift_gemm", C.byref(g), stream())
 
 

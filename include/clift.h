@@ -133,7 +133,10 @@ int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const 
 /* ---- nn.Linear building block on the matrix cores (tensoRF.py:65,393-397,475-491,576-582 and their
  * backward).  C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] ) * (mask[m][n] > 0)
  *   A(m,k) = a_trans ? A[k*lda+m] : A[m*lda+k];   B(n,k) = b_trans ? B[k*ldb+n] : B[n*ldb+k].
- * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32).  K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
+ * precision 0: fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32, exact fp32 products).
+ * precision 1: "bf16 mode" -- A and B are rounded to bf16 (RNE) on their way into LDS, products on
+ *   v_mfma_f32_32x32x16_bf16 with fp32 accumulation; all tensors stay fp32 in memory (BASELINE config 3).
+ * K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
  * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C). */
 typedef struct {
     int M, N, K;
@@ -147,6 +150,7 @@ typedef struct {
     int split_k;
     int c_trans;                    /* write C[n*ldc + m] (lets a narrow-M wgrad run as a narrow-N problem) */
     float* colsum;                  /* nullable; a_trans only: colsum[m] += sum_k A(m,k)  (bias gradient) */
+    int precision;                  /* 0 fp32 operands, 1 bf16 operands (fp32 accumulate) */
 } clift_gemm_t;
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 

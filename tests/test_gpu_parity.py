@@ -81,6 +81,52 @@ def test_gemm_matches_fp64(at, bt, M, N, K):
     rel_close(out3, ref - bias.double() + 1.0, 2e-5, atol=4e-5 * float(ref.abs().max()), what="gemm split-k accumulate")
 
 
+@pytest.mark.parametrize("at,bt", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 128, 152), (517, 27, 144), (257, 3, 128), (129, 150, 36), (64, 22, 7),
+                                   (128 * 3, 256, 64)])
+def test_gemm_bf16_mode_matches_rounded_operands(at, bt, M, N, K):
+    """bf16 mode (clift_gemm precision = 1): operands rounded to bf16 (RNE) in the kernel, exact products, fp32 accumulate.
+    So the result must equal the fp64 product of the bf16-ROUNDED operands to fp32 summation accuracy (2e-5), and the plain
+    fp32 product only to bf16 accuracy."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + at * 2 + bt + 1000)
+    Kp, Mp, Np = (K + 3) // 4 * 4, (M + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = torch.randn((K, Mp) if at else (M, Kp), generator=g)
+    B = torch.randn((K, Np) if bt else (N, Kp), generator=g)
+    bias = torch.randn(N, generator=g)
+    rnd = lambda t: t.to(torch.bfloat16).double()
+    Aop = A[:, :M].T if at else A[:, :K]
+    Bop = B[:, :N].T if bt else B[:, :K]
+    ref = rnd(Aop) @ rnd(Bop).T + bias.double()
+    mask = torch.randn(M, N, generator=g)
+    Ad, Bd, biasd, maskd = A.to(DEV), B.to(DEV), bias.to(DEV), mask.to(DEV).contiguous()
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        out = torch.full((M, N + 1), -7.0, device=DEV)
+        engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out, N + 1, a_trans=at, b_trans=bt, bias=biasd)
+        out2 = torch.zeros((M, N), device=DEV)
+        engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out2, N, a_trans=at, b_trans=bt, bias=biasd, act=1, mask=maskd, ldmask=N)
+        out3 = torch.ones((M, N), device=DEV)
+        engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out3, N, a_trans=at, b_trans=bt, accumulate=1, split_k=3)
+        colsum = None
+        if at:
+            colsum = torch.zeros(M, device=DEV)
+            out4 = torch.zeros((M, N), device=DEV)
+            engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], out4, N, a_trans=at, b_trans=bt, accumulate=1, split_k=2, colsum=colsum)
+    finally:
+        engine.set_mlp_precision(prev)
+    scale = float(ref.abs().max())
+    rel_close(out[:, :N], ref, 2e-5, atol=2e-5 * scale, what="bf16 gemm vs rounded operands")
+    assert bool((out[:, N] == -7.0).all())
+    rel_close(out2, torch.relu(ref) * (mask > 0), 2e-5, atol=2e-5 * scale, what="bf16 gemm relu+mask")
+    rel_close(out3, ref - bias.double() + 1.0, 2e-5, atol=4e-5 * scale, what="bf16 gemm split-k")
+    full = Aop.double() @ Bop.double().T + bias.double()
+    assert float((out[:, :N].double().cpu() - full).abs().max()) <= 2e-2 * scale        # bf16-level agreement with fp32 math
+    if colsum is not None:
+        refc = rnd(Aop).sum(1)
+        rel_close(colsum, refc, 1e-4, atol=1e-4 * float(refc.abs().max()) + 1e-5, what="bf16 colsum")
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
