@@ -102,57 +102,97 @@ extern "C" int clift_active_xyz(const clift_march_t* h_m, const float* rays, con
     return clift_check_launch("clift_active_xyz");
 }
 
-// Backward of the appearance gather.  Persistent blocks, ONE CHANNEL PER LANE: every atomic instruction of a wave covers runs
-// of `comps` consecutive floats of one texel, which the memory pipeline folds into cache-line-granular requests (measured 3.8x
-// faster than a float4-per-lane mapping whose lanes are 16 B apart within an instruction).  Line gradients accumulate in LDS
-// and are flushed once per block; plane gradients go to the per-XCD accumulation copies.
+// Backward of the appearance gather.  Persistent blocks, ONE (plane, channel) PER LANE: every atomic instruction of a wave
+// covers runs of `comps` consecutive floats of one texel, which the memory pipeline folds into cache-line-granular requests
+// (measured 3.8x faster than a float4-per-lane mapping whose lanes are 16 B apart within an instruction).
+// Like k_density_bwd (march.hip) a lane WALKS a short run of consecutive active samples -- consecutive samples of one ray
+// in the compacted order -- keeping its plane's four current texels in registers (key, table value, gradient sum); a texel
+// costs one load when the walk enters it and one atomic when the walk leaves it.  Line gradients accumulate in LDS and are
+// flushed once per block; plane gradients go to the per-XCD accumulation copies.
+// Measured at 265 k active samples (profiles/r01_scatter_notes.txt): 1 -> 667 us (no merging; the pre-walk kernel: 624), 2 -> 520,
+// 4 -> 469, 8 -> 461.
+constexpr int APP_SEG = 8;
+
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
-                                                            const float* __restrict__ jitter, const int* __restrict__ act, long total,
-                                                            const float* __restrict__ dF) {
+                                                            const float* __restrict__ jitter, const int* __restrict__ act, int M,
+                                                            const float* __restrict__ dF, int seg_len) {
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = line_lds_floats(t.res, t.comps);
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
     const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
+    const bool xcd = gr.xcd_stride > 0;
     const int C = t.comps, G = 3 * C;
     const long nthreads = (long)gridDim.x * blockDim.x;
+    const long total = (long)((M + seg_len - 1) / seg_len) * G;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += nthreads) {
-        const int s = (int)(gid / G), j = (int)(gid - (long)s * G);
+        const int w = (int)(gid / G), j = (int)(gid - (long)w * G);
         const int i = j / C, c = j - i * C;
-        const int sid = act[s];
-        const int r = sid / m.S, k = sid - r * m.S;
-        const RayG g = load_ray(rays, r, m);
-        float xn[3];
-        sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
-        const VmTaps tp = vm_taps(t, i, xn);
         int a, b, v;
         vm_axes(i, a, b, v);
         const int W = t.res[a];
         const float* pp = t.plane[i] + c;
         const float* lp = t.line[i] + c;
-        const size_t o00 = ((size_t)tp.ty.i0 * W + tp.tx.i0) * C, o10 = ((size_t)tp.ty.i0 * W + tp.tx.i1) * C;
-        const size_t o01 = ((size_t)tp.ty.i1 * W + tp.tx.i0) * C, o11 = ((size_t)tp.ty.i1 * W + tp.tx.i1) * C;
-        const float w00 = tp.tx.w0 * tp.ty.w0, w10 = tp.tx.w1 * tp.ty.w0, w01 = tp.tx.w0 * tp.ty.w1, w11 = tp.tx.w1 * tp.ty.w1;
-        const float P = fmaf(w11, pp[o11], fmaf(w01, pp[o01], fmaf(w10, pp[o10], w00 * pp[o00])));
-        const float L = fmaf(tp.tz.w1, lp[(size_t)tp.tz.i1 * C], tp.tz.w0 * lp[(size_t)tp.tz.i0 * C]);
-        const float d = dF[(size_t)s * G + j];
-        const float gP = d * L, gL = d * P;
         float* gp = gr.plane[i] + xoff + c;
-#define CLIFT_ADD1(ptr, val) do { if (gr.xcd_stride > 0) __hip_atomic_fetch_add(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else unsafeAtomicAdd(ptr, val); } while (0)
-        if (w00 != 0.f) CLIFT_ADD1(gp + o00, w00 * gP);
-        if (w10 != 0.f) CLIFT_ADD1(gp + o10, w10 * gP);
-        if (w01 != 0.f) CLIFT_ADD1(gp + o01, w01 * gP);
-        if (w11 != 0.f) CLIFT_ADD1(gp + o11, w11 * gP);
-        if (LDS_LINES) {
-            float* ll = lds_lines + line_lds_offset(t, i) + c;
-            if (tp.tz.w0 != 0.f) atomicAdd(ll + tp.tz.i0 * C, tp.tz.w0 * gL);
-            if (tp.tz.w1 != 0.f) atomicAdd(ll + tp.tz.i1 * C, tp.tz.w1 * gL);
-        } else {
-            float* gl = gr.line[i] + xoff + c;
-            if (tp.tz.w0 != 0.f) CLIFT_ADD1(gl + (size_t)tp.tz.i0 * C, tp.tz.w0 * gL);
-            if (tp.tz.w1 != 0.f) CLIFT_ADD1(gl + (size_t)tp.tz.i1 * C, tp.tz.w1 * gL);
+        float* ll = lds_lines + line_lds_offset(t, i) + c;
+        float* gl = gr.line[i] + xoff + c;
+        int ck[4] = {-1, -1, -1, -1};      // open texels (y * W + x), -1 = empty
+        float cv[4] = {0.f, 0.f, 0.f, 0.f}, ca[4] = {0.f, 0.f, 0.f, 0.f};
+        const int s0 = w * seg_len, s1 = min(M, s0 + seg_len);
+        for (int s = s0; s < s1; ++s) {
+            const int sid = act[s];
+            const int r = sid / m.S, k = sid - r * m.S;
+            const RayG g = load_ray(rays, r, m);
+            float xn[3];
+            sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+            const Tap2 tx = make_tap(xn[a], t.res[a]), ty = make_tap(xn[b], t.res[b]), tz = make_tap(xn[v], t.res[v]);
+            const float w4[4] = {tx.w0 * ty.w0, tx.w1 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w1};
+            int nk[4] = {ty.i0 * W + tx.i0, ty.i0 * W + tx.i1, ty.i1 * W + tx.i0, ty.i1 * W + tx.i1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (w4[q] == 0.f) nk[q] = -1;        // clamped out-of-range taps: never loaded, never written
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {            // leave
+                const int key = ck[q];
+                if (key >= 0 && key != nk[0] && key != nk[1] && key != nk[2] && key != nk[3]) {
+                    if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C, ca[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else unsafeAtomicAdd(gp + (size_t)key * C, ca[q]);
+                }
+            }
+            float nv[4], na[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {            // enter
+                float val = 0.f, sum = 0.f;
+                bool hit = false;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (nk[q] >= 0 && ck[o] == nk[q]) { val = cv[o]; sum = ca[o]; hit = true; }
+                if (!hit && nk[q] >= 0) val = pp[(size_t)nk[q] * C];
+                nv[q] = val; na[q] = sum;
+            }
+            const float P = fmaf(w4[3], nv[3], fmaf(w4[2], nv[2], fmaf(w4[1], nv[1], w4[0] * nv[0])));
+            const float L = fmaf(tz.w1, lp[(size_t)tz.i1 * C], tz.w0 * lp[(size_t)tz.i0 * C]);
+            const float d = dF[(size_t)s * G + j];
+            const float gP = d * L, gL = d * P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ck[q] = nk[q]; cv[q] = nv[q]; ca[q] = fmaf(w4[q], gP, na[q]); }
+            if (LDS_LINES) {
+                if (tz.w0 != 0.f) atomicAdd(ll + tz.i0 * C, tz.w0 * gL);
+                if (tz.w1 != 0.f) atomicAdd(ll + tz.i1 * C, tz.w1 * gL);
+            } else if (xcd) {
+                if (tz.w0 != 0.f) __hip_atomic_fetch_add(gl + (size_t)tz.i0 * C, tz.w0 * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tz.w1 != 0.f) __hip_atomic_fetch_add(gl + (size_t)tz.i1 * C, tz.w1 * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (tz.w0 != 0.f) unsafeAtomicAdd(gl + (size_t)tz.i0 * C, tz.w0 * gL);
+                if (tz.w1 != 0.f) unsafeAtomicAdd(gl + (size_t)tz.i1 * C, tz.w1 * gL);
+            }
         }
-#undef CLIFT_ADD1
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ck[q] >= 0) {
+                if (xcd) __hip_atomic_fetch_add(gp + (size_t)ck[q] * C, ca[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else unsafeAtomicAdd(gp + (size_t)ck[q] * C, ca[q]);
+            }
     }
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
@@ -162,7 +202,8 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
                                     clift_stream_t s) {
     CLIFT_REQUIRE(h_app->comps % 4 == 0, "clift_app_gather_bwd: comps must be a multiple of 4");
     if (M <= 0) return 0;
-    const long total = (long)M * 3 * h_app->comps;
+    const int seg = APP_SEG;
+    const long total = (long)cdiv(M, seg) * 3 * h_app->comps;
     const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
@@ -171,9 +212,9 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     if (use_lds) {
         if (lds_bytes > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, total, dF);
+        k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg);
     } else {
-        k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, total, dF);
+        k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg);
     }
     return clift_check_launch("clift_app_gather_bwd");
 }

@@ -82,72 +82,132 @@ extern "C" int clift_density_points(const clift_vm_t* h_dens, const float* xn, i
 }
 
 // ============================================================================ density backward
-// Persistent blocks (grid-stride over samples), `comps` lanes per sample with ONE CHANNEL PER LANE (comps = 4..64,
-// power of two; 16 in the reference configs => 4 samples per wave): every atomic instruction covers whole 64-byte
-// texels.  Line gradients accumulate in LDS and are flushed once per block, plane gradients go to the per-XCD
-// accumulation copies (clift_dev.h).
+// Persistent blocks; `comps` lanes form a GROUP with ONE CHANNEL PER LANE (comps = 4..64, power of two; 16 in the
+// reference configs => 4 groups per wave), so every atomic instruction covers whole 64-byte texels.
+// The kernel is bound by the plane atomics (measured: 1.11 ms with, 0.32 ms without them at 1.8 M samples), and
+// consecutive samples of a ray move ~0.3 texel per step in each plane, so a group WALKS a segment of consecutive samples
+// of one ray and keeps, per plane, the current sample's four texels in registers (key, table value, gradient sum).
+// A texel is written to memory (one atomic) only when the walk leaves it, and read only when the walk enters it:
+// ~1.1 instead of 4 atomics and loads per plane per sample.  Line gradients accumulate in LDS and are flushed once per
+// block; plane gradients go to the per-XCD accumulation copies (clift_dev.h).
+// Samples per walk segment.  Measured at 1.8 M samples (profiles/r01_scatter_notes.txt): 32 -> 535 us, 16 -> 430, 8 -> 421,
+// 4 -> 389 (one sample per group, no merging: 1114): longer walks save more atomics but serialise more steps per group
+// and diverge more between the four groups of a wave.
+constexpr int DENS_SEG_DEFAULT = 4;
+
+template <bool LDS_LINES>
+__device__ __forceinline__ void line_add(const VmG& gr, int i, size_t xoff, float* lds_line, int off, float v) {
+    if (LDS_LINES) atomicAdd(lds_line + off, v);
+    else if (gr.xcd_stride > 0) __hip_atomic_fetch_add(gr.line[i] + xoff + off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else unsafeAtomicAdd(gr.line[i] + off, v);
+}
+
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_density_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
-                                                       const float* __restrict__ jitter, long total, int lg_c,
-                                                       const float* __restrict__ dsigma) {
+                                                       const float* __restrict__ jitter, int N, int lg_c,
+                                                       const float* __restrict__ dsigma, int DENS_SEG) {
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = line_lds_floats(t.res, t.comps);
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
     const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
+    const bool xcd = gr.xcd_stride > 0;
     const int C = t.comps;
-    const long nthreads = (long)gridDim.x * blockDim.x;      // multiple of 64 >= C: the C lanes of a sample iterate together
-    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < (total << lg_c); gid += nthreads) {
-        const long s = gid >> lg_c;
-        const int c = (int)(gid & (C - 1));
-        const float ds = dsigma[s];
-        if (ds == 0.f) continue;  // uniform over the lanes of a sample
-        const int r = (int)(s / m.S), k = (int)(s - (long)r * m.S);
+    const int c = threadIdx.x & (C - 1);
+    const long ngroups = ((long)gridDim.x * blockDim.x) >> lg_c;
+    const int nchunk = (m.S + DENS_SEG - 1) / DENS_SEG;
+    const long nseg = (long)N * nchunk;
+    for (long seg = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> lg_c; seg < nseg; seg += ngroups) {
+        const int r = (int)(seg / nchunk);
+        const int k0 = (int)(seg - (long)r * nchunk) * DENS_SEG, k1 = min(m.S, k0 + DENS_SEG);
         const RayG g = load_ray(rays, r, m);
-        float xn[3];
-        if (!sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn)) continue;
-        float P[3], L[3], w4[3][4], wz[3][2];
-        size_t o4[3][4];
-        int oz[3][2];
-        float acc = 0.f;
+        const float jit = jitter ? jitter[r] : 0.f;
+        const float* dsr = dsigma + (size_t)r * m.S;
+        int ck[3][4];            // texel index (y * W + x) of the open entries, -1 = empty
+        float cv[3][4], ca[3][4];  // table value / gradient sum of this lane's channel
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const VmTaps tp = vm_taps(t, i, xn);
-            int a, b, v;
-            vm_axes(i, a, b, v);
-            const int W = t.res[a];
-            o4[i][0] = ((size_t)tp.ty.i0 * W + tp.tx.i0) * C + c; o4[i][1] = ((size_t)tp.ty.i0 * W + tp.tx.i1) * C + c;
-            o4[i][2] = ((size_t)tp.ty.i1 * W + tp.tx.i0) * C + c; o4[i][3] = ((size_t)tp.ty.i1 * W + tp.tx.i1) * C + c;
-            w4[i][0] = tp.tx.w0 * tp.ty.w0; w4[i][1] = tp.tx.w1 * tp.ty.w0; w4[i][2] = tp.tx.w0 * tp.ty.w1; w4[i][3] = tp.tx.w1 * tp.ty.w1;
-            oz[i][0] = tp.tz.i0 * C + c; oz[i][1] = tp.tz.i1 * C + c;
-            wz[i][0] = tp.tz.w0; wz[i][1] = tp.tz.w1;
-            const float* pp = t.plane[i];
-            const float* lp = t.line[i];
-            P[i] = fmaf(w4[i][3], pp[o4[i][3]], fmaf(w4[i][2], pp[o4[i][2]], fmaf(w4[i][1], pp[o4[i][1]], w4[i][0] * pp[o4[i][0]])));
-            L[i] = fmaf(wz[i][1], lp[oz[i][1]], wz[i][0] * lp[oz[i][0]]);
-            acc = fmaf(P[i], L[i], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ck[i][q] = -1; cv[i][q] = 0.f; ca[i][q] = 0.f; }
         }
-        for (int d = 1; d < C; d <<= 1) acc += __shfl_xor(acc, d);
-        const float x = acc + m.shift;
-        const float up = ds * ((x > 20.f) ? 1.f : 1.f / (1.f + expf(-x)));
-        int loff = 0;
+        float ds_next = dsr[k0];
+        for (int k = k0; k < k1; ++k) {
+            const float ds = ds_next;
+            if (k + 1 < k1) ds_next = dsr[k + 1];
+            if (ds == 0.f) continue;     // uniform over the lanes of a group
+            float xn[3];
+            if (!sample_xn(g, m, sample_z(g, m, k, jit), xn)) continue;
+            float P[3], L[3], w4[3][4], wz[3][2];
+            int oz[3][2];
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const VmTaps tp = vm_taps(t, i, xn);
+                int a, b, v;
+                vm_axes(i, a, b, v);
+                const int W = t.res[a];
+                int nk[4];
+                w4[i][0] = tp.tx.w0 * tp.ty.w0; w4[i][1] = tp.tx.w1 * tp.ty.w0; w4[i][2] = tp.tx.w0 * tp.ty.w1; w4[i][3] = tp.tx.w1 * tp.ty.w1;
+                nk[0] = tp.ty.i0 * W + tp.tx.i0; nk[1] = tp.ty.i0 * W + tp.tx.i1; nk[2] = tp.ty.i1 * W + tp.tx.i0; nk[3] = tp.ty.i1 * W + tp.tx.i1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (w4[i][q] == 0.f) nk[q] = -1;       // clamped out-of-range taps: never loaded, never written
+                float* gp = gr.plane[i] + xoff;
+                const float* pp = t.plane[i];
+                // leave: open entries that are not part of this sample
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int key = ck[i][q];
+                    if (key >= 0 && key != nk[0] && key != nk[1] && key != nk[2] && key != nk[3]) {
+                        if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C + c, ca[i][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else unsafeAtomicAdd(gp + (size_t)key * C + c, ca[i][q]);
+                    }
+                }
+                // enter: keep matching entries, load the new ones
+                float nv[4], na[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float val = 0.f, sum = 0.f;
+                    bool hit = false;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        if (nk[q] >= 0 && ck[i][o] == nk[q]) { val = cv[i][o]; sum = ca[i][o]; hit = true; }
+                    if (!hit && nk[q] >= 0) val = pp[(size_t)nk[q] * C + c];
+                    nv[q] = val; na[q] = sum;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ck[i][q] = nk[q]; cv[i][q] = nv[q]; ca[i][q] = na[q]; }
+                oz[i][0] = tp.tz.i0 * C + c; oz[i][1] = tp.tz.i1 * C + c;
+                wz[i][0] = tp.tz.w0; wz[i][1] = tp.tz.w1;
+                const float* lp = t.line[i];
+                P[i] = fmaf(w4[i][3], nv[3], fmaf(w4[i][2], nv[2], fmaf(w4[i][1], nv[1], w4[i][0] * nv[0])));
+                L[i] = fmaf(wz[i][1], lp[oz[i][1]], wz[i][0] * lp[oz[i][0]]);
+                acc = fmaf(P[i], L[i], acc);
+            }
+            for (int d = 1; d < C; d <<= 1) acc += __shfl_xor(acc, d);
+            const float x = acc + m.shift;
+            const float up = ds * ((x > 20.f) ? 1.f : 1.f / (1.f + expf(-x)));
+            int loff = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float gP = up * L[i], gL = up * P[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ca[i][q] = fmaf(w4[i][q], gP, ca[i][q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (wz[i][q] != 0.f) line_add<LDS_LINES>(gr, i, xoff, lds_lines + loff, oz[i][q], wz[i][q] * gL);
+                loff += t.res[2 - i] * C;
+            }
+        }
+        // end of the segment: write out whatever is still open
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float gP = up * L[i], gL = up * P[i];
             float* gp = gr.plane[i] + xoff;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (w4[i][q] != 0.f) {
-                    if (gr.xcd_stride > 0) __hip_atomic_fetch_add(gp + o4[i][q], w4[i][q] * gP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else unsafeAtomicAdd(gp + o4[i][q], w4[i][q] * gP);
+                if (ck[i][q] >= 0) {
+                    if (xcd) __hip_atomic_fetch_add(gp + (size_t)ck[i][q] * C + c, ca[i][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else unsafeAtomicAdd(gp + (size_t)ck[i][q] * C + c, ca[i][q]);
                 }
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (wz[i][q] != 0.f) {
-                    if (LDS_LINES) atomicAdd(lds_lines + loff + oz[i][q], wz[i][q] * gL);
-                    else if (gr.xcd_stride > 0) __hip_atomic_fetch_add(gr.line[i] + xoff + oz[i][q], wz[i][q] * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else unsafeAtomicAdd(gr.line[i] + oz[i][q], wz[i][q] * gL);
-                }
-            loff += t.res[2 - i] * C;
         }
     }
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
@@ -160,18 +220,19 @@ extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_d
     if (N <= 0) return 0;
     int lg = 0;
     while ((1 << lg) < Cc) ++lg;
-    const long total = (long)N * h_m->n_samples;
+    const int DENS_SEG = DENS_SEG_DEFAULT;
+    const long nseg = (long)N * cdiv(h_m->n_samples, DENS_SEG);
     const int lds_bytes = line_lds_floats(h_dens->res, Cc) * 4;
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
-    const int want = cdiv(total << lg, threads);
-    const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
+    const long want = cdiv(nseg << lg, (long)threads);
+    const int blocks = (int)(want < 256 * per_cu ? want : 256 * per_cu);
     if (use_lds) {
         if (lds_bytes > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        k_density_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, lg, dsigma);
+        k_density_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, N, lg, dsigma, DENS_SEG);
     } else {
-        k_density_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, total, lg, dsigma);
+        k_density_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, N, lg, dsigma, DENS_SEG);
     }
     return clift_check_launch("clift_density_bwd");
 }
