@@ -5,9 +5,9 @@
 // v_mfma_f32_32x32x2_f32: per wave a 32x32 tile, lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
 // exact fp32 (bit-identical to an fmaf chain), 64 cycles per instruction per SIMD = 256 FLOP/clk/CU.
 // Block = WM x WN waves, each owning a (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles.  Operand tiles
-// are staged global -> registers -> LDS in k-major order ([k][m], so a fragment read is 32 consecutive
-// floats per half-wave: conflict-free ds_read_b32) with the next k-tile's global loads in flight under the
-// MFMAs of the current one; interior tiles load without any bounds checks (rows clamped, never stored).
+// are staged global -> registers -> LDS (images described at lds_floats below: 16-byte stores for both operand
+// orientations, 16-byte fragment reads for row-major operands) with the next k-tile's global loads in flight under the
+// MFMAs of the current one; full tiles load without bounds checks or clamps.
 // Measured (profiles/r01_gemm_pmc_notes.txt): the k-loop sustains ~128 TFLOP/s (4096^3); at the K = 256 of the MLP
 // layers a large K-independent share remained, traced to the EPILOGUE being store-issue-bound: 64 four-byte stores per
 // lane.  The forward/dgrad kernels therefore issue the MFMAs with swapped operands (SWAP) so that every lane owns four
@@ -26,10 +26,8 @@ constexpr int BK = 32;
 //                                                        16 lanes of a ds_read_b128 group land on 16 distinct 4-bank slots)
 // Both serve the same k-interleaved MFMA order: within a group of 8 consecutive k, step s (0..3) multiplies k = s on
 // lanes 0-31 and k = 4 + s on lanes 32-63, so a lane's four fragment values are 4 consecutive k of its row.
-// The forward kernel (both operands plain) keeps a third, scalar image -- [k][ROWS + 1], transposing 4-byte stores and
-// 4-byte fragment reads in natural k order -- because the 16-byte-fragment form pushes it past 128 VGPRs (spills).
-template <bool TR, bool LEGACY>
-__host__ __device__ constexpr int lds_floats(int rows) { return LEGACY ? BK * (rows + 1) : TR ? BK * (rows + 4) : rows * (BK + 4); }
+template <bool TR>
+__host__ __device__ constexpr int lds_floats(int rows) { return TR ? BK * (rows + 4) : rows * (BK + 4); }
 
 // Stage one operand tile (ROWS = BM or BN along m, BK along k) from global into registers.
 //   non-trans: element (m,k) at P[m*ld + k]  -> float4 along k
@@ -39,11 +37,10 @@ struct Stager {
     static constexpr int NV = (ROWS * BK / 4 + NT - 1) / NT;  // float4 per thread
     float4 v[NV];
 
-    // interior tiles: no bounds checks at all.  non-trans rows beyond mlim are clamped to the last valid row (their
-    // products land in accumulator rows the epilogue never stores); requires k0 + BK <= klim (and, for trans operands,
-    // m0 + ROWS <= mlim) -- see fast_ok().
+    // full tiles (k0 + BK <= klim and m0 + ROWS <= mlim): no bounds checks and no index clamps -- a clamp per load costs
+    // a 64-bit address each and pushed the forward kernel past 128 VGPRs.
     static __device__ __forceinline__ bool fast_ok(int m0, int mlim, int k0, int klim) {
-        return (k0 + BK <= klim) && (!TR || m0 + ROWS <= mlim) && mlim > 0;
+        return (k0 + BK <= klim) && (m0 + ROWS <= mlim);
     }
     __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int m0, int mlim, int k0, int tid) {
 #pragma unroll
@@ -51,7 +48,7 @@ struct Stager {
             const int e = tid + p * NT;
             if ((ROWS * BK / 4) % NT == 0 || e < ROWS * BK / 4) {
                 if (!TR) {
-                    const int m = min(m0 + e / (BK / 4), mlim - 1), k = k0 + (e % (BK / 4)) * 4;
+                    const int m = m0 + e / (BK / 4), k = k0 + (e % (BK / 4)) * 4;
                     v[p] = *reinterpret_cast<const float4*>(P + (size_t)m * ld + k);
                 } else {
                     const int k = k0 + e / (ROWS / 4), m = m0 + (e % (ROWS / 4)) * 4;
@@ -97,18 +94,6 @@ struct Stager {
             v[p] = x;
         }
     }
-    __device__ __forceinline__ void store_legacy(float* __restrict__ L, int tid) const {   // plain operand -> [k][ROWS+1]
-        constexpr int LS = ROWS + 1;
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const int e = tid + p * NT;
-            if ((ROWS * BK / 4) % NT == 0 || e < ROWS * BK / 4) {
-                const int m = e / (BK / 4), k = (e % (BK / 4)) * 4;
-                L[(k + 0) * LS + m] = v[p].x; L[(k + 1) * LS + m] = v[p].y;
-                L[(k + 2) * LS + m] = v[p].z; L[(k + 3) * LS + m] = v[p].w;
-            }
-        }
-    }
     __device__ __forceinline__ void store(float* __restrict__ L, int tid) const {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -137,10 +122,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LSA = BM + 4;      // k-row pitch of a transposed A image (column sums read it)
-    constexpr bool LEGACY = !AT && !BT;
-    __shared__ __attribute__((aligned(16))) float lds[lds_floats<AT, LEGACY>(BM) + lds_floats<BT, LEGACY>(BN)];
+    __shared__ __attribute__((aligned(16))) float lds[lds_floats<AT>(BM) + lds_floats<BT>(BN)];
     float* As = lds;
-    float* Bs = lds + lds_floats<AT, LEGACY>(BM);
+    float* Bs = lds + lds_floats<AT>(BM);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -167,8 +151,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
     sa.load_any(g.A, g.lda, m0, g.M, kbeg, kend, tid);
     sb.load_any(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        if (LEGACY) { sa.store_legacy(As, tid); sb.store_legacy(Bs, tid); }
-        else { sa.store(As, tid); sb.store(Bs, tid); }
+        sa.store(As, tid);
+        sb.store(Bs, tid);
         __syncthreads();
         if (AT && do_colsum && tid < BM) {
 #pragma unroll 8
@@ -179,24 +163,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
             sb.load_any(g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
         }
         const int arow = wm * (BM / WM) + li, brow = wn * (BN / WN) + li;
-        if (LEGACY) {
-            const float* ap = As + lh * (BM + 1) + arow;
-            const float* bp = Bs + lh * (BN + 1) + brow;
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int t = 0; t < TM; ++t) a[t] = ap[kk * (BM + 1) + t * 32];
-#pragma unroll
-                for (int t = 0; t < TN; ++t) b[t] = bp[kk * (BN + 1) + t * 32];
-#pragma unroll
-                for (int x = 0; x < TM; ++x)
-#pragma unroll
-                    for (int y = 0; y < TN; ++y)
-                        acc[x][y] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[y], a[x], acc[x][y], 0, 0, 0)
-                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
-            }
-        } else
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 8) {
             float4 a[TM];
