@@ -24,6 +24,7 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="rays per renderer call; 0 = whole batch (reference: 2048)")
     ap.add_argument("--lean", action="store_true", help="skip the instance heads in the main pass (their output is discarded)")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="MLP operand precision: fp32 (headline, BASELINE configs[1]) or bf16 operands / fp32 accumulate (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -65,7 +68,7 @@ def main():
 
     model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
     S = int(renderer.n_samples)
-    cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0)
+    cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype)
     tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
     n_batches = 4
     batches = [synthetic.make_batches(pool, a.rays, a.inst_rays, a.classes, 25, seed=100 + rank * 17 + i, device=dev) for i in range(n_batches)]
@@ -113,15 +116,17 @@ def main():
             extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
                          main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                          f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
-            roof = roofline(tr, batches[0], a.lean, engine)
+            roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
-                                       "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32",
+                "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
+                "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
+                                        "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype == "fp32" else
+                                       (f"BASELINE configs[2]-style bf16 mode on the configs[1] shapes (C={a.classes}, E=3/D=6, grid {a.grid}^3): MLP "
+                                        "operands rounded to bf16 in-kernel, fp32 accumulate, fp32 tensors in HBM; everything else fp32"),
                            "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
                            "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean),
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
@@ -132,7 +137,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(tr, batch, lean, engine):
+def roofline(tr, batch, lean, engine, dtype="fp32"):
     """Instrumented step (outside the timed region, same workload): every clift_gemm launch is bracketed by HIP events on
     the stream it is launched on (torch's current stream; the side-stream mode is off by default).  The dominant kernel
     by time is the instantiation k_gemm<128,256,2,4,false,false> = the 256x256 forward layers of the semantic / fast /
@@ -169,6 +174,17 @@ def roofline(tr, batch, lean, engine):
             dom_f += fl; dom_ms += ms; dom_n += 1
     tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ach = tf(dom_f, dom_ms)
+    if dtype == "bf16":
+        # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its fp32
+        # activations.  Algorithmic bytes per launch = A read (M x 256 x 4) + C written (M x 256 x 4) + weights (256 KB, L2).
+        dom_b = sum(4.0 * M * K + 4.0 * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec if kind == "fwd" and N > 128)
+        gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": "k_gemm_bf16<128,256,2,4,false,false,true> (v_mfma_f32_32x32x16_bf16; 256x256 forward MLP layers)",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
+                "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec), "ms_per_step": tot_ms,
+                             "gflop_per_step": tot_f / 1e9,
+                             "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
     return {"bound": "mfma", "kernel": "k_gemm<128,256,2,4,false,false> (fp32 v_mfma_f32_32x32x2_f32; 256x256 forward MLP layers)",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "traffic_note": "not collected live (needs rocprofv3 --pmc passes); profiles/r01_gemm_pmc_notes.txt: FETCH_SIZE x2 + WRITE_SIZE = "

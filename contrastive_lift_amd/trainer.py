@@ -25,7 +25,8 @@ def default_config(**over):
              late_semantic_optimization=1, instance_optimization_epoch=3, chunk=2048, perturb=1.0, batch_size=2048,
              max_rays_instances=1024, max_instances=3, instance_loss_mode="slow_fast", use_DINO_style=True,
              semantic_weight_mode="softmax", stop_semantic_grad=True, probabilistic_ce_mode="TTAConf", weight_class_0=0.0,
-             decay_step=[9, 10], decay_gamma=0.5, temperature=100.0)
+             decay_step=[9, 10], decay_gamma=0.5, temperature=100.0,
+             mlp_dtype="fp32")     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
     c.update(over)
     return types.SimpleNamespace(**c)
 
@@ -56,6 +57,7 @@ class HotPathTrainer:
     def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
         self.white_bg = bool(white_bg)            # dataset attribute in the reference (train_set.white_bg, T:109)
+        engine.set_mlp_precision(getattr(config, "mlp_dtype", "fp32") or "fp32")    # process-wide switch of the matrix-core launches
         self.device = model.param_flat.device
         self.current_epoch = current_epoch
         C = model.num_semantic_classes

@@ -34,6 +34,8 @@ def strip_prefix(state_dict, key):
 
 
 def build_from_checkpoint(config, scene, device):
+    from contrastive_lift_amd import engine
+    engine.set_mlp_precision(getattr(config, "mlp_dtype", "fp32") or "fp32")
     ckpt = torch.load(config.resume, map_location="cpu", weights_only=False)
     sd = ckpt["state_dict"]
     total_classes = len(scene.segmentation_data.bg_classes) + len(scene.segmentation_data.fg_classes)

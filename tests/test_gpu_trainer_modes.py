@@ -102,3 +102,40 @@ def test_data_parallel_two_ranks_match_single_process():
         g0, g1 = tr.model.arena.range_of("grid_density", "grid_app")
         assert float(diff[g0:g1].max()) <= 0.1 * 1e-2 and float(diff[g1:b].max()) <= 0.1 * 5e-4, (float(diff[g0:g1].max()), float(diff[g1:b].max()))
     assert torch.equal(res[0][2], res[1][2])          # both ranks hold bit-identical parameters after the step
+
+
+def test_bf16_mode_tracks_fp32():
+    """bf16 mode (config.mlp_dtype = "bf16", BASELINE configs[2]): MLP operands rounded to bf16 inside the GEMM kernels, fp32
+    accumulation, everything else fp32.  Element-wise it agrees with the fp32 path to bf16 accuracy (1e-3 is NOT expected,
+    SURVEY 7 'bf16 tolerance'); what is asserted is (i) rendered tensors within 2e-2 of the tensor scale, (ii) gradients
+    within 5 % of the tensor scale, (iii) after the same 120 training steps the fit quality (PSNR on the training rays)
+    within 0.1 dB of the fp32 run."""
+    from contrastive_lift_amd import engine
+    try:
+        outs, grads, psnrs = {}, {}, {}
+        for mode in ("fp32", "bf16"):
+            tr, batch, jit = _setup(seed=5, B=2048, Bi=256)
+            tr.config.mlp_dtype = mode
+            engine.set_mlp_precision(mode)
+            o, ctx = engine.render_forward(tr.model, tr.renderer, batch[0]["rays"], jit, False)
+            outs[mode] = {k: o[k].clone() for k in ("rgb", "semantics", "instances")}
+            tr.main_pass(batch[0], jitter=jit, white_bg=False)
+            grads[mode] = _grads(tr)
+            torch.manual_seed(11)
+            for _ in range(120):
+                tr.training_step(batch)
+            rgb, _ = tr.last_outputs
+            psnrs[mode] = float(-10.0 * torch.log10(((rgb - batch[0]["rgbs"]) ** 2).mean()))
+        for k in outs["fp32"]:
+            a, b = outs["bf16"][k], outs["fp32"][k]
+            err = float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+            assert err < 2e-2, (k, err)
+        for k in grads["fp32"]:
+            a, b = grads["bf16"][k], grads["fp32"][k]
+            sc = float(b.abs().max())
+            if sc > 0:
+                assert float((a - b).abs().max()) / sc < 5e-2, k
+        print("PSNR fp32 / bf16 after 120 steps:", psnrs)
+        assert abs(psnrs["fp32"] - psnrs["bf16"]) < 0.1, psnrs
+    finally:
+        engine.set_mlp_precision("fp32")
