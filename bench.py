@@ -117,6 +117,7 @@ def main():
                          main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                          f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
             roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
+            extra.update(inference_probe(cl, model, renderer, pool))
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
@@ -135,6 +136,27 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
+    """Frame-render throughput (BASELINE configs[4] shape: is_train=False, halved step ratio as RP:104, chunked like
+    RP:114-120) on a bounded 262144-ray tile -- reported beside the training metric, outside the timed region."""
+    from contrastive_lift_amd import inference as inf
+    ratio = renderer.step_ratio
+    renderer.update_step_ratio(ratio * 0.5)
+    try:
+        rays = pool[:n_rays].contiguous()
+        inf.render_rays(model, renderer, rays[:chunk], chunk)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        inf.render_rays(model, renderer, rays, chunk)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        S = int(renderer.n_samples)
+    finally:
+        renderer.update_step_ratio(ratio)
+    return dict(inference_rays_per_s=rays.shape[0] / dt, inference_ray_samples_per_s=rays.shape[0] * S / dt,
+                inference_samples_per_ray=S, inference_probe=f"{rays.shape[0]} rays, chunk {chunk}, fp32 outputs rgb/sem/inst/dist")
 
 
 def roofline(tr, batch, lean, engine, dtype="fp32"):

@@ -22,6 +22,44 @@ def render_rays(model, renderer, rays, chunk, white_bg=False):
     return tuple(torch.cat(x, 0) for x in outs)
 
 
+def tile_bounds(n, world):
+    """Contiguous row-tile boundaries of n rays over `world` ranks (sizes differ by at most one)."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+@torch.no_grad()
+def render_rays_sharded(model, renderer, rays, chunk, white_bg=False, render_fn=None):
+    """Multi-GPU frame render (BASELINE configs[4]): the rays of a frame are cut into contiguous row-tiles, one
+    per rank; every rank renders its tile with no communication, then ONE all-gather (RCCL over xGMI; 4*(4+C+D) bytes per
+    ray) assembles the per-ray outputs on every rank.  With no process group it is ``render_rays``.
+    ``render_fn(model, renderer, rays, chunk, white_bg)`` defaults to ``render_rays`` (injectable for CPU tests)."""
+    import torch.distributed as dist
+    fn = render_fn or render_rays
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return fn(model, renderer, rays, chunk, white_bg)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    P = rays.shape[0]
+    b = tile_bounds(P, world)
+    n_mine = b[rank + 1] - b[rank]
+    # a rank whose tile is empty (fewer rays than ranks) renders one ray so that it knows the output widths, and keeps none
+    mine = fn(model, renderer, rays[b[rank]:b[rank + 1]] if n_mine else rays[:1], chunk, white_bg)
+    mine = tuple(x[:n_mine] for x in mine)
+    widths = [int(x.shape[1]) if x.dim() == 2 else 1 for x in mine]
+    packed = torch.cat([x.reshape(n_mine, w) for x, w in zip(mine, widths)], 1)
+    cap = max(b[r + 1] - b[r] for r in range(world))                      # equal-size slots: tiles differ by <= 1 ray
+    slot = torch.zeros((cap, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    slot[:packed.shape[0]] = packed
+    slots = [torch.empty_like(slot) for _ in range(world)]
+    dist.all_gather(slots, slot)
+    full = torch.cat([slots[r][:b[r + 1] - b[r]] for r in range(world)], 0)
+    outs, c = [], 0
+    for x, w in zip(mine, widths):
+        o = full[:, c:c + w]
+        outs.append(o.contiguous() if x.dim() == 2 else o.reshape(-1).contiguous())
+        c += w
+    return tuple(outs)
+
+
 def distance_to_depth(K, dist):
     """util/camera.py:86-104 for a (H,W) distance image on the device: z = dist / |K^-1 [u, v, 1]|."""
     H, W = dist.shape

@@ -88,6 +88,16 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
         raise NotImplementedError("trajectory rendering needs the scene's trajectory_blender poses; only the test split is wired")
     out = output_dirname(config, trajectory_name, test_only, use_dbscan, segmentwise)
     out.mkdir(exist_ok=True, parents=True)
+    # launched under torch.distributed.run: one process per GPU, every frame rendered as row-tiles (one per rank) and
+    # assembled with one all-gather (inference.render_rays_sharded); clustering and file output happen on rank 0
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        device = f"cuda:{local}"
+        dist.init_process_group(os.environ.get("CLIFT_DIST_BACKEND", "nccl"))
+    rank = dist.get_rank() if dist.is_initialized() else 0
     device = torch.device(device)
     if config.dataset_class != "mos":
         raise NotImplementedError("only the MOS (Messy-Rooms) on-disk layout is wired in this round (SURVEY 8f rank 4)")
@@ -100,7 +110,7 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
     with torch.no_grad():
         for i in scene.val_indices:
             rays = scene.rays_for(i)
-            p_rgb, p_sem, p_inst, p_dist = inf.render_rays(model, renderer, rays, int(config.chunk), scene.white_bg)
+            p_rgb, p_sem, p_inst, p_dist = inf.render_rays_sharded(model, renderer, rays, int(config.chunk), scene.white_bg)
             depths.append(inf.distance_to_depth(scene.intrinsics[i], p_dist.view(H, W)))
             if config.use_delta:
                 p_inst = p_inst + (rays[:, 0:3] + p_dist[:, None] * rays[:, 3:6])
@@ -111,6 +121,8 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
             rgbs.append(p_rgb)
             sems.append(p_sem)
             thing_feats.append(inf.create_instances_from_semantics(p_inst, p_sem, fg))
+    if rank != 0:
+        return out
     np.save(out / "instance_features.npy", torch.cat(inst_feats, 0).cpu().numpy())
     all_thing = torch.cat(thing_feats, 0).cpu().numpy()
     np.save(out / "thing_features.npy", all_thing)

@@ -98,3 +98,43 @@ def test_state_dict_roundtrip_and_layout():
     assert len(groups) == 7 and groups[0]["lr"] == 1e-2 and groups[-1]["lr"] == 5e-4
     assert len(m2.get_optimizable_instance_parameters(1e-2, 5e-4, using_DINO=True)) == 1
     assert len(m2.get_optimizable_instance_parameters(1e-2, 5e-4, using_DINO=False)) == 2
+
+
+def _fake_render(model, renderer, rays, chunk, white_bg):
+    """Deterministic per-ray stand-in for the GPU renderer with the real output signature (rgb, semantics, instances, dist)."""
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    return (o * 2 + d, torch.cat([o, d, o * d], 1)[:, :5], torch.cat([d, o], 1), rays[:, 7] * 3 - rays[:, 6])
+
+
+def _shard_worker(rank, world, port, q, P):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contrastive_lift_amd import inference as inf
+        g = torch.Generator().manual_seed(9)
+        rays = torch.randn((P, 8), generator=g)
+        got = inf.render_rays_sharded(None, None, rays, 0, False, render_fn=_fake_render)
+        want = _fake_render(None, None, rays, 0, False)
+        ok = all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(got, want))
+        b = inf.tile_bounds(P, world)
+        ok = ok and b[0] == 0 and b[-1] == P and max(b[i + 1] - b[i] for i in range(world)) - min(b[i + 1] - b[i] for i in range(world)) <= 1
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_render_row_tiles_world2():
+    """Inference sharding (BASELINE configs[4]): contiguous row-tiles per rank + one all-gather == the unsharded render, for
+    even, odd and smaller-than-world ray counts."""
+    for P in (64, 1001, 1):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, P)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(180)
+            assert p.exitcode == 0, P
+        res = [q.get(timeout=10) for _ in ps]
+        assert all(ok for _, ok in res), (P, res)
