@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--lean", action="store_true", help="skip the instance heads in the main pass (their output is discarded)")
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                     help="MLP operand precision: fp32 (headline, BASELINE configs[1]) or bf16 operands / fp32 accumulate (configs[2])")
+    ap.add_argument("--inference-probe", action="store_true",
+                    help="also report frame-render throughput (adds larger launches of the same kernels: keep it out of profiled runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -117,7 +119,8 @@ def main():
                          main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                          f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
             roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
-            extra.update(inference_probe(cl, model, renderer, pool))
+            if a.inference_probe:
+                extra.update(inference_probe(cl, model, renderer, pool))
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
@@ -208,9 +211,12 @@ def roofline(tr, batch, lean, engine, dtype="fp32"):
                              "gflop_per_step": tot_f / 1e9,
                              "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
     return {"bound": "mfma", "kernel": "k_gemm<128,256,2,4,false,false> (fp32 v_mfma_f32_32x32x2_f32; 256x256 forward MLP layers)",
-            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "traffic_note": "not collected live (needs rocprofv3 --pmc passes); profiles/r01_gemm_pmc_notes.txt: FETCH_SIZE x2 + WRITE_SIZE = "
-                            "541 MB per M=265k launch vs 543 MB algorithmic (A read + C written, weights L2-resident)",
+            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+            # HBM bytes per (average) launch of the dominant kernel: PMC ratio measured offline with separate rocprofv3 --pmc
+            # passes (profiles/r01_gemm_pmc_notes.txt: FETCH_SIZE x2 (gfx950) + WRITE_SIZE = 541 MB for the M = 265 k launch vs
+            # 543 MB algorithmic = A read + C written, weights L2-resident), applied to this run's average launch size
+            "traffic": (541.0 / 543.0) * (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0,
+            "traffic_unit": "bytes/launch (PMC ratio 541/543 from profiles/r01_gemm_pmc_notes.txt x algorithmic 8 B per output element)",
             "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
             "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec),
                          "ms_per_step": tot_ms, "gflop_per_step": tot_f / 1e9,
