@@ -151,11 +151,13 @@ class HotPathTrainer:
             rays = img["rays"]
             n = rays.shape[0]
             jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
-            # EMA first (T:258-259): one fused axpy over the contiguous fast/slow arena ranges
+            # reference order: render the features (fast and slow halves) first (T:214), THEN the EMA step of the slow net at
+            # the top of the loss (T:258-259) -- the slow features of this step come from the pre-update weights (golden G12).
+            # One fused axpy over the contiguous fast/slow arena ranges; stream order keeps it behind the forward's reads.
+            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance")
             f0, f1 = m.arena.range_of("inst_fast")
             s0, s1 = m.arena.range_of("inst_slow")
             _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
-            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance")
             loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
             self.losses[3] = self.losses[3] + loss
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)

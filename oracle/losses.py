@@ -40,7 +40,9 @@ def ema_(slow_params, fast_params, momentum=0.9):
     """trainer/train_panopli_tensorf.py:325-329."""
     with torch.no_grad():
         for s, f in zip(slow_params, fast_params):
-            s.mul_(momentum).add_((1 - momentum) * f.detach())
+            # .data like the reference: the update happens between the forward and the backward of the same step (T:214 vs
+            # T:258) and must not invalidate the autograd graph (the slow half only ever receives zero gradients)
+            s.data.mul_(momentum).add_((1 - momentum) * f.detach().data)
 
 
 def slow_fast(inst_feats, labels, conf):

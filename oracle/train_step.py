@@ -37,7 +37,7 @@ class CpuTrainer:
         if class_weights is None:
             self.cw[0] = 0.0
 
-    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags):
+    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None):
         self.opt_main.zero_grad(set_to_none=True)
         for p in self.fast + self.slow:
             p.grad = None
@@ -47,6 +47,9 @@ class CpuTrainer:
             outs.append(orender.render_forward(self.P, rays[i:i + self.chunk], self.cfg, jit, bool(white_flags[ci])))
         rgb = torch.cat([o[0] for o in outs])
         sem = torch.cat([o[1] for o in outs])
+        if mask is not None:                      # T:156-158: masked pixels contribute neither colour nor semantics
+            keep = mask.to(rgb.dtype)
+            rgb, rgbs, conf = rgb * keep[:, None], rgbs * keep[:, None], conf * keep
         dreg = torch.stack([o[5] for o in outs]).mean()
         l_rgb = torch.nn.functional.mse_loss(rgb, rgbs)
         l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva)
@@ -58,8 +61,10 @@ class CpuTrainer:
 
     def instance_pass(self, rays, labels, conf, jitter):
         self.opt_inst.zero_grad(set_to_none=True)
-        olosses.ema_(self.slow, self.fast, 0.9)
+        # order of the reference: the features (fast AND slow halves) are rendered first (T:214), the EMA step of the slow
+        # net happens at the top of the loss (T:258-259) -- so the slow features of step t come from the pre-update weights
         inst, xyz = orender.render_instance_feature(self.P, rays, self.cfg, jitter)
+        olosses.ema_(self.slow, self.fast, 0.9)
         loss = olosses.slow_fast(inst, labels, conf)
         loss.backward()
         self.opt_inst.step()

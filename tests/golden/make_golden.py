@@ -116,7 +116,7 @@ def grad_digest(prefix, named_grads):
     for k, g in named_grads.items():
         g = torch.zeros(1) if g is None else g.detach().reshape(-1)
         out[f"{prefix}norm.{k}"] = g.norm()
-        out[f"{prefix}sub.{k}"] = g if g.numel() <= 4096 else g[::GRAD_STRIDE]
+        out[f"{prefix}sub.{k}"] = (g if g.numel() <= 4096 else g[::GRAD_STRIDE]).clone()   # clone: parameters are updated in place later
     return out
 
 
@@ -439,7 +439,128 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
+def g12_training_steps():
+    """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
+    .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
+    (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
+    trainer flags).  The random draws of the renderer (per-ray jitter R:810, white-background coin R:164) are recorded and
+    stored so that the oracle can replay them."""
+    import types as _t
+    import trainer.train_panopli_tensorf as T
+    import model.renderer.panopli_tensoRF_renderer as RR
+    from model.loss.loss import TVLoss
+    res, C, E = (9, 13, 17), 4, 3
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    P, pool, rng = _scene(121, res, C, E, aabb, 200)
+    B, Bi, steps, epoch = 96, 64, 3, 4
+    cfg = _t.SimpleNamespace(
+        lr=5e-4, weight_decay=1e-8, decay_step=[9, 10], decay_gamma=0.5, warmup_epochs=0, chunk=40, perturb=1.0,
+        optimize_instance_only=False, lambda_rgb=1.0, lambda_semantics=0.1, lambda_feat=0.0, lambda_segment=0.0,
+        lambda_tv_density=0.1, lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02,
+        use_distilled_features_semantic=False, use_distilled_features_instance=False, feature_optimization_end_epoch=0,
+        late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=100, segment_grouping_mode="none",
+        probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E)
+    m = build_reference_model(P, res, C, E, shift=-3.0)
+    rr = build_reference_renderer(aabb, res, "softmax")
+    cw = torch.ones(C)
+    cw[0] = 0.0
+
+    class Shim:
+        configure_optimizers = T.TensoRFTrainer.configure_optimizers
+        forward = T.TensoRFTrainer.forward
+        forward_instance = T.TensoRFTrainer.forward_instance
+        training_step = T.TensoRFTrainer.training_step
+        calculate_instance_clustering_loss = T.TensoRFTrainer.calculate_instance_clustering_loss
+        ema_update_slownet = T.TensoRFTrainer.ema_update_slownet
+
+        def __call__(self, *a):
+            return self.forward(*a)
+
+        def optimizers(self):
+            return self._opts
+
+        def lr_schedulers(self):
+            return self._scheds
+
+        def manual_backward(self, loss):
+            loss.backward()
+
+        def log(self, name, value, **k):
+            self.logged.setdefault(name, []).append(float(value))
+
+    sh = Shim()
+    sh.config, sh.model, sh.renderer = cfg, m, rr
+    sh.train_set = _t.SimpleNamespace(white_bg=False)
+    sh.loss = torch.nn.MSELoss(reduction="mean")
+    sh.loss_feat = torch.nn.L1Loss(reduction="mean")
+    sh.tv_regularizer = TVLoss()
+    sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
+    sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = "slow_fast", True, 100.0, False
+    sh.device = torch.device("cpu")
+    sh.current_epoch = epoch
+    sh.current_lambda_dist_reg = 0.005 * (1 - np.exp(-0.25 * epoch))                      # T:447
+    sh.trainer = _t.SimpleNamespace(is_last_batch=False, current_epoch=epoch)
+    sh.logged = {}
+    sh._opts, sh._scheds = sh.configure_optimizers()
+    groups = [[(float(g["lr"]), float(g["weight_decay"]), tuple(float(b) for b in g["betas"]), sum(p.numel() for p in g["params"]))
+               for g in o.param_groups] for o in sh._opts]
+
+    out = dict(res=np.array(res), C=C, E=E, seed=121, shift=-3.0, aabb=aabb, B=B, Bi=Bi, steps=steps, epoch=epoch, chunk=cfg.chunk,
+               class_weights=cw, lambda_dist=np.float64(sh.current_lambda_dist_reg),
+               opt_groups=np.array([[g[0], g[1], g[2][0], g[2][1], g[3]] for o in groups for g in o], np.float64),
+               opt_group_counts=np.array([len(o) for o in groups]))
+    real_rl, real_r = RR.torch.rand_like, RR.torch.rand
+    draws = []
+
+    def rec_rand_like(t, *a, **k):
+        v = real_rl(t, *a, **k)
+        draws.append(("jit", v.reshape(-1).clone()))
+        return v
+
+    def rec_rand(*a, **k):
+        v = real_r(*a, **k)
+        draws.append(("coin", v.reshape(-1).clone()))
+        return v
+
+    RR.torch.rand_like, RR.torch.rand = rec_rand_like, rec_rand
+    try:
+        for st in range(steps):
+            pick = torch.from_numpy(rng.choice(pool.shape[0], size=B, replace=False))
+            rays = pool[pick].clone()
+            rgbs = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+            probs = torch.softmax(torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32)), -1)
+            confs = torch.from_numpy(rng.uniform(0, 1, (B,)).astype(np.float32))
+            mask = torch.from_numpy(rng.uniform(0, 1, (B,)) > 0.1)
+            sem = probs.argmax(-1)
+            pick2 = torch.from_numpy(rng.choice(pool.shape[0], size=Bi, replace=False))
+            irays = pool[pick2].clone()
+            labels = torch.from_numpy(rng.integers(1, 5, size=(Bi,)))
+            iconf = torch.from_numpy(rng.uniform(0, 1, (Bi,)).astype(np.float32))
+            out.update({f"s{st}.rays": rays.clone(), f"s{st}.rgbs": rgbs.clone(), f"s{st}.probs": probs.clone(), f"s{st}.confs": confs.clone(),
+                        f"s{st}.mask": mask.clone(), f"s{st}.irays": irays.clone(), f"s{st}.labels": labels.clone(), f"s{st}.iconf": iconf.clone()})
+            batch = {0: dict(rays=rays, rgbs=rgbs, semantics=sem, probabilities=probs, confidences=confs, mask=mask, feats=torch.zeros(B, 1)),
+                     1: dict(rays=[irays], instances=[labels], confidences=[iconf])}
+            draws.clear()
+            torch.manual_seed(1000 + st)
+            sh.training_step(batch, st)
+            jit = torch.cat([v for k, v in draws if k == "jit"][: (B + cfg.chunk - 1) // cfg.chunk])
+            ijit = torch.cat([v for k, v in draws if k == "jit"][(B + cfg.chunk - 1) // cfg.chunk:])
+            coins = torch.cat([v for k, v in draws if k == "coin"])
+            assert jit.numel() == B and ijit.numel() == Bi and coins.numel() == (B + cfg.chunk - 1) // cfg.chunk, (jit.shape, ijit.shape, coins.shape)
+            out.update({f"s{st}.jitter": jit, f"s{st}.ijitter": ijit, f"s{st}.white": (coins < 0.5)})
+            out.update({f"s{st}.loss_rgb": np.float32(sh.logged["train/loss_rgb"][-1]),
+                        f"s{st}.loss_sem": np.float32(sh.logged["train/loss_semantics"][-1]),
+                        f"s{st}.loss_clustering": np.float32(sh.logged["train/loss_clustering"][-1]),
+                        f"unpinned_s{st}.loss_dist": np.float32(sh.logged["train/loss_dist_regularizer"][-1]),
+                        f"s{st}.psnr": np.float32(sh.logged["train/psnr"][-1])})
+            out.update(grad_digest(f"s{st}.p", {k: p.detach() for k, p in m.named_parameters()}))
+    finally:
+        RR.torch.rand_like, RR.torch.rand = real_rl, real_r
+    npz("g12_training_steps", **out)
+
+
 def main():
+    only = sys.argv[1:]
     if not os.path.isdir(REF):
         sys.exit(f"reference not found at {REF}: golden vectors can only be regenerated in the build container")
     torch.set_num_threads(4)
@@ -454,6 +575,7 @@ def main():
     g9_tv()
     g10_grid_ops()
     g11_metrics()
+    g12_training_steps()
 
 
 if __name__ == "__main__":

@@ -554,6 +554,45 @@ def test_training_step_vs_oracle():
         assert diff <= 0.1 * lr * 2 + 1e-7, f"param {k}: max |diff| {diff:.3e} vs lr {lr}"   # elements with |g| ~ eps amplify gradient round-off
 
 
+def test_g12_reference_training_steps_on_gpu():
+    """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
+    class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
+    instance pass with the EMA between forward and loss): losses to 1e-3, every parameter after every step to 10 % of a
+    learning-rate step (Adam moves a weight by ~lr whatever the gradient size, so gradient round-off on |g| ~ eps elements
+    is amplified to that scale) and norms to 1e-3."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    g = load_golden("g12_training_steps")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, float(g["shift"]))
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+    cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3)
+    tr = HotPathTrainer(m, r, cfg, class_weights=T(g["class_weights"]), current_epoch=int(g["epoch"]))
+    rel_close(tr.current_lambda_dist_reg, g["lambda_dist"], 1e-6, what="dist-reg ramp")
+    d = lambda a: (torch.from_numpy(a) if isinstance(a, np.ndarray) else a).to(DEV)
+    for st in range(int(g["steps"])):
+        white = [bool(x) for x in g[f"s{st}.white"]]
+        assert len(set(white)) == 1          # the recorded coin flips of one step happen to agree: one flag per main pass
+        batch0 = dict(rays=d(g[f"s{st}.rays"]), rgbs=d(g[f"s{st}.rgbs"]), probabilities=d(g[f"s{st}.probs"]),
+                      confidences=d(g[f"s{st}.confs"]), mask=d(g[f"s{st}.mask"]))
+        tr.main_pass(batch0, jitter=d(g[f"s{st}.jitter"]), white_bg=white[0])
+        rel_close(tr.losses[0], g[f"s{st}.loss_rgb"], 1e-3, what=f"step {st} loss_rgb")
+        rel_close(tr.losses[1], g[f"s{st}.loss_sem"], 1e-3, what=f"step {st} loss_sem")
+        tr.instance_pass([dict(rays=d(g[f"s{st}.irays"]), instances=d(g[f"s{st}.labels"]), confidences=d(g[f"s{st}.iconf"]))],
+                         jitter=d(g[f"s{st}.ijitter"]))
+        rel_close(tr.losses[3], g[f"s{st}.loss_clustering"], 1e-3, what=f"step {st} loss_clustering")
+        sd = m.state_dict()
+        for k in P:
+            flat = sd[k].detach().cpu().reshape(-1)
+            sub = flat if flat.numel() <= 4096 else flat[::17]
+            lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
+            rel_close(flat.norm(), g[f"s{st}.pnorm.{k}"], 1e-3, atol=1e-6, what=f"step {st} |{k}|")
+            diff = float((sub - T(g[f"s{st}.psub.{k}"]).reshape(-1)).abs().max())
+            assert diff <= 0.1 * lr * (st + 1) + 1e-7, f"step {st} param {k}: max |diff| {diff:.3e} vs lr {lr}"
+
+
 # ============================================================================ field point API + grid surgery (8f rank 1)
 def test_field_point_api_golden_g3():
     cl, op, *_ = _import()

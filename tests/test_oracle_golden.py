@@ -191,3 +191,40 @@ def test_g11_metrics_vs_reference():
         rel_close(torch.stack([pq, sq, rq]), g[f"pq{k}.out"], 1e-6, atol=1e-9, what=f"pq case {k}")
     with pytest.raises(ValueError):
         panoptic_quality(T(g["pq0.preds"]), T(g["pq0.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=False)
+
+
+def test_g12_three_reference_training_steps():
+    """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
+    forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
+    net) with the recorded jitter / white-background draws: losses to 1e-4, every parameter after every step to a small
+    fraction of one Adam step (Adam normalises the gradient, so a round-off-level gradient difference on a near-zero
+    gradient moves a weight by up to lr; what is asserted is the norm to 1e-4 and elementwise 5 % of lr)."""
+    from oracle.train_step import CpuTrainer
+    g = load_golden("g12_training_steps")
+    res = tuple(int(x) for x in g["res"])
+    C, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E), res, 2.5, 0.45)
+    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
+    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]))
+    rel_close(tr.l_dist, g["lambda_dist"], 1e-6, what="dist-reg ramp")
+    # optimizer layout of the reference (T:98-103): 7 main groups (4 grid groups at 20 lr, 3 net groups at lr) + 1 instance group
+    og = g["opt_groups"]
+    assert list(g["opt_group_counts"]) == [7, 1]
+    main_lr = {float(x["lr"]): sum(p.numel() for p in x["params"]) for x in tr.opt_main.param_groups}
+    assert main_lr[1e-2] == int(og[:4, 4].sum()) and main_lr[5e-4] == int(og[4:7, 4].sum())
+    assert sum(p.numel() for p in tr.opt_inst.param_groups[0]["params"]) == int(og[7, 4])
+    assert tr.opt_main.param_groups[0]["betas"] == (0.9, 0.99) and tr.opt_inst.param_groups[0]["betas"] == (0.9, 0.999)
+    assert all(abs(x["weight_decay"] - og[0, 1]) < 1e-20 for x in tr.opt_main.param_groups + tr.opt_inst.param_groups)
+    for st in range(int(g["steps"])):
+        o = tr.main_pass(T(g[f"s{st}.rays"]), T(g[f"s{st}.rgbs"]), T(g[f"s{st}.probs"]), T(g[f"s{st}.confs"]), T(g[f"s{st}.jitter"]),
+                         [bool(x) for x in g[f"s{st}.white"]], mask=torch.from_numpy(g[f"s{st}.mask"]))
+        rel_close(o["loss_rgb"], g[f"s{st}.loss_rgb"], 1e-4, what=f"step {st} loss_rgb")
+        rel_close(o["loss_sem"], g[f"s{st}.loss_sem"], 1e-4, what=f"step {st} loss_sem")
+        oi = tr.instance_pass(T(g[f"s{st}.irays"]), torch.from_numpy(g[f"s{st}.labels"]), T(g[f"s{st}.iconf"]), T(g[f"s{st}.ijitter"]))
+        rel_close(oi["loss"], g[f"s{st}.loss_clustering"], 1e-4, what=f"step {st} loss_clustering")
+        for k, v in tr.P.items():
+            flat = v.detach().reshape(-1)
+            sub = flat if flat.numel() <= 4096 else flat[::17]
+            lr = 1e-2 if k.startswith(("density_", "appearance_plane", "appearance_line")) else 5e-4
+            rel_close(flat.norm(), g[f"s{st}.pnorm.{k}"], 1e-4, atol=1e-7, what=f"step {st} |{k}|")
+            assert float((sub - T(g[f"s{st}.psub.{k}"]).reshape(-1)).abs().max()) <= 0.05 * lr * (st + 1), (st, k)
