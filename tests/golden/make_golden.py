@@ -559,6 +559,42 @@ def g12_training_steps():
     npz("g12_training_steps", **out)
 
 
+def g13_postprocess():
+    """Inference post-processing of the reference: create_instances_from_semantics (RP:422-427), assign_clusters
+    (RP:371-419: per thing class nearest cached centroid, disjoint label offsets, one-hot), distance_to_depth
+    (util/camera.py:86-104)."""
+    sys.modules["hdbscan"].HDBSCAN = _Inert
+    import importlib
+    RP = importlib.import_module("inference.render_panopli")
+    assert RP.__file__.startswith(REF)
+    from util.camera import distance_to_depth
+    rng = np.random.default_rng(131)
+    n_img, Ppx, C, E = 3, 40, 5, 3
+    things = [2, 3]
+    sems = [torch.from_numpy(rng.standard_normal((Ppx, C)).astype(np.float32)) for _ in range(n_img)]
+    insts = [torch.from_numpy(rng.standard_normal((Ppx, E)).astype(np.float32)) for _ in range(n_img)]
+    thing_feats = [RP.create_instances_from_semantics(i, s, things) for i, s in zip(insts, sems)]
+    all_thing = torch.cat(thing_feats, 0).numpy()
+    cents = {2: rng.standard_normal((3, E)).astype(np.float32), 3: rng.standard_normal((2, E)).astype(np.float32)}
+    with quiet():
+        onehot = RP.assign_clusters(all_thing.copy(), sems, cents, torch.device("cpu"), num_images=n_img)
+    # a second case in which one thing class never occurs (labels stay disjoint, K shrinks)
+    sems_b = [s.clone() for s in sems]
+    for s_ in sems_b:
+        s_[:, 3] = -10.0
+    thing_b = torch.cat([RP.create_instances_from_semantics(i, s_, things) for i, s_ in zip(insts, sems_b)], 0).numpy()
+    with quiet():
+        onehot_b = RP.assign_clusters(thing_b.copy(), sems_b, cents, torch.device("cpu"), num_images=n_img)
+    K = torch.tensor([[55.0, 0.0, 11.5], [0.0, 57.0, 7.5], [0.0, 0.0, 1.0]])
+    dist = torch.from_numpy(rng.uniform(0.2, 3.0, (16, 24)).astype(np.float32))
+    z = distance_to_depth(K, dist)
+    out = dict(things=np.array(things), n_img=n_img, K=K, dist=dist, depth=z, onehot=onehot, onehot_b=onehot_b, all_thing=all_thing, all_thing_b=thing_b,
+               cent2=cents[2], cent3=cents[3])
+    for j in range(n_img):
+        out[f"sem{j}"], out[f"inst{j}"], out[f"thing{j}"], out[f"semb{j}"] = sems[j], insts[j], thing_feats[j], sems_b[j]
+    npz("g13_postprocess", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -576,6 +612,7 @@ def main():
     g10_grid_ops()
     g11_metrics()
     g12_training_steps()
+    g13_postprocess()
 
 
 if __name__ == "__main__":

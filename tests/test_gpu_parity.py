@@ -593,6 +593,20 @@ def test_g12_reference_training_steps_on_gpu():
             assert diff <= 0.1 * lr * (st + 1) + 1e-7, f"step {st} param {k}: max |diff| {diff:.3e} vs lr {lr}"
 
 
+def test_g13_assign_clusters_vs_reference():
+    """inference.assign_clusters (clift_nearest_centroid per thing class, disjoint label offsets, one-hot) reproduces the
+    reference's RP:371-419 output exactly, including the case where a thing class never occurs."""
+    from contrastive_lift_amd.inference import assign_clusters
+    g = load_golden("g13_postprocess")
+    cents = {2: g["cent2"], 3: g["cent3"]}
+    n = int(g["n_img"])
+    for feats, pre, want in ((g["all_thing"], "sem", g["onehot"]), (g["all_thing_b"], "semb", g["onehot_b"])):
+        sems = [T(g[f"{pre}{j}"]) for j in range(n)]
+        got = assign_clusters(feats, sems, cents, torch.device(DEV), num_images=n)
+        assert tuple(got.shape) == tuple(want.shape)
+        assert torch.equal(got.cpu().to(torch.float64), torch.from_numpy(want))
+
+
 # ============================================================================ field point API + grid surgery (8f rank 1)
 def test_field_point_api_golden_g3():
     cl, op, *_ = _import()

@@ -228,3 +228,15 @@ def test_g12_three_reference_training_steps():
             lr = 1e-2 if k.startswith(("density_", "appearance_plane", "appearance_line")) else 5e-4
             rel_close(flat.norm(), g[f"s{st}.pnorm.{k}"], 1e-4, atol=1e-7, what=f"step {st} |{k}|")
             assert float((sub - T(g[f"s{st}.psub.{k}"]).reshape(-1)).abs().max()) <= 0.05 * lr * (st + 1), (st, k)
+
+
+def test_g13_postprocess_host_parts():
+    """create_instances_from_semantics and distance_to_depth of the product (pure torch, device-agnostic) against the
+    reference's outputs; assign_clusters (nearest-centroid kernel) is checked on the GPU (tests/test_gpu_parity.py)."""
+    from contrastive_lift_amd.inference import create_instances_from_semantics, distance_to_depth
+    g = load_golden("g13_postprocess")
+    things = [int(x) for x in g["things"]]
+    for j in range(int(g["n_img"])):
+        got = create_instances_from_semantics(T(g[f"inst{j}"]), T(g[f"sem{j}"]), things)
+        assert torch.equal(got, T(g[f"thing{j}"]))
+    rel_close(distance_to_depth(T(g["K"]), T(g["dist"])), g["depth"], 1e-6, what="distance_to_depth")
