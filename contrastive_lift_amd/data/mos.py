@@ -121,11 +121,18 @@ class MOSScene:
             conf = np.ones_like(sem).astype(np.float32)
         sem_t = torch.from_numpy(np.array(Image.fromarray(sem.astype(np.uint8)).resize((W, H), Image.NEAREST))).long()
         inst_t = torch.from_numpy(np.array(Image.fromarray(inst.astype(np.int16)).resize((W, H), Image.NEAREST))).long()
-        conf_t = torch.nn.functional.interpolate(torch.from_numpy(conf).float()[None, None], size=(H, W), mode="bilinear",
+        # size = image_dim[::-1] = (W, H) exactly as the reference (:171): a no-op distinction for the square training images
+        # (TI:71); for non-square image_dim the reference's confidence table is the (W, H)-shaped resize flattened (golden G14)
+        conf_t = torch.nn.functional.interpolate(torch.from_numpy(conf).float()[None, None], size=(W, H), mode="bilinear",
                                                  align_corners=False)[0, 0]
         probs = torch.nn.functional.one_hot(sem_t, num_classes=self.num_semantics).float()
+        mpath = os.path.join(self.root, "invalid", f"{name}.jpg")              # :196-200 room mask (True = pixel is used)
+        if os.path.exists(mpath):
+            mask = ~torch.from_numpy(np.array(Image.open(mpath).resize((W, H), Image.NEAREST)) > 0).bool().reshape(-1)
+        else:
+            mask = torch.ones(H * W, dtype=torch.bool)
         return dict(rgbs=rgb.reshape(-1, 3), semantics=sem_t.reshape(-1), instances=inst_t.reshape(-1),
-                    probabilities=probs.reshape(-1, self.num_semantics), confidences=conf_t.reshape(-1))
+                    probabilities=probs.reshape(-1, self.num_semantics), confidences=conf_t.reshape(-1), mask=mask)
 
     def build_train_tables(self):
         """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
@@ -134,7 +141,6 @@ class MOSScene:
             rays.append(self.rays_for(i))
             tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items()})
         self.tables = dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]})
-        self.tables["mask"] = torch.ones(self.tables["rays"].shape[0], dtype=torch.bool, device=self.device)
         hw = self.image_dim[0] * self.image_dim[1]
         self.instance_images = []
         for j in range(len(self.train_indices)):

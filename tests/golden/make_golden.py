@@ -595,6 +595,56 @@ def g13_postprocess():
     npz("g13_postprocess", **out)
 
 
+def g14_mos_dataset():
+    """The reference's MOSDataset (dataset/many_object_scenes.py:22-207: camera conventions, frustum-sphere scene
+    normalisation util/camera.py:10-73, train/val split, image / label / confidence resizing, ray table, room mask) run on a
+    scene written by tools/make_synthetic_mos.py (deterministic; the test regenerates the same files).
+    pyquaternion is absent from this image: ``Quaternion(w,x,y,z).rotation_matrix`` is supplied by the textbook unit-
+    quaternion formula (normalised first, as that package does) -- the only restated arithmetic in this fixture."""
+    import pathlib
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+
+    class Quaternion:
+        def __init__(self, w, x, y, z):
+            q = np.array([w, x, y, z], np.float64)
+            self.q = q / np.linalg.norm(q)
+
+        @property
+        def rotation_matrix(self):
+            w, x, y, z = self.q
+            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                             [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                             [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    sys.modules["pyquaternion"].Quaternion = Quaternion
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="g14_")
+    scene_args = dict(n_frames=10, size=24, seed=7, invalid_frames=(0,))
+    root = gen.make_scene(os.path.join(tmp, "scene"), **scene_args)
+    cwd = os.getcwd()
+    os.chdir(REF)                               # the reference reads resources/*.csv relative to its checkout
+    try:
+        from dataset.many_object_scenes import MOSDataset
+        out = dict(n_frames=10, size=24, seed=7, invalid_frame=0, max_depth=3.0, frames=np.array([0, 5]))
+        for tag, dim in (("native", (24, 24)), ("resized", (16, 20))):
+            with quiet():
+                ds = MOSDataset(pathlib.Path(root), "train", dim, 3.0, instance_dir="detic_instance", semantics_dir="detic_semantic",
+                                instance_to_semantic_key=None, create_seg_data_func=None)
+            hw = dim[0] * dim[1]
+            out.update({f"{tag}.dim": np.array(dim), f"{tag}.train_indices": np.array(ds.train_indices), f"{tag}.val_indices": np.array(ds.val_indices),
+                        f"{tag}.scene2normscene": ds.scene2normscene, f"{tag}.scene_bounds": ds.scene_bounds})
+            for f in (0, 5):
+                j = ds.train_indices.index(f)
+                sl = slice(j * hw, (j + 1) * hw)
+                out.update({f"{tag}.f{f}.K": ds.intrinsics[f], f"{tag}.f{f}.cam2normscene": ds.cam2normscene[f],
+                            f"{tag}.f{f}.rays": ds.all_rays[sl], f"{tag}.f{f}.rgbs": ds.all_rgbs[sl], f"{tag}.f{f}.semantics": ds.all_semantics[sl],
+                            f"{tag}.f{f}.instances": ds.all_instances[sl], f"{tag}.f{f}.probabilities": ds.all_probabilities[sl],
+                            f"{tag}.f{f}.confidences": ds.all_confidences[sl], f"{tag}.f{f}.mask": ds.all_masks[sl]})
+    finally:
+        os.chdir(cwd)
+    npz("g14_mos_dataset", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -613,6 +663,7 @@ def main():
     g11_metrics()
     g12_training_steps()
     g13_postprocess()
+    g14_mos_dataset()
 
 
 if __name__ == "__main__":

@@ -43,3 +43,41 @@ def test_mos_camera_conventions(tmp_path):
     M = world_to_normscene([[16, 16]] * 6, [K] * 6, poses, max_depth=5.0)
     for P in poses:                                     # every camera ends up inside the unit sphere
         assert np.linalg.norm((M @ P)[:3, 3]) < 1.0
+
+
+def _g14_scene(tmp_path, g):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+    return gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
+                          invalid_frames=(int(g["invalid_frame"]),))
+
+
+def test_g14_mos_reader_vs_reference_dataset(tmp_path):
+    """MOSScene against the REFERENCE's MOSDataset run on the same files (golden G14): split, scene normalisation, per-frame
+    intrinsics and camera matrices, and every per-pixel target table (image LANCZOS resize, NEAREST labels, bilinear
+    confidences with the background override, one-hot probabilities, room mask) -- native and resized image_dim.
+    The ray tables (device kernel) are compared in tests/test_gpu_parity.py."""
+    import numpy as np
+    import torch
+    from conftest import load_golden, rel_close
+    from contrastive_lift_amd.data import MOSScene
+    g = load_golden("g14_mos_dataset")
+    root = _g14_scene(tmp_path, g)
+    for tag in ("native", "resized"):
+        dim = tuple(int(x) for x in g[f"{tag}.dim"])
+        sc = MOSScene(root, "train", dim, float(g["max_depth"]), device="cpu")
+        assert sc.train_indices == list(g[f"{tag}.train_indices"]) and sc.val_indices == list(g[f"{tag}.val_indices"])
+        rel_close(torch.from_numpy(sc.scene2normscene).float(), g[f"{tag}.scene2normscene"], 1e-5, atol=1e-6, what="scene2normscene")
+        assert torch.equal(sc.scene_bounds, torch.from_numpy(g[f"{tag}.scene_bounds"]))
+        for f in (int(x) for x in g["frames"]):
+            rel_close(sc.intrinsics[f], g[f"{tag}.f{f}.K"], 1e-6, what="K")
+            rel_close(sc.cam2normscene[f], g[f"{tag}.f{f}.cam2normscene"], 1e-5, atol=1e-6, what="cam2normscene")
+            t = sc.load_targets(f)
+            rel_close(t["rgbs"], g[f"{tag}.f{f}.rgbs"], 1e-6, what="rgbs")
+            assert torch.equal(t["semantics"], torch.from_numpy(g[f"{tag}.f{f}.semantics"]))
+            assert torch.equal(t["instances"], torch.from_numpy(g[f"{tag}.f{f}.instances"]))
+            assert torch.equal(t["probabilities"], torch.from_numpy(g[f"{tag}.f{f}.probabilities"]))
+            rel_close(t["confidences"], g[f"{tag}.f{f}.confidences"], 1e-6, what="confidences")
+            assert torch.equal(t["mask"], torch.from_numpy(g[f"{tag}.f{f}.mask"]))
+        assert int((~sc.load_targets(int(g["invalid_frame"]))["mask"]).sum()) > 0

@@ -5,12 +5,13 @@ Tolerance (BASELINE.json north_star): 1e-3 relative, fp32.  ``rel_close`` assert
 Most checks pass a tighter rtol (stated per call).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, T, rel_close, grad_close
+from conftest import REPO, load_golden, T, rel_close, grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -605,6 +606,35 @@ def test_g13_assign_clusters_vs_reference():
         got = assign_clusters(feats, sems, cents, torch.device(DEV), num_images=n)
         assert tuple(got.shape) == tuple(want.shape)
         assert torch.equal(got.cpu().to(torch.float64), torch.from_numpy(want))
+
+
+def test_g14_mos_ray_tables_vs_reference_dataset(tmp_path):
+    """MOSScene.rays_for (clift_gen_rays on the device, from the per-frame intrinsics and normalised camera matrix) against
+    the ray table the REFERENCE's MOSDataset built for the same files (golden G14), native and resized image_dim; and the
+    flat training tables / instance images built from them."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+    from contrastive_lift_amd.data import MOSScene
+    g = load_golden("g14_mos_dataset")
+    root = gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
+                          invalid_frames=(int(g["invalid_frame"]),))
+    for tag in ("native", "resized"):
+        dim = tuple(int(x) for x in g[f"{tag}.dim"])
+        sc = MOSScene(root, "train", dim, float(g["max_depth"]), device=DEV)
+        for f in (int(x) for x in g["frames"]):
+            rays = sc.rays_for(f)
+            ref = g[f"{tag}.f{f}.rays"]
+            rel_close(rays[:, 0:3], ref[:, 0:3], 1e-5, atol=1e-6, what="origins")
+            rel_close(rays[:, 3:6], ref[:, 3:6], 1e-5, atol=1e-6, what="directions")
+            rel_close(rays[:, 6:8], ref[:, 6:8], 1e-4, what="near/far")
+        tabs = sc.build_train_tables()
+        hw = dim[0] * dim[1]
+        assert tabs["rays"].shape == (len(sc.train_indices) * hw, 8) and tabs["mask"].dtype == torch.bool
+        j = sc.train_indices.index(5)
+        rel_close(tabs["rays"][j * hw:(j + 1) * hw], g[f"{tag}.f5.rays"], 1e-4, atol=1e-6, what="table rays")
+        assert torch.equal(tabs["mask"][:hw].cpu(), torch.from_numpy(g[f"{tag}.f0.mask"]))
+        assert len(sc.instance_images) > 0 and all(int((im["instances"] == 0).sum()) == 0 for im in sc.instance_images)
 
 
 # ============================================================================ field point API + grid surgery (8f rank 1)

@@ -39,7 +39,7 @@ def look_at_cv(eye, target=(0, 0, 0), up=(0, 0, 1)):
     return np.stack([r, d, f], 1)
 
 
-def make_scene(out, n_frames=30, size=64, seed=0):
+def make_scene(out, n_frames=30, size=64, seed=0, invalid_frames=()):
     rng = np.random.default_rng(seed)
     for d in ("color", "detic_semantic", "detic_instance", "detic_probabilities", "semantic", "instance"):
         os.makedirs(os.path.join(out, d), exist_ok=True)
@@ -95,6 +95,13 @@ def make_scene(out, n_frames=30, size=64, seed=0):
     meta = {"camera": {"K": [[K[0, 0] / size, 0, K[0, 2] / size], [0, K[1, 1] / size, K[1, 2] / size], [0, 0, 1]],
                        "positions": positions, "quaternions": quats}}
     json.dump(meta, open(os.path.join(out, "metadata.json"), "w"))
+    # optional "invalid" room masks (MOS layout: invalid/<frame>.jpg, non-zero = pixel excluded): a rectangle per listed frame
+    if invalid_frames:
+        os.makedirs(os.path.join(out, "invalid"), exist_ok=True)
+        for f in invalid_frames:
+            m = np.zeros((size, size), np.uint8)
+            m[size // 4: size // 2, size // 3: (2 * size) // 3] = 255
+            Image.fromarray(m).save(os.path.join(out, "invalid", f"{f:04d}.jpg"), quality=95)
     return out
 
 
