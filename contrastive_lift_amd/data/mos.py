@@ -147,8 +147,10 @@ class MOSScene:
             sl = slice(j * hw, (j + 1) * hw)
             m = self.tables["instances"][sl] != 0
             if bool(m.any()):
+                # :242-258 -- pixels with a label, confidences of room-masked pixels forced to 0
+                conf = self.tables["confidences"][sl] * self.tables["mask"][sl].to(torch.float32)
                 self.instance_images.append(dict(rays=self.tables["rays"][sl][m], instances=self.tables["instances"][sl][m],
-                                                 confidences=self.tables["confidences"][sl][m]))
+                                                 confidences=conf[m]))
         return self.tables
 
     def pixel_batch(self, batch_size, generator=None):
