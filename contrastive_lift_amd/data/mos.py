@@ -66,7 +66,74 @@ def world_to_normscene(dims, intrinsics, cam2worlds, max_depth, rescale_factor=1
     return M
 
 
-class MOSScene:
+class SceneTables:
+    """What the readers share once cameras and per-frame targets exist: device-side ray tables, HBM-resident training
+    tables, pixel batches and per-image instance batches (reference: BaseDataset + Inconsistent*SingleDataset)."""
+
+    def __len__(self):
+        return len(self.train_indices if self.split == "train" else self.val_indices)
+
+    def frame_index(self, i):
+        return (self.train_indices if self.split == "train" else self.val_indices)[i]
+
+    def rays_for(self, sample_index):
+        H, W = self.image_dim
+        return generate_ray_table(H, W, self.intrinsics[sample_index], self.cam2normscene[sample_index], near=0.01, device=self.device)
+
+    def build_train_tables(self):
+        """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
+        rays, tg = [], []
+        for i in self.train_indices:
+            rays.append(self.rays_for(i))
+            tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items()})
+        self.tables = dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]})
+        hw = self.image_dim[0] * self.image_dim[1]
+        self.instance_images = []
+        for j in range(len(self.train_indices)):
+            sl = slice(j * hw, (j + 1) * hw)
+            m = self.tables["instances"][sl] != 0
+            if bool(m.any()):
+                # many_object_scenes.py:242-258 / panopli.py:211-238: pixels with a label, confidences of room-masked pixels forced to 0
+                conf = self.tables["confidences"][sl] * self.tables["mask"][sl].to(torch.float32)
+                self.instance_images.append(dict(rays=self.tables["rays"][sl][m], instances=self.tables["instances"][sl][m],
+                                                 confidences=conf[m]))
+        return self.tables
+
+    def pixel_batch(self, batch_size, generator=None):
+        n = self.tables["rays"].shape[0]
+        idx = torch.randint(0, n, (batch_size,), device=self.device, generator=generator)
+        return {k: v[idx] for k, v in self.tables.items()}
+
+    def instance_batch(self, max_rays, image_index):
+        img = self.instance_images[image_index % len(self.instance_images)]
+        n = img["rays"].shape[0]
+        if n > max_rays:
+            sel = torch.randperm(n, device=self.device)[:max_rays]
+            img = {k: v[sel] for k, v in img.items()}
+        return [dict(rays=img["rays"].contiguous(), instances=img["instances"], confidences=img["confidences"].contiguous())]
+
+    def _finish_cameras(self, K, poses, img_h, img_w, max_depth):
+        """Shared tail of setup_data: frustum-sphere normalisation, per-frame scaled intrinsics and normalised cameras."""
+        n = len(poses)
+        idx = list(range(n))
+        self.scene2normscene = world_to_normscene([[img_h, img_w]] * n, [K] * n, poses, max_depth, 1.0)
+        self.normscene_scale = float(self.scene2normscene[0, 0])
+        scale = np.diag([self.image_dim[1] / img_w, self.image_dim[0] / img_h, 1.0])
+        self.intrinsics = {i: torch.from_numpy(scale @ K).float() for i in idx}
+        self.cam2normscene = {i: torch.from_numpy(self.scene2normscene @ poses[i]).float() for i in idx}
+        self.scene_bounds = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+        self.white_bg = False
+
+    def _room_mask(self, name):
+        """invalid/<frame>.jpg, non-zero = pixel excluded (True in the returned mask = pixel is used)."""
+        H, W = self.image_dim
+        mpath = os.path.join(self.root, "invalid", f"{name}.jpg")
+        if os.path.exists(mpath):
+            return ~torch.from_numpy(np.array(Image.open(mpath).resize((W, H), Image.NEAREST)) > 0).bool().reshape(-1)
+        return torch.ones(H * W, dtype=torch.bool)
+
+
+class MOSScene(SceneTables):
     def __init__(self, root_dir, split, image_dim, max_depth, subsample_frames=1, device="cuda",
                  semantics_dir="detic_semantic", instance_dir="detic_instance"):
         self.root = str(root_dir)
@@ -85,25 +152,9 @@ class MOSScene:
         img_h, img_w = img.shape[:2]
         meta = json.load(open(os.path.join(self.root, "metadata.json")))
         K, poses = read_cameras(meta, img_h, img_w)
-        self.scene2normscene = world_to_normscene([[img_h, img_w]] * n, [K] * n, poses, max_depth, 1.0)
-        self.normscene_scale = float(self.scene2normscene[0, 0])
-        scale = np.diag([self.image_dim[1] / img_w, self.image_dim[0] / img_h, 1.0])
-        self.intrinsics = {i: torch.from_numpy(scale @ K).float() for i in idx}
-        self.cam2normscene = {i: torch.from_numpy(self.scene2normscene @ poses[i]).float() for i in idx}
-        self.scene_bounds = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
-        self.white_bg = False
+        self._finish_cameras(K, poses, img_h, img_w, max_depth)
         self.segmentation_data = type("Seg", (), dict(fg_classes=[1], bg_classes=[0], num_semantic_classes=2, num_instances=1))()
         self.num_semantics = 2
-
-    def __len__(self):
-        return len(self.train_indices if self.split == "train" else self.val_indices)
-
-    def frame_index(self, i):
-        return (self.train_indices if self.split == "train" else self.val_indices)[i]
-
-    def rays_for(self, sample_index):
-        H, W = self.image_dim
-        return generate_ray_table(H, W, self.intrinsics[sample_index], self.cam2normscene[sample_index], near=0.01, device=self.device)
 
     def load_targets(self, sample_index):
         """:146-207 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,2), confidences (HW,)."""
@@ -126,42 +177,6 @@ class MOSScene:
         conf_t = torch.nn.functional.interpolate(torch.from_numpy(conf).float()[None, None], size=(W, H), mode="bilinear",
                                                  align_corners=False)[0, 0]
         probs = torch.nn.functional.one_hot(sem_t, num_classes=self.num_semantics).float()
-        mpath = os.path.join(self.root, "invalid", f"{name}.jpg")              # :196-200 room mask (True = pixel is used)
-        if os.path.exists(mpath):
-            mask = ~torch.from_numpy(np.array(Image.open(mpath).resize((W, H), Image.NEAREST)) > 0).bool().reshape(-1)
-        else:
-            mask = torch.ones(H * W, dtype=torch.bool)
+        mask = self._room_mask(name)
         return dict(rgbs=rgb.reshape(-1, 3), semantics=sem_t.reshape(-1), instances=inst_t.reshape(-1),
                     probabilities=probs.reshape(-1, self.num_semantics), confidences=conf_t.reshape(-1), mask=mask)
-
-    def build_train_tables(self):
-        """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
-        rays, tg = [], []
-        for i in self.train_indices:
-            rays.append(self.rays_for(i))
-            tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items()})
-        self.tables = dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]})
-        hw = self.image_dim[0] * self.image_dim[1]
-        self.instance_images = []
-        for j in range(len(self.train_indices)):
-            sl = slice(j * hw, (j + 1) * hw)
-            m = self.tables["instances"][sl] != 0
-            if bool(m.any()):
-                # :242-258 -- pixels with a label, confidences of room-masked pixels forced to 0
-                conf = self.tables["confidences"][sl] * self.tables["mask"][sl].to(torch.float32)
-                self.instance_images.append(dict(rays=self.tables["rays"][sl][m], instances=self.tables["instances"][sl][m],
-                                                 confidences=conf[m]))
-        return self.tables
-
-    def pixel_batch(self, batch_size, generator=None):
-        n = self.tables["rays"].shape[0]
-        idx = torch.randint(0, n, (batch_size,), device=self.device, generator=generator)
-        return {k: v[idx] for k, v in self.tables.items()}
-
-    def instance_batch(self, max_rays, image_index):
-        img = self.instance_images[image_index % len(self.instance_images)]
-        n = img["rays"].shape[0]
-        if n > max_rays:
-            sel = torch.randperm(n, device=self.device)[:max_rays]
-            img = {k: v[sel] for k, v in img.items()}
-        return [dict(rays=img["rays"].contiguous(), instances=img["instances"], confidences=img["confidences"].contiguous())]

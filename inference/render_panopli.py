@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import contrastive_lift_amd as cl                                   # noqa: E402
 from contrastive_lift_amd import inference as inf                    # noqa: E402
 from contrastive_lift_amd.config import load_run_config              # noqa: E402
-from contrastive_lift_amd.data import MOSScene                       # noqa: E402
+from contrastive_lift_amd.data import get_scene                       # noqa: E402
 
 
 def strip_prefix(state_dict, key):
@@ -99,9 +99,7 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
         dist.init_process_group(os.environ.get("CLIFT_DIST_BACKEND", "nccl"))
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = torch.device(device)
-    if config.dataset_class != "mos":
-        raise NotImplementedError("only the MOS (Messy-Rooms) on-disk layout is wired in this round (SURVEY 8f rank 4)")
-    scene = MOSScene(config.dataset_root, "test", config.image_dim, config.max_depth, subsample_frames=config.subsample_frames, device=device)
+    scene = get_scene(config, "test", device)
     H, W = scene.image_dim
     model, renderer, _ = build_from_checkpoint(config, scene, device)
     renderer.update_step_ratio(renderer.step_ratio * 0.5)                                    # RP:104

@@ -645,6 +645,46 @@ def g14_mos_dataset():
     npz("g14_mos_dataset", **out)
 
 
+def g15_panopli_dataset():
+    """The reference's PanopLiDataset (dataset/panopli.py:42-198 with the label directories of dataset/__init__.py:14) run on a
+    scene written by tools/make_synthetic_panopli.py: splits.json handling (train / val / test), text intrinsics and poses,
+    scene normalisation, jpg / png / npz targets with the joint probability+confidence resize, segmentation_data.pkl."""
+    import pathlib
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_panopli as gen
+    tmp = tempfile.mkdtemp(prefix="g15_")
+    root = gen.make_scene(os.path.join(tmp, "scene"), n_frames=10, size=24, seed=5, invalid_frames=(1,))
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from dataset.panopli import PanopLiDataset, create_segmentation_data_panopli
+        out = dict(n_frames=10, size=24, seed=5, invalid_frame=1, max_depth=3.0, frames=np.array([1, 6]))
+        for tag, dim in (("native", (24, 24)), ("resized", (16, 20))):
+            with quiet():
+                ds = PanopLiDataset(pathlib.Path(root), "train", dim, 3.0, semantics_dir="m2f_semantics", instance_dir="m2f_instance",
+                                    instance_to_semantic_key="m2f_instance_to_semantic", create_seg_data_func=create_segmentation_data_panopli)
+                dt = PanopLiDataset(pathlib.Path(root), "test", dim, 3.0, semantics_dir="m2f_semantics", instance_dir="m2f_instance",
+                                    instance_to_semantic_key="m2f_instance_to_semantic", create_seg_data_func=create_segmentation_data_panopli)
+            hw = dim[0] * dim[1]
+            sd = ds.segmentation_data
+            out.update({f"{tag}.dim": np.array(dim), f"{tag}.train_indices": np.array(ds.train_indices), f"{tag}.val_indices": np.array(ds.val_indices),
+                        f"{tag}.test_val_indices": np.array(dt.val_indices), f"{tag}.scene2normscene": ds.scene2normscene,
+                        f"{tag}.fg": np.array(sd.fg_classes), f"{tag}.bg": np.array(sd.bg_classes), f"{tag}.num_classes": sd.num_semantic_classes,
+                        f"{tag}.num_instances": sd.num_instances,
+                        f"{tag}.i2s": np.array(sorted(sd.instance_to_semantics.items()))})
+            for f in (1, 6):
+                j = ds.train_indices.index(f)
+                sl = slice(j * hw, (j + 1) * hw)
+                out.update({f"{tag}.f{f}.K": ds.intrinsics[f], f"{tag}.f{f}.cam2normscene": ds.cam2normscene[f],
+                            f"{tag}.f{f}.rays": ds.all_rays[sl], f"{tag}.f{f}.rgbs": ds.all_rgbs[sl], f"{tag}.f{f}.semantics": ds.all_semantics[sl],
+                            f"{tag}.f{f}.instances": ds.all_instances[sl], f"{tag}.f{f}.probabilities": ds.all_probabilities[sl],
+                            f"{tag}.f{f}.confidences": ds.all_confidences[sl], f"{tag}.f{f}.mask": ds.all_masks[sl]})
+    finally:
+        os.chdir(cwd)
+    npz("g15_panopli_dataset", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -664,6 +704,7 @@ def main():
     g12_training_steps()
     g13_postprocess()
     g14_mos_dataset()
+    g15_panopli_dataset()
 
 
 if __name__ == "__main__":

@@ -81,3 +81,37 @@ def test_g14_mos_reader_vs_reference_dataset(tmp_path):
             rel_close(t["confidences"], g[f"{tag}.f{f}.confidences"], 1e-6, what="confidences")
             assert torch.equal(t["mask"], torch.from_numpy(g[f"{tag}.f{f}.mask"]))
         assert int((~sc.load_targets(int(g["invalid_frame"]))["mask"]).sum()) > 0
+
+
+def test_g15_panopli_reader_vs_reference_dataset(tmp_path):
+    """PanopLiScene against the REFERENCE's PanopLiDataset run on the same files (golden G15): splits.json handling, text
+    intrinsics / poses, scene normalisation, segmentation data, and every per-pixel target table (jpg LANCZOS resize, png NEAREST
+    labels, jointly resized probabilities + confidences, room mask) -- native and resized image_dim."""
+    import torch
+    from conftest import load_golden, rel_close
+    import make_synthetic_panopli as gen
+    from contrastive_lift_amd.data import PanopLiScene
+    g = load_golden("g15_panopli_dataset")
+    root = gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
+                          invalid_frames=(int(g["invalid_frame"]),))
+    for tag in ("native", "resized"):
+        dim = tuple(int(x) for x in g[f"{tag}.dim"])
+        sc = PanopLiScene(root, "train", dim, float(g["max_depth"]), device="cpu")
+        st = PanopLiScene(root, "test", dim, float(g["max_depth"]), device="cpu")
+        assert sc.train_indices == list(g[f"{tag}.train_indices"]) and sc.val_indices == list(g[f"{tag}.val_indices"])
+        assert st.val_indices == list(g[f"{tag}.test_val_indices"])
+        sd = sc.segmentation_data
+        assert sd.fg_classes == list(g[f"{tag}.fg"]) and sd.bg_classes == list(g[f"{tag}.bg"])
+        assert sd.num_semantic_classes == int(g[f"{tag}.num_classes"]) and sd.num_instances == int(g[f"{tag}.num_instances"])
+        assert sorted(sd.instance_to_semantics.items()) == [tuple(x) for x in g[f"{tag}.i2s"].tolist()]
+        rel_close(torch.from_numpy(sc.scene2normscene).float(), g[f"{tag}.scene2normscene"], 1e-5, atol=1e-6, what="scene2normscene")
+        for f in (int(x) for x in g["frames"]):
+            rel_close(sc.intrinsics[f], g[f"{tag}.f{f}.K"], 1e-6, what="K")
+            rel_close(sc.cam2normscene[f], g[f"{tag}.f{f}.cam2normscene"], 1e-5, atol=1e-6, what="cam2normscene")
+            t = sc.load_targets(f)
+            rel_close(t["rgbs"], g[f"{tag}.f{f}.rgbs"], 1e-6, what="rgbs")
+            assert torch.equal(t["semantics"], torch.from_numpy(g[f"{tag}.f{f}.semantics"]))
+            assert torch.equal(t["instances"], torch.from_numpy(g[f"{tag}.f{f}.instances"]))
+            rel_close(t["probabilities"], g[f"{tag}.f{f}.probabilities"], 1e-6, atol=1e-8, what="probabilities")
+            rel_close(t["confidences"], g[f"{tag}.f{f}.confidences"], 1e-6, what="confidences")
+            assert torch.equal(t["mask"], torch.from_numpy(g[f"{tag}.f{f}.mask"]))

@@ -82,3 +82,43 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
     iou, pq, sq, rq = ev.evaluate_mos(str(out), scene_dir, (64, 64))
     print("scene mIoU", iou, "PQ_scene", pq, "SQ", sq, "RQ", rq)
     assert 0.5 < iou <= 1.0 and 0.0 <= pq <= 1.0 and 0.0 <= sq <= 1.0 and 0.0 <= rq <= 1.0
+
+
+def test_train_cli_on_panopli_layout(tmp_path, monkeypatch):
+    """The train and render CLIs on a PanopLi-layout scene (dataset_class: panopli -- the default experiment config): five semantic
+    classes with three thing classes, jpg / png / npz inputs, splits.json; short run, then the checkpoint renders."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_panopli as gen
+    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_panopli"), n_frames=40, size=48)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("experiment", "e2e_panopli")
+    train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli_p")
+    run_dir = train.main(["+experiment=contrastive_lift", f"dataset_root={scene_dir}", "image_dim=48", "min_grid_dim=32", "max_grid_dim=48",
+                          "max_epoch=6", "steps_per_epoch=400", "batch_size=2048", "chunk=0", "max_depth=3", "seed=3", "max_rays_instances=256",
+                          "decay_step=[4,5]", "late_semantic_optimization=0", "instance_optimization_epoch=1"])
+    ckpts = sorted(os.listdir(os.path.join(run_dir, "checkpoints")))
+    ck = torch.load(os.path.join(run_dir, "checkpoints", ckpts[-1]), map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    assert sd["model.render_semantic_mlp.mlp.8.weight"].shape[0] == 5 and sd["loss_semantics.weight"].shape == (5,)
+    rp = _load(os.path.join(REPO, "inference", "render_panopli.py"), "clift_render_cli_p")
+    from contrastive_lift_amd.config import load_run_config
+    cfg = load_run_config(os.path.join(run_dir, "config.yaml"))
+    cfg.resume = os.path.join(run_dir, "checkpoints", ckpts[-1])
+    cfg.image_dim = [48, 48]
+    cents = {c: np.random.default_rng(c).standard_normal((2, 3)).astype(np.float32) for c in (2, 3, 4)}
+    cpath = str(tmp_path / "cents.pkl")
+    pickle.dump(cents, open(cpath, "wb"))
+    out = rp.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, cached_centroids_path=cpath)
+    names = sorted(os.listdir(out / "pred_semantics"))
+    assert len(names) == 8
+    from PIL import Image
+    sem = np.array(Image.open(out / "pred_semantics" / names[0]))
+    assert sem.shape == (48, 48) and int(sem.max()) <= 4
+    # semantic accuracy of the fit on a held-out view (labels of the test split)
+    from contrastive_lift_amd.data import PanopLiScene
+    sc = PanopLiScene(scene_dir, "test", (48, 48), 3, device="cpu")
+    gt = sc.load_targets(sc.val_indices[0])["semantics"].reshape(48, 48).numpy()
+    valid = gt != 0              # class 0 carries zero loss weight (weight_class_0: 0 in the template): its pixels are unconstrained
+    acc = float((sem == gt)[valid].mean())
+    print("PanopLi-layout held-out semantic accuracy on labelled pixels", acc, "of", int(valid.sum()))
+    assert acc > 0.6, acc

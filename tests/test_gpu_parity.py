@@ -637,6 +637,28 @@ def test_g14_mos_ray_tables_vs_reference_dataset(tmp_path):
         assert len(sc.instance_images) > 0 and all(int((im["instances"] == 0).sum()) == 0 for im in sc.instance_images)
 
 
+def test_g15_panopli_ray_tables_vs_reference_dataset(tmp_path):
+    """PanopLiScene.rays_for (device ray generation) against the ray tables of the REFERENCE's PanopLiDataset (golden G15)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_panopli as gen
+    from contrastive_lift_amd.data import PanopLiScene
+    g = load_golden("g15_panopli_dataset")
+    root = gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
+                          invalid_frames=(int(g["invalid_frame"]),))
+    for tag in ("native", "resized"):
+        dim = tuple(int(x) for x in g[f"{tag}.dim"])
+        sc = PanopLiScene(root, "train", dim, float(g["max_depth"]), device=DEV)
+        for f in (int(x) for x in g["frames"]):
+            rays = sc.rays_for(f)
+            ref = g[f"{tag}.f{f}.rays"]
+            rel_close(rays[:, 0:3], ref[:, 0:3], 1e-5, atol=1e-6, what="origins")
+            rel_close(rays[:, 3:6], ref[:, 3:6], 1e-5, atol=1e-6, what="directions")
+            rel_close(rays[:, 6:8], ref[:, 6:8], 1e-4, what="near/far")
+        tabs = sc.build_train_tables()
+        assert tabs["probabilities"].shape[1] == int(g[f"{tag}.num_classes"]) and len(sc.instance_images) > 0
+
+
 # ============================================================================ field point API + grid surgery (8f rank 1)
 def test_field_point_api_golden_g3():
     cl, op, *_ = _import()

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import contrastive_lift_amd as cl                                        # noqa: E402
 from contrastive_lift_amd.config import load_config, save_config          # noqa: E402
-from contrastive_lift_amd.data import MOSScene                            # noqa: E402
+from contrastive_lift_amd.data import get_scene                            # noqa: E402
 from contrastive_lift_amd.inference import psnr                           # noqa: E402
 from contrastive_lift_amd.trainer import HotPathTrainer                   # noqa: E402
 
@@ -60,12 +60,10 @@ def main(argv):
     torch.manual_seed(seed)                                                # identical initial weights on every rank
     cfg.instance_optimization_epoch = cfg.instance_optimization_epoch + cfg.late_semantic_optimization     # T:46
     cfg.segment_optimization_epoch = cfg.segment_optimization_epoch + cfg.late_semantic_optimization       # T:47
-    if cfg.dataset_class != "mos":
-        raise NotImplementedError("only the MOS (Messy-Rooms) on-disk layout is wired in this round (SURVEY 8f rank 4)")
-    scene = MOSScene(cfg.dataset_root, "train", cfg.image_dim, cfg.max_depth, subsample_frames=cfg.subsample_frames, device=dev)
+    scene = get_scene(cfg, "train", dev)
     scene.build_train_tables()
-    val = MOSScene(cfg.dataset_root, "val", cfg.image_dim, cfg.max_depth, subsample_frames=cfg.subsample_frames, device=dev)
-    total_classes = 2
+    val = get_scene(cfg, "val", dev)
+    total_classes = len(scene.segmentation_data.bg_classes) + len(scene.segmentation_data.fg_classes)      # T:51
     slow_fast = cfg.instance_loss_mode == "slow_fast"
     g = int(cfg.min_grid_dim)
     model = cl.TensorVMSplit([g, g, g], num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=total_classes,
@@ -75,7 +73,9 @@ def main(argv):
                              pe_sem=cfg.pe_sem, pe_ins=cfg.pe_ins, slow_fast_mode=slow_fast, use_proj=cfg.use_proj, device=dev)
     renderer = cl.TensoRFRenderer(scene.scene_bounds, [g, g, g], semantic_weight_mode=cfg.semantic_weight_mode,
                                   stop_semantic_grad=cfg.stop_semantic_grad).to(dev)
-    cw = torch.ones(total_classes)
+    cw = torch.ones(total_classes)                                         # loss.py:29-33 get_semantic_weights + T:70
+    if getattr(cfg, "reweight_fg", False):
+        cw[list(scene.segmentation_data.fg_classes)] = 2
     cw[0] = cfg.weight_class_0
     tr = HotPathTrainer(model, renderer, cfg, class_weights=cw, current_epoch=0)
     run_dir = Path("runs") / cfg.experiment
