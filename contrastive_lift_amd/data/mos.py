@@ -80,6 +80,19 @@ class SceneTables:
         H, W = self.image_dim
         return generate_ray_table(H, W, self.intrinsics[sample_index], self.cam2normscene[sample_index], near=0.01, device=self.device)
 
+    def trajectory_set(self, trajectory_name):
+        """dataset/base.py:320-365 (get_trajectory_set(name, norm_scene=True) -> MainerTrajectoryDataset): the camera-to-scene
+        matrices pickled in ``trajectories/<name>.pkl`` mapped into the normalised scene; every frame uses the intrinsics of
+        frame 0 and is named by its index.  Returns [(name, rays (H*W, 8))] lazily generated on the device."""
+        import pickle
+        with open(os.path.join(self.root, "trajectories", f"{trajectory_name}.pkl"), "rb") as f:
+            poses = pickle.load(f)
+        H, W = self.image_dim
+        s2n = torch.from_numpy(np.asarray(self.scene2normscene)).float()
+        for idx, pose in enumerate(poses):
+            c2n = s2n @ torch.from_numpy(np.asarray(pose)).float()
+            yield f"{idx:04d}", generate_ray_table(H, W, self.intrinsics[0], c2n, near=0.01, device=self.device)
+
     def build_train_tables(self):
         """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
         rays, tg = [], []

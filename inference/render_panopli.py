@@ -84,8 +84,6 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
     if use_dbscan or segmentwise:
         raise NotImplementedError("HDBSCAN / segment-wise clustering are CPU post-processing variants not built here "
                                   "(hdbscan is absent from this image); use MeanShift or --cached_centroids_path")
-    if not test_only:
-        raise NotImplementedError("trajectory rendering needs the scene's trajectory_blender poses; only the test split is wired")
     out = output_dirname(config, trajectory_name, test_only, use_dbscan, segmentwise)
     out.mkdir(exist_ok=True, parents=True)
     # launched under torch.distributed.run: one process per GPU, every frame rendered as row-tiles (one per rank) and
@@ -105,11 +103,18 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
     renderer.update_step_ratio(renderer.step_ratio * 0.5)                                    # RP:104
     fg = scene.segmentation_data.fg_classes
     rgbs, sems, depths, inst_feats, thing_feats, slow_feats = [], [], [], [], [], []
+    # RP:67-72: the test split, or the predefined trajectory trajectories/<trajectory_name>.pkl (frames named by index, all
+    # with the intrinsics of frame 0)
+    if test_only:
+        frames = ((scene.all_frame_names[i], scene.rays_for(i), scene.intrinsics[i]) for i in scene.val_indices)
+    else:
+        frames = ((n, r, scene.intrinsics[0]) for n, r in scene.trajectory_set(trajectory_name))
+    names = []
     with torch.no_grad():
-        for i in scene.val_indices:
-            rays = scene.rays_for(i)
+        for name, rays, K_frame in frames:
+            names.append(name)
             p_rgb, p_sem, p_inst, p_dist = inf.render_rays_sharded(model, renderer, rays, int(config.chunk), scene.white_bg)
-            depths.append(inf.distance_to_depth(scene.intrinsics[i], p_dist.view(H, W)))
+            depths.append(inf.distance_to_depth(K_frame, p_dist.view(H, W)))
             if config.use_delta:
                 p_inst = p_inst + (rays[:, 0:3] + p_dist[:, None] * rays[:, 3:6])
             if model.slow_fast_mode:
@@ -134,8 +139,8 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
         insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs))
     for d in ("vis_semantics_and_surrogate", "pred_semantics", "pred_surrogateid"):
         (out / d).mkdir(exist_ok=True)
-    for j, idx in enumerate(scene.val_indices):
-        name = f"{scene.all_frame_names[idx]}.png"
+    for j, frame_name in enumerate(names):
+        name = f"{frame_name}.png"
         sem_id = sems[j].argmax(dim=1).reshape(H, W).cpu().numpy()
         sur_id = insts[j].argmax(dim=1).reshape(H, W).cpu().numpy()
         Image.fromarray(sem_id.astype(np.uint8)).save(out / "pred_semantics" / name)

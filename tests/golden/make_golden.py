@@ -619,7 +619,7 @@ def g14_mos_dataset():
     sys.modules["pyquaternion"].Quaternion = Quaternion
     import tempfile
     tmp = tempfile.mkdtemp(prefix="g14_")
-    scene_args = dict(n_frames=10, size=24, seed=7, invalid_frames=(0,))
+    scene_args = dict(n_frames=10, size=24, seed=7, invalid_frames=(0,), trajectory_frames=4)
     root = gen.make_scene(os.path.join(tmp, "scene"), **scene_args)
     cwd = os.getcwd()
     os.chdir(REF)                               # the reference reads resources/*.csv relative to its checkout
@@ -640,6 +640,13 @@ def g14_mos_dataset():
                             f"{tag}.f{f}.rays": ds.all_rays[sl], f"{tag}.f{f}.rgbs": ds.all_rgbs[sl], f"{tag}.f{f}.semantics": ds.all_semantics[sl],
                             f"{tag}.f{f}.instances": ds.all_instances[sl], f"{tag}.f{f}.probabilities": ds.all_probabilities[sl],
                             f"{tag}.f{f}.confidences": ds.all_confidences[sl], f"{tag}.f{f}.mask": ds.all_masks[sl]})
+            # predefined camera path (dataset/base.py:320-365, as inference/render_panopli.py:71 requests it)
+            ts = ds.get_trajectory_set("trajectory_blender", True)
+            out[f"{tag}.traj.len"] = len(ts)
+            for j in (0, 3):
+                item = ts[j]
+                out[f"{tag}.traj.{j}.name"] = np.array(item["name"])
+                out[f"{tag}.traj.{j}.rays"] = item["rays"]
     finally:
         os.chdir(cwd)
     npz("g14_mos_dataset", **out)

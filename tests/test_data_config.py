@@ -50,7 +50,7 @@ def _g14_scene(tmp_path, g):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
     return gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
-                          invalid_frames=(int(g["invalid_frame"]),))
+                          invalid_frames=(int(g["invalid_frame"]),), trajectory_frames=4)
 
 
 def test_g14_mos_reader_vs_reference_dataset(tmp_path):

@@ -25,7 +25,7 @@ def _load(path, name):
 def test_train_checkpoint_render(tmp_path, monkeypatch):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
-    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=40, size=64)
+    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=40, size=64, trajectory_frames=3)
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("experiment", "e2e_test")
     train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli")
@@ -57,6 +57,9 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
     feats = np.load(out / "instance_features.npy")
     assert feats.shape == (4 * 64 * 64, 3) and np.isfinite(feats).all()
     assert np.load(out / "slow_features.npy").shape == feats.shape
+    # predefined camera path (--render_trajectory): frames named by index
+    out_t = rp.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=False, cached_centroids_path=cpath)
+    assert sorted(os.listdir(out_t / "pred_semantics")) == ["0000.png", "0001.png", "0002.png"] and "trajectory_blender" in str(out_t)
     thing = np.load(out / "thing_features.npy")
     assert thing.shape == (4 * 64 * 64, 4) and set(np.unique(np.isinf(thing[:, 0]))) == {True}
     from PIL import Image

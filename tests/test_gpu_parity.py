@@ -618,10 +618,18 @@ def test_g14_mos_ray_tables_vs_reference_dataset(tmp_path):
     from contrastive_lift_amd.data import MOSScene
     g = load_golden("g14_mos_dataset")
     root = gen.make_scene(str(tmp_path / "scene"), n_frames=int(g["n_frames"]), size=int(g["size"]), seed=int(g["seed"]),
-                          invalid_frames=(int(g["invalid_frame"]),))
+                          invalid_frames=(int(g["invalid_frame"]),), trajectory_frames=4)
     for tag in ("native", "resized"):
         dim = tuple(int(x) for x in g[f"{tag}.dim"])
         sc = MOSScene(root, "train", dim, float(g["max_depth"]), device=DEV)
+        traj = list(sc.trajectory_set("trajectory_blender"))          # predefined camera path (dataset/base.py:320-365)
+        assert len(traj) == int(g[f"{tag}.traj.len"])
+        for j in (0, 3):
+            name, rays = traj[j]
+            assert name == str(g[f"{tag}.traj.{j}.name"])
+            ref = g[f"{tag}.traj.{j}.rays"]
+            rel_close(rays[:, 0:6], ref[:, 0:6], 1e-5, atol=1e-6, what="trajectory rays")
+            rel_close(rays[:, 6:8], ref[:, 6:8], 1e-4, what="trajectory near/far")
         for f in (int(x) for x in g["frames"]):
             rays = sc.rays_for(f)
             ref = g[f"{tag}.f{f}.rays"]

@@ -39,7 +39,7 @@ def look_at_cv(eye, target=(0, 0, 0), up=(0, 0, 1)):
     return np.stack([r, d, f], 1)
 
 
-def make_scene(out, n_frames=30, size=64, seed=0, invalid_frames=()):
+def make_scene(out, n_frames=30, size=64, seed=0, invalid_frames=(), trajectory_frames=0):
     rng = np.random.default_rng(seed)
     for d in ("color", "detic_semantic", "detic_instance", "detic_probabilities", "semantic", "instance"):
         os.makedirs(os.path.join(out, d), exist_ok=True)
@@ -95,6 +95,19 @@ def make_scene(out, n_frames=30, size=64, seed=0, invalid_frames=()):
     meta = {"camera": {"K": [[K[0, 0] / size, 0, K[0, 2] / size], [0, K[1, 1] / size, K[1, 2] / size], [0, 0, 1]],
                        "positions": positions, "quaternions": quats}}
     json.dump(meta, open(os.path.join(out, "metadata.json"), "w"))
+    # optional predefined camera path (MOS / PanopLi layout: trajectories/trajectory_blender.pkl = list of 4x4 camera-to-scene
+    # matrices, OpenCV axes): an orbit at fixed elevation
+    if trajectory_frames:
+        import pickle
+        os.makedirs(os.path.join(out, "trajectories"), exist_ok=True)
+        traj = []
+        for j in range(trajectory_frames):
+            az = 2 * np.pi * j / trajectory_frames
+            eye = 3.0 * np.array([np.cos(az) * np.cos(0.6), np.sin(az) * np.cos(0.6), np.sin(0.6)])
+            P = np.eye(4)
+            P[:3, :3], P[:3, 3] = look_at_cv(eye, target=(0, 0, 0.25)), eye
+            traj.append(P)
+        pickle.dump(traj, open(os.path.join(out, "trajectories", "trajectory_blender.pkl"), "wb"))
     # optional "invalid" room masks (MOS layout: invalid/<frame>.jpg, non-zero = pixel excluded): a rectangle per listed frame
     if invalid_frames:
         os.makedirs(os.path.join(out, "invalid"), exist_ok=True)
