@@ -23,7 +23,7 @@ class _Scaled(torch.autograd.Function):
         return g * grad, None, None
 
 
-def contrastive_loss(features, instance_labels, temperature):
+def contrastive_loss(features, instance_labels, temperature, return_grad=False):
     """loss.py:62-82.  features (B,E) float32 cuda, instance_labels (B,) integer."""
     f = _lib.f32(features, "features").contiguous()
     B, E = f.shape
@@ -33,6 +33,8 @@ def contrastive_loss(features, instance_labels, temperature):
     work = torch.empty((max(4 * B, 4),), dtype=torch.float32, device=f.device)
     _lib.call("clift_contrastive", _lib.ptr(f), _lib.ptr(y), B, E, float(temperature), _lib.ptr(loss), _lib.ptr(grad),
               _lib.ptr(work), _lib.stream())
+    if return_grad:
+        return loss[0], grad
     return _Scaled.apply(features, loss[0], grad)
 
 

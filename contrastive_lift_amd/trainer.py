@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, engine
-from .loss import slow_fast_loss
+from .loss import contrastive_loss, slow_fast_loss
 
 
 def default_config(**over):
@@ -142,23 +142,35 @@ class HotPathTrainer:
     def instance_pass(self, inst_batch, jitter=None):
         """inst_batch: list of dicts (one per image) with rays (n,8), instances (n,) int, confidences (n,)."""
         c, m, r = self.config, self.model, self.renderer
-        if c.instance_loss_mode != "slow_fast":
-            raise NotImplementedError("HotPathTrainer: only instance_loss_mode='slow_fast' is wired (contrastive via "
-                                      "contrastive_lift_amd.contrastive_loss)")
+        if c.instance_loss_mode not in ("slow_fast", "contrastive"):
+            raise NotImplementedError(f"HotPathTrainer: instance_loss_mode={c.instance_loss_mode!r} is not wired (slow_fast and "
+                                      "contrastive are; linear_assignment / ae_loss are the Panoptic-Lifting baselines)")
         m.grad_flat[self.inst_range[0]:self.inst_range[1]].zero_()
         gv = m.named_grad_views()
         for img in inst_batch:
             rays = img["rays"]
             n = rays.shape[0]
             jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
-            # reference order: render the features (fast and slow halves) first (T:214), THEN the EMA step of the slow net at
-            # the top of the loss (T:258-259) -- the slow features of this step come from the pre-update weights (golden G12).
-            # One fused axpy over the contiguous fast/slow arena ranges; stream order keeps it behind the forward's reads.
             (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance")
-            f0, f1 = m.arena.range_of("inst_fast")
-            s0, s1 = m.arena.range_of("inst_slow")
-            _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
-            loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
+            if c.instance_loss_mode == "slow_fast":
+                # reference order: the features (fast and slow halves) are rendered first (T:214), THEN the EMA step of the slow
+                # net at the top of the loss (T:258-259) -- the slow features of this step come from the pre-update weights
+                # (golden G12).  One fused axpy over the contiguous fast/slow arena ranges; stream order keeps it behind the
+                # forward's reads.
+                f0, f1 = m.arena.range_of("inst_fast")
+                s0, s1 = m.arena.range_of("inst_slow")
+                _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
+                loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
+            else:                                   # T:243-250: plain contrastive loss, optionally on points + features ("delta")
+                use_delta = bool(getattr(c, "use_delta", False))
+                if use_delta:
+                    assert inst.shape[-1] == 3, "delta mode only works with 3D features"
+                feats = xyz + inst if use_delta else inst
+                loss, g_inst = contrastive_loss(feats, img["instances"], c.temperature, return_grad=True)
+                if use_delta:                       # + 0.1 * mean ||delta||
+                    nrm = torch.linalg.norm(inst, dim=-1, keepdim=True)
+                    loss = loss + 0.1 * nrm.mean()
+                    g_inst = g_inst + 0.1 * inst / (nrm.clamp_min(1e-30) * inst.shape[0])
             self.losses[3] = self.losses[3] + loss
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
         self._allreduce(self.inst_range)

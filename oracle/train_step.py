@@ -18,9 +18,11 @@ GRID_KEYS = ("density_plane", "density_line", "appearance_plane", "appearance_li
 
 class CpuTrainer:
     def __init__(self, P, cfg, lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
-                 lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True):
+                 lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True,
+                 instance_loss_mode="slow_fast", temperature=100.0, use_delta=False):
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
         self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
+        self.inst_mode, self.temperature, self.use_delta = instance_loss_mode, temperature, use_delta
         self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
         self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
         grids = [v for k, v in self.P.items() if k.startswith(GRID_KEYS)]
@@ -64,8 +66,14 @@ class CpuTrainer:
         # order of the reference: the features (fast AND slow halves) are rendered first (T:214), the EMA step of the slow
         # net happens at the top of the loss (T:258-259) -- so the slow features of step t come from the pre-update weights
         inst, xyz = orender.render_instance_feature(self.P, rays, self.cfg, jitter)
-        olosses.ema_(self.slow, self.fast, 0.9)
-        loss = olosses.slow_fast(inst, labels, conf)
+        if self.inst_mode == "slow_fast":
+            olosses.ema_(self.slow, self.fast, 0.9)
+            loss = olosses.slow_fast(inst, labels, conf)
+        else:                                                      # T:243-250 contrastive (optionally on points + features)
+            feats = xyz + inst if self.use_delta else inst
+            loss = olosses.contrastive(feats, labels, self.temperature)
+            if self.use_delta:
+                loss = loss + 0.1 * torch.norm(feats - xyz, dim=-1).mean()
         loss.backward()
         self.opt_inst.step()
         return dict(loss=loss.detach(), inst=inst.detach())

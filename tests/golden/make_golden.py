@@ -120,13 +120,13 @@ def grad_digest(prefix, named_grads):
     return out
 
 
-def build_reference_model(P, res, C, E, shift, softmax=True):
+def build_reference_model(P, res, C, E, shift, softmax=True, slow_fast=True):
     from model.radiance_field.tensoRF import TensorVMSplit
     with quiet():
         m = TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32),
-                          num_semantic_classes=C, dim_feature_instance=2 * E, splus_density_shift=shift,
+                          num_semantic_classes=C, dim_feature_instance=(2 * E if slow_fast else E), splus_density_shift=shift,
                           output_mlp_semantics=(torch.nn.Softmax(dim=-1) if softmax else torch.nn.Identity()),
-                          use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True)
+                          use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=slow_fast)
     missing, unexpected = m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
     assert not missing and not unexpected
     return m
@@ -439,7 +439,7 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
-def g12_training_steps():
+def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -452,7 +452,9 @@ def g12_training_steps():
     res, C, E = (9, 13, 17), 4, 3
     aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
     P, pool, rng = _scene(121, res, C, E, aabb, 200)
-    B, Bi, steps, epoch = 96, 64, 3, 4
+    if mode != "slow_fast":                      # single instance MLP with E outputs (tensoRF.py:462-511, slow_fast_mode=False)
+        P = op.add_blob(op.make_params(121, res, C, E, slow_fast=False), res, amplitude=2.5, sigma_g=0.45)
+    B, Bi, epoch = 96, 64, 4
     cfg = _t.SimpleNamespace(
         lr=5e-4, weight_decay=1e-8, decay_step=[9, 10], decay_gamma=0.5, warmup_epochs=0, chunk=40, perturb=1.0,
         optimize_instance_only=False, lambda_rgb=1.0, lambda_semantics=0.1, lambda_feat=0.0, lambda_segment=0.0,
@@ -460,7 +462,7 @@ def g12_training_steps():
         use_distilled_features_semantic=False, use_distilled_features_instance=False, feature_optimization_end_epoch=0,
         late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=100, segment_grouping_mode="none",
         probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E)
-    m = build_reference_model(P, res, C, E, shift=-3.0)
+    m = build_reference_model(P, res, C, E, shift=-3.0, slow_fast=(mode == "slow_fast"))
     rr = build_reference_renderer(aabb, res, "softmax")
     cw = torch.ones(C)
     cw[0] = 0.0
@@ -495,7 +497,7 @@ def g12_training_steps():
     sh.loss_feat = torch.nn.L1Loss(reduction="mean")
     sh.tv_regularizer = TVLoss()
     sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
-    sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = "slow_fast", True, 100.0, False
+    sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = mode, True, 100.0, use_delta
     sh.device = torch.device("cpu")
     sh.current_epoch = epoch
     sh.current_lambda_dist_reg = 0.005 * (1 - np.exp(-0.25 * epoch))                      # T:447
@@ -506,6 +508,7 @@ def g12_training_steps():
                for g in o.param_groups] for o in sh._opts]
 
     out = dict(res=np.array(res), C=C, E=E, seed=121, shift=-3.0, aabb=aabb, B=B, Bi=Bi, steps=steps, epoch=epoch, chunk=cfg.chunk,
+               mode=np.array(mode), use_delta=int(use_delta),
                class_weights=cw, lambda_dist=np.float64(sh.current_lambda_dist_reg),
                opt_groups=np.array([[g[0], g[1], g[2][0], g[2][1], g[3]] for o in groups for g in o], np.float64),
                opt_group_counts=np.array([len(o) for o in groups]))
@@ -556,7 +559,7 @@ def g12_training_steps():
             out.update(grad_digest(f"s{st}.p", {k: p.detach() for k, p in m.named_parameters()}))
     finally:
         RR.torch.rand_like, RR.torch.rand = real_rl, real_r
-    npz("g12_training_steps", **out)
+    npz(fname, **out)
 
 
 def g13_postprocess():
@@ -709,6 +712,7 @@ def main():
     g10_grid_ops()
     g11_metrics()
     g12_training_steps()
+    g12_training_steps(mode="contrastive", use_delta=True, fname="g12c_training_steps_contrastive", steps=2)
     g13_postprocess()
     g14_mos_dataset()
     g15_panopli_dataset()

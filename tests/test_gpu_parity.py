@@ -24,11 +24,11 @@ def _import():
     return cl, op, orender, ofld, olosses, orays
 
 
-def build_model(cl, P, res, C_, E, shift, mode="softmax"):
+def build_model(cl, P, res, C_, E, shift, mode="softmax", slow_fast=True):
     m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_,
-                         dim_feature_instance=2 * E, splus_density_shift=shift,
+                         dim_feature_instance=(2 * E if slow_fast else E), splus_density_shift=shift,
                          output_mlp_semantics=(torch.nn.Softmax(dim=-1) if mode == "softmax" else torch.nn.Identity()),
-                         use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True, device=DEV)
+                         use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=slow_fast, device=DEV)
     missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
     assert not missing and not unexpected
     return m
@@ -555,7 +555,8 @@ def test_training_step_vs_oracle():
         assert diff <= 0.1 * lr * 2 + 1e-7, f"param {k}: max |diff| {diff:.3e} vs lr {lr}"   # elements with |g| ~ eps amplify gradient round-off
 
 
-def test_g12_reference_training_steps_on_gpu():
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive"])
+def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
     instance pass with the EMA between forward and loss): losses to 1e-3, every parameter after every step to 10 % of a
@@ -563,13 +564,16 @@ def test_g12_reference_training_steps_on_gpu():
     is amplified to that scale) and norms to 1e-3."""
     cl, op, orender, ofld, olosses, orays = _import()
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
-    g = load_golden("g12_training_steps")
+    g = load_golden(fixture)          # second fixture: instance_loss_mode "contrastive" + use_delta on a single instance MLP
     res = tuple(int(x) for x in g["res"])
     C_, E = int(g["C"]), int(g["E"])
-    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
-    m = build_model(cl, P, res, C_, E, float(g["shift"]))
+    mode = str(g["mode"]) if "mode" in g else "slow_fast"
+    sf = mode == "slow_fast"
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, float(g["shift"]), slow_fast=sf)
     r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
-    cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3)
+    cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
+                         use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False, max_instances=E)
     tr = HotPathTrainer(m, r, cfg, class_weights=T(g["class_weights"]), current_epoch=int(g["epoch"]))
     rel_close(tr.current_lambda_dist_reg, g["lambda_dist"], 1e-6, what="dist-reg ramp")
     d = lambda a: (torch.from_numpy(a) if isinstance(a, np.ndarray) else a).to(DEV)

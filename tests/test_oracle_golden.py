@@ -193,19 +193,22 @@ def test_g11_metrics_vs_reference():
         panoptic_quality(T(g["pq0.preds"]), T(g["pq0.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=False)
 
 
-def test_g12_three_reference_training_steps():
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive"])
+def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
     net) with the recorded jitter / white-background draws: losses to 1e-4, every parameter after every step to a small
     fraction of one Adam step (Adam normalises the gradient, so a round-off-level gradient difference on a near-zero
     gradient moves a weight by up to lr; what is asserted is the norm to 1e-4 and elementwise 5 % of lr)."""
     from oracle.train_step import CpuTrainer
-    g = load_golden("g12_training_steps")
+    g = load_golden(fixture)          # the second fixture: instance_loss_mode "contrastive" with use_delta (T:243-250), single MLP
     res = tuple(int(x) for x in g["res"])
     C, E = int(g["C"]), int(g["E"])
-    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E), res, 2.5, 0.45)
+    mode = str(g["mode"]) if "mode" in g else "slow_fast"
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=(mode == "slow_fast")), res, 2.5, 0.45)
     cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
-    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]))
+    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]),
+                    instance_loss_mode=mode, use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False)
     rel_close(tr.l_dist, g["lambda_dist"], 1e-6, what="dist-reg ramp")
     # optimizer layout of the reference (T:98-103): 7 main groups (4 grid groups at 20 lr, 3 net groups at lr) + 1 instance group
     og = g["opt_groups"]
