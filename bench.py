@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="rays per renderer call; 0 = whole batch (reference: 2048)")
     ap.add_argument("--lean", action="store_true", help="skip the instance heads in the main pass (their output is discarded)")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp32x6"], default="fp32",
                     help="MLP operand precision: fp32 (headline, BASELINE configs[1]) or bf16 operands / fp32 accumulate (configs[2])")
     ap.add_argument("--inference-probe", action="store_true",
                     help="also report frame-render throughput (adds larger launches of the same kernels: keep it out of profiled runs)")
@@ -126,7 +126,8 @@ def main():
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
+                "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32 (fp32-faithful 6-product bf16 split on the matrix cores)"}[a.dtype],
+                "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
                                         "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype == "fp32" else
                                        (f"BASELINE configs[2]-style bf16 mode on the configs[1] shapes (C={a.classes}, E=3/D=6, grid {a.grid}^3): MLP "

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -40,12 +40,13 @@ class Gemm(C.Structure):
                 ("bias", C.c_void_p), ("act", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p),
-                ("precision", C.c_int)]
+                ("precision", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 _SIGNATURES = {
     "clift_version": ([], C.c_int),
+    "clift_gemm_workspace_bytes": ([_I, _I], C.c_long),
     "clift_last_error": ([], C.c_char_p),
     "clift_gen_rays": ([_I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
     "clift_density_fwd": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),

@@ -205,6 +205,8 @@ static int launch_gemm(const GemmP& p, int a_trans, int b_trans, int splits, hip
     return launch_one<BM, BN, WM, WN, true, false>(p, splits, st);
 }
 
+extern "C" long clift_gemm_workspace_bytes(int N, int K) { return clift_gemm_split_workspace_bytes(N, K); }
+
 extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     CLIFT_REQUIRE(h->M >= 0 && h->N >= 0 && h->K >= 0, "clift_gemm: negative dimension");
     if (h->M == 0 || h->N == 0) return 0;
@@ -225,8 +227,15 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (splits < 1) splits = 1;
     p.k_per_split = kper;
     hipStream_t st = as_stream(s);
-    CLIFT_REQUIRE(h->precision == 0 || h->precision == 1, "clift_gemm: precision must be 0 (fp32) or 1 (bf16 operands), got %d", h->precision);
+    CLIFT_REQUIRE(h->precision >= 0 && h->precision <= 2, "clift_gemm: precision must be 0 (fp32), 1 (bf16 operands) or 2 (fp32x6 split), got %d", h->precision);
     if (h->precision == 1) return clift_gemm_bf16_launch(p, h->a_trans, h->b_trans, splits, st);
+    // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); everything else (wgrad: both operands streamed) stays exact fp32
+    if (h->precision == 2 && !h->a_trans && !h->accumulate && splits == 1 && !h->c_trans && (long)h->N * h->K <= (1L << 22)) {
+        const long need = clift_gemm_split_workspace_bytes(h->N, h->K);
+        CLIFT_REQUIRE(h->workspace != nullptr && h->workspace_bytes >= need && (((uintptr_t)h->workspace & 15) == 0),
+                      "clift_gemm: precision 2 needs a 16-byte aligned workspace of %ld bytes (got %ld)", need, h->workspace_bytes);
+        return clift_gemm_split_launch(p, h->a_trans, h->b_trans, h->workspace, st);
+    }
     if (h->N > 128) {
         return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
     }

@@ -28,6 +28,8 @@ static inline bool gemm_vector_epilogue_ok(const GemmP& p) {
 }
 
 int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st);   // gemm_bf16.hip
+long clift_gemm_split_workspace_bytes(int N, int K);                                                // gemm_split.hip
+int clift_gemm_split_launch(const GemmP& p, int a_trans, int b_trans, void* workspace, hipStream_t st);
 
 // acc[x][y] = 32x32 accumulator tile (x, y) of this wave; (wm, wn) = wave coordinates in the block; li = lane & 31,
 // lh = lane >> 5.  csum = this thread's partial bias-gradient (column sum of A) when do_colsum.

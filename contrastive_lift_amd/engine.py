@@ -92,14 +92,16 @@ def _pitch(t):
 
 # MLP operand precision of every matrix-core launch: 0 = fp32 (default, exact fp32 products), 1 = "bf16 mode" (operands
 # rounded to bf16 in the kernel, fp32 accumulate, fp32 tensors in memory) -- BASELINE config 3 / SURVEY 7.9.
-MLP_PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
+# 2 = "fp32x6": fp32-faithful 6-product bf16 split on the matrix cores for the forward / dgrad launches (opt-in).
+_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32x6": 2}
+MLP_PRECISION = _PRECISIONS[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
 
 
 def set_mlp_precision(name):
-    """'fp32' or 'bf16'; returns the previous setting's name."""
+    """'fp32', 'bf16' or 'fp32x6'; returns the previous setting's name."""
     global MLP_PRECISION
-    prev = "bf16" if MLP_PRECISION else "fp32"
-    MLP_PRECISION = {"fp32": 0, "f32": 0, "bf16": 1}[str(name).lower()]
+    prev = {0: "fp32", 1: "bf16", 2: "fp32x6"}[MLP_PRECISION]
+    MLP_PRECISION = _PRECISIONS[str(name).lower()]
     return prev
 
 
@@ -118,6 +120,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
     g.precision = MLP_PRECISION
+    if MLP_PRECISION == 2 and not a_trans and not accumulate and not c_trans:
+        nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)          # split weight planes (stream-ordered scratch)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     call("clift_gemm", C.byref(g), stream())
 
 

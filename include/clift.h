@@ -136,6 +136,9 @@ int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const 
  * precision 0: fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32, exact fp32 products).
  * precision 1: "bf16 mode" -- A and B are rounded to bf16 (RNE) on their way into LDS, products on
  *   v_mfma_f32_32x32x16_bf16 with fp32 accumulation; all tensors stay fp32 in memory (BASELINE config 3).
+ * precision 2: "fp32x6" -- fp32-faithful products on the bf16 matrix cores: every operand value is split exactly into three
+ *   bf16 terms and the six leading cross products are accumulated in fp32 (error below fp32 product rounding).  Applies to
+ *   the forward / dgrad forms (a_trans = 0, no accumulate); other forms run as precision 0.  Needs `workspace`.
  * K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
  * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C). */
 typedef struct {
@@ -150,8 +153,11 @@ typedef struct {
     int split_k;
     int c_trans;                    /* write C[n*ldc + m] (lets a narrow-M wgrad run as a narrow-N problem) */
     float* colsum;                  /* nullable; a_trans only: colsum[m] += sum_k A(m,k)  (bias gradient) */
-    int precision;                  /* 0 fp32 operands, 1 bf16 operands (fp32 accumulate) */
+    int precision;                  /* 0 fp32 operands, 1 bf16 operands (fp32 accumulate), 2 fp32x6 split (see above) */
+    void* workspace;                /* precision 2 only: device scratch for the split weight planes, 16-byte aligned */
+    long workspace_bytes;           /* >= clift_gemm_workspace_bytes(N, K) */
 } clift_gemm_t;
+long clift_gemm_workspace_bytes(int N, int K);
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 
 /* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4), W (Nout, 3)

@@ -128,6 +128,42 @@ def test_gemm_bf16_mode_matches_rounded_operands(at, bt, M, N, K):
         rel_close(colsum, refc, 1e-4, atol=1e-4 * float(refc.abs().max()) + 1e-5, what="bf16 colsum")
 
 
+@pytest.mark.parametrize("bt", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 128, 152), (517, 27, 144), (257, 3, 128), (129, 150, 36), (64, 22, 7),
+                                   (128 * 5 + 1, 256, 64)])
+def test_gemm_fp32x6_split_is_fp32_faithful(bt, M, N, K):
+    """fp32x6 (clift_gemm precision = 2): every operand split exactly into three bf16 terms, six products on the bf16 matrix
+    cores, fp32 accumulate.  It must meet the SAME fp64 tolerance as the exact-fp32 kernel (2e-5 of the tensor scale), and its
+    worst error must stay within 4x of the exact-fp32 kernel's own round-off on the same problem."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M * 5 + N * 3 + K + bt + 77)
+    Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = torch.randn((M, Kp), generator=g) * torch.exp(2.0 * torch.randn((M, 1), generator=g))      # rows of very different scale
+    B = torch.randn((K, Np) if bt else (N, Kp), generator=g)
+    bias = torch.randn(N, generator=g)
+    Bop = B[:, :N].T if bt else B[:, :K]
+    ref = A[:, :K].double() @ Bop.double().T + bias.double()
+    mask = torch.randn(M, N, generator=g)
+    Ad, Bd, biasd, maskd = A.to(DEV), B.to(DEV), bias.to(DEV), mask.to(DEV).contiguous()
+    outs = {}
+    for mode in ("fp32", "fp32x6"):
+        prev = engine.set_mlp_precision(mode)
+        try:
+            o1 = torch.full((M, N + 1), -7.0, device=DEV)
+            engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], o1, N + 1, b_trans=bt, bias=biasd)
+            o2 = torch.zeros((M, N), device=DEV)
+            engine.gemm(M, N, K, Ad, A.shape[1], Bd, B.shape[1], o2, N, b_trans=bt, bias=biasd, act=1, mask=maskd, ldmask=N)
+        finally:
+            engine.set_mlp_precision(prev)
+        outs[mode] = (o1, o2)
+    row_scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    err = {k: float(((v[0][:, :N].double().cpu() - ref).abs() / row_scale).max()) for k, v in outs.items()}
+    assert bool((outs["fp32x6"][0][:, N] == -7.0).all())
+    assert err["fp32x6"] <= 2e-5, err
+    assert err["fp32x6"] <= 4.0 * err["fp32"] + 2e-7, err                 # same order as fp32 round-off, row by row
+    rel_close(outs["fp32x6"][1], torch.relu(ref) * (mask > 0), 2e-5, atol=2e-5 * float(ref.abs().max()), what="fp32x6 relu+mask")
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine

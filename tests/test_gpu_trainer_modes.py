@@ -139,3 +139,28 @@ def test_bf16_mode_tracks_fp32():
         assert abs(psnrs["fp32"] - psnrs["bf16"]) < 0.1, psnrs
     finally:
         engine.set_mlp_precision("fp32")
+
+
+def test_fp32x6_mode_matches_fp32_path():
+    """fp32x6 mode (mlp_dtype = "fp32x6": forward / dgrad GEMMs as six bf16 products of exactly split operands) is fp32-FAITHFUL:
+    rendered tensors and every parameter gradient agree with the exact-fp32 path to fp32 round-off scale (1e-5 of the tensor
+    scale; gradients through the usual grad_close), far inside the 1e-3 parity budget."""
+    from contrastive_lift_amd import engine
+    try:
+        outs, grads = {}, {}
+        for mode in ("fp32", "fp32x6"):
+            tr, batch, jit = _setup(seed=5, B=2048, Bi=256)
+            engine.set_mlp_precision(mode)
+            o, ctx = engine.render_forward(tr.model, tr.renderer, batch[0]["rays"], jit, False)
+            outs[mode] = {k: o[k].clone() for k in ("rgb", "semantics", "instances")}
+            tr.config.mlp_dtype = mode
+            tr.main_pass(batch[0], jitter=jit, white_bg=False)
+            grads[mode] = _grads(tr)
+        for k in outs["fp32"]:
+            a, b = outs["fp32x6"][k], outs["fp32"][k]
+            assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max())), k
+        for k in grads["fp32"]:
+            if not k.startswith("render_instance_mlp"):
+                grad_close(grads["fp32x6"][k], grads["fp32"][k], what=f"fp32x6 {k}")
+    finally:
+        engine.set_mlp_precision("fp32")

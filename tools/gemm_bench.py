@@ -7,7 +7,7 @@ from contrastive_lift_amd import engine
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 265000
 if len(sys.argv) > 2:
-    engine.set_mlp_precision(sys.argv[2])      # fp32 | bf16
+    engine.set_mlp_precision(sys.argv[2])      # fp32 | bf16 | fp32x6
 dev = "cuda"
 shapes = [("fwd 256x256", M, 256, 256, 0, 0), ("dgrad 256x256", M, 256, 256, 0, 1), ("wgrad 256x256", 256, 256, M, 1, 1),
           ("fwd 152->128", M, 128, 152, 0, 0), ("fwd 128->128", M, 128, 128, 0, 0), ("fwd 256->22", M, 22, 256, 0, 0),
