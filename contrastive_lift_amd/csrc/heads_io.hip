@@ -222,23 +222,41 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
 // ============================================================================ appearance MLP input
 // Column map (tensoRF.py:401-408,413-418): [feat(nf) | dir(3) | sin(feat_f*2^p) (f-major, p minor) | cos(...) |
 // sin(dir_a*2^p) | cos(...) | zero pad].
+// Thread = (sample, SOURCE element j): j < nf a feature, nf <= j < nf + 3 a view-direction component, j = nf + 3 the zero pad.
+// One sincosf per (element, frequency) yields both encodings (the per-output-column form evaluated every sine and cosine
+// separately with a full range reduction each: 226 us -> see profiles/r01_v4 for 265 k samples); neighbouring threads write
+// neighbouring columns in every block of the row.
 __global__ __launch_bounds__(256) void k_app_encode_fwd(const float* __restrict__ feat, int ldf, int nf, int pef, int pev,
                                                          const float* __restrict__ rays, const int* __restrict__ act, int S, long total,
                                                          float* __restrict__ X, int ldx) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
-    const int s = (int)(gid / ldx), c = (int)(gid - (long)s * ldx);
-    const float* f = feat + (size_t)s * ldf;
-    const float* d = rays + (size_t)(act[s] / S) * 8 + 3;
+    const int J = nf + 4;
+    const int s = (int)(gid / J), j = (int)(gid - (long)s * J);
+    float* x = X + (size_t)s * ldx;
     const int b0 = nf, b1 = b0 + 3, b2 = b1 + nf * pef, b3 = b2 + nf * pef, b4 = b3 + 3 * pev, b5 = b4 + 3 * pev;
-    float v = 0.f;
-    if (c < b0) v = f[c];
-    else if (c < b1) v = d[c - b0];
-    else if (c < b2) { const int e = c - b1; v = sinf(f[e / pef] * (float)(1 << (e % pef))); }
-    else if (c < b3) { const int e = c - b2; v = cosf(f[e / pef] * (float)(1 << (e % pef))); }
-    else if (c < b4) { const int e = c - b3; v = sinf(d[e / pev] * (float)(1 << (e % pev))); }
-    else if (c < b5) { const int e = c - b4; v = cosf(d[e / pev] * (float)(1 << (e % pev))); }
-    X[gid] = v;
+    if (j < nf) {
+        const float v = feat[(size_t)s * ldf + j];
+        x[j] = v;
+        for (int p = 0; p < pef; ++p) {
+            float sn, cs;
+            sincosf(v * (float)(1 << p), &sn, &cs);
+            x[b1 + j * pef + p] = sn;
+            x[b2 + j * pef + p] = cs;
+        }
+    } else if (j < nf + 3) {
+        const int a = j - nf;
+        const float v = rays[(size_t)(act[s] / S) * 8 + 3 + a];
+        x[b0 + a] = v;
+        for (int p = 0; p < pev; ++p) {
+            float sn, cs;
+            sincosf(v * (float)(1 << p), &sn, &cs);
+            x[b3 + a * pev + p] = sn;
+            x[b4 + a * pev + p] = cs;
+        }
+    } else {
+        for (int c = b5; c < ldx; ++c) x[c] = 0.f;       // alignment padding of the GEMM operand row stays zero
+    }
 }
 
 extern "C" int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* rays,
@@ -246,7 +264,7 @@ extern "C" int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_f
     CLIFT_REQUIRE(ldx >= nf + 3 + 2 * pe_feat * nf + 2 * pe_view * 3, "clift_app_encode_fwd: ldx %d too small", ldx);
     CLIFT_REQUIRE(pe_feat >= 1 && pe_view >= 1, "clift_app_encode_fwd: pe_feat/pe_view must be >= 1");
     if (M <= 0) return 0;
-    const long total = (long)M * ldx;
+    const long total = (long)M * (nf + 4);
     k_app_encode_fwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, pe_view, rays, act_idx, S, total, X, ldx);
     return clift_check_launch("clift_app_encode_fwd");
 }
@@ -264,8 +282,10 @@ __global__ __launch_bounds__(256) void k_app_encode_bwd(const float* __restrict_
         v = g[c];
         const int bs = nf + 3, bc = bs + nf * pef;
         for (int p = 0; p < pef; ++p) {
-            const float fr = (float)(1 << p), a = x * fr;
-            v += fr * (cosf(a) * g[bs + c * pef + p] - sinf(a) * g[bc + c * pef + p]);
+            const float fr = (float)(1 << p);
+            float sn, cs;
+            sincosf(x * fr, &sn, &cs);
+            v += fr * (cs * g[bs + c * pef + p] - sn * g[bc + c * pef + p]);
         }
     }
     dfeat[gid] = v;
