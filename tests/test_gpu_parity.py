@@ -326,6 +326,32 @@ def test_forward_backward_vs_oracle_mid(mode, white):
         rel_close(got, ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=f"grad {k}")
 
 
+def test_forward_backward_vs_oracle_large_grid_no_lds_lines():
+    """Grid 300 x 280 x 330 (beyond the reference's 192^3): the appearance line accumulators (910 x 48 floats = 175 KB) no
+    longer fit the 160 KB LDS, so k_app_gather_bwd takes its global-atomic line path (LDS_LINES = false) while the density
+    kernel (58 KB) keeps the LDS path; also covers XCD-private accumulation copies at a large table size."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    res, C_, E, n_rays = (300, 280, 330), 5, 3, 96
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, 29, res, C_, E, n_rays, amp=2.2, sg=0.4)
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((n_rays, 3), (n_rays, C_), (n_rays, 2 * E))]
+    Pg = op.clone_params(P, requires_grad=True)
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0, semantic_weight_mode="softmax")
+    o = orender.render_forward(Pg, rays, cfg, jitter, False)
+    L = (o[0] * cots[0]).sum() + (o[1] * cots[1]).sum() + (o[2] * cots[2]).sum() + 3.0 * o[5]
+    L.backward()
+    m = build_model(cl, P, res, C_, E, -3.0, "softmax")
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    outs, grads = _run_forward_backward(cl, m, r, rays, jitter, False, cots + [3.0])
+    for a, b, nm in zip(outs[:4], o[:4], ("rgb", "sem", "inst", "depth")):
+        rel_close(a, b.detach(), 1e-3, what=nm)
+    for k in ("density_plane.0", "density_line.2", "appearance_plane.1", "appearance_line.0", "appearance_line.1", "appearance_line.2"):
+        ref = Pg[k].grad
+        got = grads[k].detach().cpu()
+        rel_close(got, ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=f"grad {k}")
+
+
 def test_instance_and_segment_golden_g7():
     cl, op, *_ = _import()
     g = load_golden("g7_instance_segment")
