@@ -617,6 +617,50 @@ def test_training_step_vs_oracle():
         assert diff <= 0.1 * lr * 2 + 1e-7, f"param {k}: max |diff| {diff:.3e} vs lr {lr}"   # elements with |g| ~ eps amplify gradient round-off
 
 
+def test_psnr_parity_over_a_training_trajectory():
+    """north_star: "PSNR ... within 0.1".  Sixty full training steps (main pass + slow-fast instance pass, both Adam optimizers,
+    EMA) from identical weights, batches, jitter and white-background draws: the HIP trainer's PSNR on the training rays stays
+    within 0.1 dB of the CPU oracle's at every checkpoint of the trajectory, and the losses within 2 %."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from oracle.train_step import CpuTrainer
+    res, C_, E, B, Bi, steps = (24, 28, 32), 5, 3, 512, 192, 60
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, 91, res, C_, E, B + Bi, amp=2.3, sg=0.42)
+    rays_main, rays_inst = rays[:B].contiguous(), rays[B:].contiguous()
+    # a learnable target: colours and labels that are smooth functions of the ray direction
+    d = rays_main[:, 3:6]
+    rgbs = (0.5 + 0.5 * torch.sin(3.0 * d + torch.tensor([0.0, 1.0, 2.0]))).contiguous()
+    probs = torch.softmax(4.0 * torch.stack([torch.sin((k + 1.0) * d[:, k % 3]) for k in range(C_)], -1), -1).contiguous()
+    conf = torch.from_numpy(rng.uniform(0.5, 1, B).astype(np.float32))
+    labels = (1 + (rays_inst[:, 3] > 0).long() + 2 * (rays_inst[:, 4] > 0).long()).contiguous()
+    iconf = torch.from_numpy(rng.uniform(0.5, 1, Bi).astype(np.float32))
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    tr = HotPathTrainer(m, r, default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0), current_epoch=4)
+    ct = CpuTrainer(P, orender.RenderCfg(aabb, res, density_shift=-3.0), chunk=4096, epoch=4)
+    batch0 = dict(rays=rays_main.to(DEV), rgbs=rgbs.to(DEV), probabilities=probs.to(DEV), confidences=conf.to(DEV), mask=None)
+    ibatch = [dict(rays=rays_inst.to(DEV), instances=labels.to(DEV), confidences=iconf.to(DEV))]
+    psnr = lambda a, b: float(-10.0 * torch.log10(((a - b) ** 2).mean()))
+    worst = 0.0
+    for step in range(steps):
+        jit = torch.from_numpy(rng.uniform(0, 1, B).astype(np.float32))
+        jit_i = torch.from_numpy(rng.uniform(0, 1, Bi).astype(np.float32))
+        white = bool(step % 3 == 0)
+        oc = ct.main_pass(rays_main, rgbs, probs, conf, jit, [white])
+        oi = ct.instance_pass(rays_inst, labels, iconf, jit_i)
+        tr.main_pass(batch0, jitter=jit.to(DEV), white_bg=white)
+        tr.instance_pass(ibatch, jitter=jit_i.to(DEV))
+        if step % 10 == 9 or step == steps - 1:
+            p_cpu, p_gpu = psnr(oc["rgb"], rgbs), psnr(tr.last_outputs[0].cpu(), rgbs)
+            worst = max(worst, abs(p_cpu - p_gpu))
+            assert abs(p_cpu - p_gpu) < 0.1, (step, p_cpu, p_gpu)
+            rel_close(tr.losses[1], oc["loss_sem"], 2e-2, what=f"step {step} loss_sem")
+            rel_close(tr.losses[3], oi["loss"], 2e-2, atol=2e-3, what=f"step {step} slow-fast loss")
+    assert p_cpu > psnr(torch.full_like(rgbs, 0.5), rgbs) + 1.0          # the trajectory actually learned something
+    print(f"PSNR after {steps} steps: oracle {p_cpu:.3f} dB, HIP {p_gpu:.3f} dB; worst |delta| along the trajectory {worst:.4f} dB")
+
+
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
