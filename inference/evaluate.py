@@ -26,11 +26,13 @@ from contrastive_lift_amd.metrics import panoptic_quality                   # no
 
 
 def read_png(path, size):
-    return np.array(Image.open(path).resize(size[::-1], Image.NEAREST))
+    # preprocess_scannet.py:594-596: ``size`` goes to PIL unchanged, i.e. it is read as (width, height); the reference always
+    # evaluates at (512, 512).  int64 so that 16-bit id PNGs and 8-bit label PNGs mix whatever Pillow decodes them to.
+    return np.array(Image.open(path).resize(tuple(size), Image.NEAREST)).astype(np.int64)
 
 
 def read_npy(path, size):
-    return np.array(Image.fromarray(np.load(path).astype(np.int16)).resize(size[::-1], Image.NEAREST))
+    return np.array(Image.fromarray(np.load(path).astype(np.int16)).resize(tuple(size), Image.NEAREST)).astype(np.int64)
 
 
 def _mos_val_names(target_dir):
@@ -50,7 +52,7 @@ def evaluate_mos(exp_path, root_path, image_dim):
     for p in _pred_paths(exp_path / "pred_semantics", val):
         ps = read_png(p, image_dim)
         ts = read_npy(root_path / "semantic" / f"{p.stem}.npy", image_dim)
-        cm.add_batch(ts, ps)
+        cm.add_batch(ps, ts)                               # the reference passes (pred, target) (:654)
         pi = read_png(exp_path / "pred_surrogateid" / p.name, image_dim)
         ti = read_npy(root_path / "instance" / f"{p.stem}.npy", image_dim)
         pred.append(np.stack([ps.reshape(-1), pi.reshape(-1)], -1))
@@ -72,7 +74,7 @@ def evaluate_panopli(exp_path, root_path, image_dim, is_thing):
         ts = read_png(root_path / "rs_semantics" / p.name, image_dim)
         valid = ~np.isin(ts, [0])
         ps = read_png(p, image_dim)
-        cm.add_batch(ts[valid], ps[valid])
+        cm.add_batch(ps[valid], ts[valid])                 # (pred, target) as :633
         pi = read_png(exp_path / "pred_surrogateid" / p.name, image_dim)
         ti = read_png(root_path / "rs_instance" / p.name, image_dim)
         pred.append(np.stack([ps[valid], pi[valid]], -1))

@@ -695,6 +695,66 @@ def g15_panopli_dataset():
     npz("g15_panopli_dataset", **out)
 
 
+def g16_scene_evaluators():
+    """The reference's scene-level evaluators (dataset/preprocessing/preprocess_scannet.py:622-732, what inference/evaluate.py
+    prints): mIoU and PQ_scene over prediction folders, MOS and ScanNet-style layouts, square and non-square evaluation sizes.
+    They call ``.cuda()`` on index tensors; this container has no GPU, so Tensor.cuda is made the identity for the call (no
+    arithmetic involved)."""
+    import pathlib
+    import tempfile
+    from PIL import Image
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen_m
+    import make_synthetic_panopli as gen_p
+    from make_fake_predictions import write_fake_predictions
+    tmp = tempfile.mkdtemp(prefix="g16_")
+    out = {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import dataset.preprocessing.preprocess_scannet as PS
+        # environment shim, no arithmetic: this image's Pillow decodes the 16-bit id PNGs to uint16 arrays, which this torch
+        # cannot concatenate with uint8 (the reference's pinned Pillow returned int32): widen what the reader returns
+        _read = PS.read_and_resize_labels
+        PS.read_and_resize_labels = lambda path, size: _read(path, size).astype(np.int32)
+        # ---- MOS layout
+        root = gen_m.make_scene(os.path.join(tmp, "mos"), n_frames=10, size=24, seed=7)
+        names = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(root, "semantic")))
+        val = names[int(len(names) * 0.8):]
+        rng = np.random.default_rng(161)
+        write_fake_predictions(os.path.join(tmp, "mos_exp"), val, [np.load(os.path.join(root, "semantic", n + ".npy")) for n in val],
+                               [np.load(os.path.join(root, "instance", n + ".npy")) for n in val], rng)
+        for tag, dim in (("sq", (24, 24)), ("ns", (20, 28))):
+            with quiet():
+                iou = PS.calculate_iou_folders_MOS(pathlib.Path(tmp, "mos_exp", "pred_semantics"), pathlib.Path(root) / "semantic", dim)
+                pq, sq, rq = PS.calculate_panoptic_quality_folders_MOS(pathlib.Path(tmp, "mos_exp", "pred_semantics"), pathlib.Path(tmp, "mos_exp", "pred_surrogateid"),
+                                                                       pathlib.Path(root) / "semantic", pathlib.Path(root) / "instance", dim)
+            out[f"mos.{tag}.dim"] = np.array(dim)
+            out[f"mos.{tag}.metrics"] = np.array([iou, pq, sq, rq], np.float64)
+        # ---- ScanNet-style (PanopLi) layout
+        rootp = gen_p.make_scene(os.path.join(tmp, "pan"), n_frames=10, size=24, seed=5)
+        test = [str(x) for x in __import__("json").load(open(os.path.join(rootp, "splits.json")))["test"]]
+        rd = lambda d, n: np.array(Image.open(os.path.join(rootp, d, n + ".png")))
+        write_fake_predictions(os.path.join(tmp, "pan_exp"), test, [rd("rs_semantics", n) for n in test], [rd("rs_instance", n) for n in test], rng)
+        for tag, dim in (("sq", (24, 24)), ("ns", (20, 28))):
+            with quiet():
+                iou = PS.calculate_iou_folders(pathlib.Path(tmp, "pan_exp", "pred_semantics"), pathlib.Path(rootp) / "rs_semantics", dim)
+                pq, sq, rq = PS.calculate_panoptic_quality_folders(pathlib.Path(tmp, "pan_exp", "pred_semantics"), pathlib.Path(tmp, "pan_exp", "pred_surrogateid"),
+                                                                   pathlib.Path(rootp) / "rs_semantics", pathlib.Path(rootp) / "rs_instance", dim)
+            out[f"pan.{tag}.dim"] = np.array(dim)
+            out[f"pan.{tag}.metrics"] = np.array([iou, pq, sq, rq], np.float64)
+        out["is_thing"] = np.array(PS.get_thing_semantics())        # the reference's class table (resources/scannet_reduced_things.csv) as data
+        out["num_classes_iou"] = 1 + len(pathlib.Path("resources/scannet_reduced_to_coco.csv").read_text().strip().splitlines())
+    finally:
+        os.chdir(cwd)
+        torch.Tensor.cuda = real_cuda
+        if "PS" in locals():
+            PS.read_and_resize_labels = _read
+    npz("g16_scene_evaluators", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -716,6 +776,7 @@ def main():
     g13_postprocess()
     g14_mos_dataset()
     g15_panopli_dataset()
+    g16_scene_evaluators()
 
 
 if __name__ == "__main__":

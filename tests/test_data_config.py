@@ -115,3 +115,38 @@ def test_g15_panopli_reader_vs_reference_dataset(tmp_path):
             rel_close(t["probabilities"], g[f"{tag}.f{f}.probabilities"], 1e-6, atol=1e-8, what="probabilities")
             rel_close(t["confidences"], g[f"{tag}.f{f}.confidences"], 1e-6, what="confidences")
             assert torch.equal(t["mask"], torch.from_numpy(g[f"{tag}.f{f}.mask"]))
+
+
+def test_g16_scene_evaluators_vs_reference(tmp_path):
+    """inference/evaluate.py (mIoU + PQ_scene over prediction folders) against the REFERENCE's evaluators
+    (preprocess_scannet.py:622-732) on the same synthetic scenes and prediction folders: MOS and ScanNet-style layouts,
+    square and non-square evaluation sizes."""
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    from conftest import load_golden
+    import make_synthetic_mos as gen_m
+    import make_synthetic_panopli as gen_p
+    from make_fake_predictions import write_fake_predictions
+    spec = importlib.util.spec_from_file_location("clift_eval", os.path.join(REPO, "inference", "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    g = load_golden("g16_scene_evaluators")
+    root = gen_m.make_scene(str(tmp_path / "mos"), n_frames=10, size=24, seed=7)
+    names = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(root, "semantic")))
+    val = names[int(len(names) * 0.8):]
+    rng = np.random.default_rng(161)
+    write_fake_predictions(str(tmp_path / "mos_exp"), val, [np.load(os.path.join(root, "semantic", n + ".npy")) for n in val],
+                           [np.load(os.path.join(root, "instance", n + ".npy")) for n in val], rng)
+    for tag in ("sq", "ns"):
+        got = ev.evaluate_mos(str(tmp_path / "mos_exp"), root, tuple(int(x) for x in g[f"mos.{tag}.dim"]))
+        np.testing.assert_allclose(np.array(got), g[f"mos.{tag}.metrics"], rtol=1e-6, atol=1e-9)
+    rootp = gen_p.make_scene(str(tmp_path / "pan"), n_frames=10, size=24, seed=5)
+    test = [str(x) for x in json.load(open(os.path.join(rootp, "splits.json")))["test"]]
+    rd = lambda d, n: np.array(Image.open(os.path.join(rootp, d, n + ".png")))
+    write_fake_predictions(str(tmp_path / "pan_exp"), test, [rd("rs_semantics", n) for n in test], [rd("rs_instance", n) for n in test], rng)
+    is_thing = [bool(x) for x in g["is_thing"]]
+    assert len(is_thing) == int(g["num_classes_iou"])
+    for tag in ("sq", "ns"):
+        got = ev.evaluate_panopli(str(tmp_path / "pan_exp"), rootp, tuple(int(x) for x in g[f"pan.{tag}.dim"]), is_thing)
+        np.testing.assert_allclose(np.array(got), g[f"pan.{tag}.metrics"], rtol=1e-6, atol=1e-9)

@@ -76,7 +76,7 @@ def make_scene(out, n_frames=12, size=32, seed=0, invalid_frames=(), n_classes=5
         np.savez(os.path.join(out, "m2f_probabilities", name + ".npz"), probability=prob.astype(np.float32),
                  confidence=rng.uniform(0.5, 1.0, (size, size)).astype(np.float32))
     n_test = max(1, n_frames // 5)
-    json.dump({"train": [int(x) for x in names[:-n_test]], "test": [int(x) for x in names[-n_test:]]}, open(os.path.join(out, "splits.json"), "w"))
+    json.dump({"train": list(names[:-n_test]), "test": list(names[-n_test:])}, open(os.path.join(out, "splits.json"), "w"))
     i2s = {int(i + 1): int(c) for i, c in enumerate(sphere_class)}
     pickle.dump({"fg_classes": [4, 2, 3], "bg_classes": [1, 0], "m2f_instance_to_semantic": i2s, "rs_instance_to_semantic": i2s},
                 open(os.path.join(out, "segmentation_data.pkl"), "wb"))
