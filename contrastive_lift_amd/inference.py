@@ -110,25 +110,36 @@ def assign_clusters(all_thing_features, all_points_semantics, all_centroids, dev
     return _one_hot(labels, num_images, device)
 
 
-def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000, seed=None):
-    """RP:196-263 (MeanShift branch): outlier filter, per-axis rescale, subsample, sklearn MeanShift, predict all."""
+def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000, use_silverman=False):
+    """RP:196-263 (MeanShift branch; HDBSCAN is not installed in this image): 3-sigma outlier filter, per-axis rescale to the
+    unit box, a 50000-point subsample drawn with ``np.random.choice`` from numpy's GLOBAL generator exactly as the reference
+    does (seed it with ``np.random.seed`` for reproducible runs), sklearn MeanShift (optionally with Silverman's bandwidth),
+    then every pixel is assigned to its nearest cluster.  Returns (one-hot (num_images, P, K+1) float64, centroids in feature
+    units).  Scenes with fewer thing pixels than ``num_points`` use all of them (the reference raises there)."""
     from sklearn.cluster import MeanShift
     feats = np.asarray(all_thing_features)
     thing = feats[..., 0] == -float("inf")
     f_th = feats[thing][:, 1:]
     f_all = feats[:, 1:]
-    mu, sd = f_th.mean(0), f_th.std(0)
+    mu, sd = f_th.mean(axis=0), f_th.std(axis=0)
     keep = np.all(np.abs(f_th - mu) < 3 * sd, axis=1)
     cf = f_th[keep]
-    bias = cf.min(0)
-    factor = 1 / (cf.max(0) - cf.min(0))
+    bias = cf.min(axis=0)
+    factor = 1 / (cf.max(axis=0) - cf.min(axis=0))
     cr = (cf - bias) * factor
-    rng = np.random.default_rng(seed)
-    idx = rng.choice(cr.shape[0], min(num_points, cr.shape[0]), replace=False)
-    ms = MeanShift(bandwidth=bandwidth, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(cr[idx])
+    idx = np.random.choice(cr.shape[0], num_points, replace=False) if cr.shape[0] >= num_points else np.arange(cr.shape[0])
+    pts = cr[idx]
+    if use_silverman:
+        from scipy.stats import gaussian_kde
+        bandwidth = gaussian_kde(pts.T, bw_method="silverman").covariance_factor()
+    ms = MeanShift(bandwidth=bandwidth, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(pts)
     all_labels = ms.predict((f_all.reshape(-1, f_all.shape[-1]) - bias) * factor)
     all_labels[~thing] = -1
-    return _one_hot(torch.as_tensor(all_labels, dtype=torch.int64, device=device), num_images, device), ms.cluster_centers_ / factor + bias
+    all_labels = all_labels + 1                                   # -1,0,..,K-1 -> 0,1,..,K
+    K1 = ms.cluster_centers_.shape[0] + 1                          # width = number of centroids + 1 (not max label + 1)
+    onehot = torch.zeros((all_labels.shape[0], K1), dtype=torch.float64, device=device)
+    onehot[torch.arange(all_labels.shape[0], device=device), torch.as_tensor(all_labels, dtype=torch.int64, device=device)] = 1
+    return onehot.view(num_images, -1, K1), ms.cluster_centers_ / factor + bias
 
 
 def psnr(image_pred, image_gt):

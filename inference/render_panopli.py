@@ -80,7 +80,7 @@ def glasbey(n):
 
 
 def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth=0.15, use_dbscan=False, segmentwise=False,
-                              cached_centroids_path=None, device="cuda:0"):
+                              cached_centroids_path=None, device="cuda:0", use_silverman=False):
     if use_dbscan or segmentwise:
         raise NotImplementedError("HDBSCAN / segment-wise clustering are CPU post-processing variants not built here "
                                   "(hdbscan is absent from this image); use MeanShift or --cached_centroids_path")
@@ -136,7 +136,7 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
             cents = pickle.load(f)
         insts = inf.assign_clusters(all_thing, sems, cents, device, num_images=len(rgbs))
     else:
-        insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs))
+        insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
     for d in ("vis_semantics_and_surrogate", "pred_semantics", "pred_surrogateid"):
         (out / d).mkdir(exist_ok=True)
     for j, frame_name in enumerate(names):
@@ -172,4 +172,4 @@ if __name__ == "__main__":
     cfg.image_dim = list(args.image_dim)
     print(render_panopli_checkpoint(cfg, "trajectory_blender", test_only=not args.render_trajectory, bandwidth=args.bandwidth,
                                     use_dbscan=args.use_dbscan, segmentwise=args.segmentwise,
-                                    cached_centroids_path=args.cached_centroids_path))
+                                    cached_centroids_path=args.cached_centroids_path, use_silverman=args.use_silverman))

@@ -755,6 +755,26 @@ def g16_scene_evaluators():
     npz("g16_scene_evaluators", **out)
 
 
+def g17_meanshift_clustering():
+    """The reference's MeanShift clustering of rendered thing features (inference/render_panopli.py:196-263): outlier filter,
+    rescale, 50000-point subsample from numpy's global generator (seeded here), sklearn MeanShift, nearest-cluster prediction,
+    one-hot of width K + 1 -- with a fixed bandwidth and with Silverman's rule."""
+    sys.modules["hdbscan"].HDBSCAN = _Inert
+    import importlib
+    RP = importlib.import_module("inference.render_panopli")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from make_fake_predictions import fake_thing_features
+    all_thing, n_img = fake_thing_features(171)          # regenerated by the test from the same seed: only the labels are stored
+    out = dict(seed=171, n_img=n_img, n_rows=all_thing.shape[0], checksum=np.float64(np.where(np.isfinite(all_thing), all_thing, 0).sum()))
+    for tag, kw in (("bw", dict(bandwidth=0.15)), ("silverman", dict(bandwidth=0.15, use_silverman=True))):
+        np.random.seed(1234)
+        with quiet():
+            onehot = RP.cluster(all_thing.copy(), kw["bandwidth"], torch.device("cpu"), num_images=n_img, use_silverman=kw.get("use_silverman", False))
+        out[f"{tag}.labels"] = onehot.argmax(-1).reshape(-1).numpy().astype(np.int16)
+        out[f"{tag}.width"] = onehot.shape[-1]
+    npz("g17_meanshift_clustering", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -777,6 +797,7 @@ def main():
     g14_mos_dataset()
     g15_panopli_dataset()
     g16_scene_evaluators()
+    g17_meanshift_clustering()
 
 
 if __name__ == "__main__":

@@ -150,3 +150,21 @@ def test_g16_scene_evaluators_vs_reference(tmp_path):
     for tag in ("sq", "ns"):
         got = ev.evaluate_panopli(str(tmp_path / "pan_exp"), rootp, tuple(int(x) for x in g[f"pan.{tag}.dim"]), is_thing)
         np.testing.assert_allclose(np.array(got), g[f"pan.{tag}.metrics"], rtol=1e-6, atol=1e-9)
+
+
+def test_g17_meanshift_clustering_vs_reference():
+    """inference.cluster against the REFERENCE's cluster() (RP:196-263) on the same 72 k synthetic thing features with numpy's
+    global generator seeded identically: identical per-pixel cluster labels and one-hot width, fixed bandwidth and Silverman."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from make_fake_predictions import fake_thing_features
+    from contrastive_lift_amd.inference import cluster
+    g = load_golden("g17_meanshift_clustering")
+    all_thing, n_img = fake_thing_features(int(g["seed"]))
+    assert all_thing.shape[0] == int(g["n_rows"]) and abs(float(np.where(np.isfinite(all_thing), all_thing, 0).sum()) - float(g["checksum"])) < 1e-6
+    for tag, silver in (("bw", False), ("silverman", True)):
+        np.random.seed(1234)
+        onehot, cents = cluster(all_thing.copy(), 0.15, torch.device("cpu"), num_images=n_img, use_silverman=silver)
+        assert onehot.shape == (n_img, all_thing.shape[0] // n_img, int(g[f"{tag}.width"])) and cents.shape[0] + 1 == onehot.shape[-1]
+        assert np.array_equal(onehot.argmax(-1).reshape(-1).numpy().astype(np.int16), g[f"{tag}.labels"])

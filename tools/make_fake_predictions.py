@@ -20,3 +20,15 @@ def write_fake_predictions(out_dir, names, sems, insts, rng, flip=0.08):
         pi = np.where(rng.uniform(0, 1, sem.shape) < flip, rng.integers(0, n_inst + 1, sem.shape), perm[inst])
         Image.fromarray(ps.astype(np.uint8)).save(os.path.join(out_dir, "pred_semantics", f"{name}.png"))
         Image.fromarray(pi.astype(np.uint16)).save(os.path.join(out_dir, "pred_surrogateid", f"{name}.png"))
+
+
+def fake_thing_features(seed=171, n_img=2, per=36000):
+    """(n_img * per, 1 + 3) rendered "thing feature" rows as render_panopli.py collects them: column 0 is -inf for thing pixels
+    and +inf for stuff pixels, columns 1..3 are instance embeddings drawn around four well separated centres."""
+    rng = np.random.default_rng(seed)
+    centers = np.array([[0.0, 0.0, 0.0], [1.0, 0.2, -0.3], [-0.4, 0.9, 0.5], [0.5, -0.8, 0.7]])
+    feats = np.concatenate([c + 0.06 * rng.standard_normal((n_img * per // len(centers), 3)) for c in centers]).astype(np.float32)
+    feats = feats[rng.permutation(feats.shape[0])]
+    thing = rng.uniform(0, 1, feats.shape[0]) < 0.85                   # 61 k thing pixels >= the reference's 50 k subsample
+    first = np.where(thing, -np.inf, np.inf).astype(np.float32)
+    return np.concatenate([first[:, None], feats], 1), n_img
