@@ -142,6 +142,58 @@ def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000,
     return onehot.view(num_images, -1, K1), ms.cluster_centers_ / factor + bias
 
 
+def cluster_segmentwise(all_thing_features, all_points_semantics, bandwidth, device, num_images, num_points=50000, use_silverman=False):
+    """RP:265-368 (MeanShift branch): the clustering of ``cluster`` run separately inside every predicted thing class, labels of
+    successive classes offset so they stay disjoint; classes with fewer than 100 (filtered) points get no instances (-1).
+    Returns (one-hot (num_images, P, max label + 2) float64, concatenated centroids in feature units).  Like the reference,
+    a class that is skipped for having too few points still appends the previous class's centroids (rescaled with its own
+    statistics) to the returned list -- only the one-hot output is consumed by the render script."""
+    from sklearn.cluster import MeanShift
+    sem = torch.cat([s_.cpu() for s_ in all_points_semantics], 0).argmax(-1).numpy()
+    feats = np.asarray(all_thing_features)
+    thing = feats[..., 0] == -float("inf")
+    f_th = feats[thing][:, 1:]
+    n_all = feats.shape[0]
+    th_sem = sem[thing]
+    all_labels = np.zeros(n_all, dtype=np.int32)
+    th_labels = np.zeros(f_th.shape[0], dtype=np.int32)
+    max_label = 0
+    cents_all, centroids = [], None
+    for cls in np.unique(th_sem):
+        m = th_sem == cls
+        fc = f_th[m]
+        mu, sd = fc.mean(axis=0), fc.std(axis=0)
+        cf = fc[np.all(np.abs(fc - mu) < 3 * sd, axis=1)]
+        if cf.shape[0] == 0:
+            th_labels[m] = -1
+            continue
+        bias = cf.min(axis=0)
+        factor = 1 / (cf.max(axis=0) - cf.min(axis=0))
+        cr = (cf - bias) * factor
+        idx = np.arange(cr.shape[0]) if cr.shape[0] < num_points else np.random.choice(cr.shape[0], num_points, replace=False)
+        pts = cr[idx]
+        if pts.shape[0] < 100:                                      # too few points for MeanShift
+            lab = -1 * np.ones(fc.shape[0], dtype=np.int32)
+        else:
+            bw = bandwidth
+            if use_silverman:
+                from scipy.stats import gaussian_kde
+                bw = gaussian_kde(pts.T, bw_method="silverman").covariance_factor()
+            ms = MeanShift(bandwidth=bw, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(pts)
+            centroids = ms.cluster_centers_
+            lab = ms.predict((fc.reshape(-1, fc.shape[-1]) - bias) * factor)
+        if centroids is not None:
+            cents_all.append(centroids / factor + bias)
+        lab[lab != -1] += max_label
+        if np.any(lab != -1):
+            max_label = lab.max() + 1
+        th_labels[m] = lab
+    all_labels[thing] = th_labels
+    all_labels[~thing] = -1
+    onehot = _one_hot(torch.as_tensor(all_labels, dtype=torch.int64, device=device), num_images, device)
+    return onehot, (np.concatenate(cents_all, axis=0) if cents_all else np.zeros((0, f_th.shape[1])))
+
+
 def psnr(image_pred, image_gt):
     """util/metrics.py:25-26."""
     return -10 * torch.log10(torch.mean((image_pred.detach() - image_gt) ** 2))

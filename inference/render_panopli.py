@@ -81,9 +81,9 @@ def glasbey(n):
 
 def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth=0.15, use_dbscan=False, segmentwise=False,
                               cached_centroids_path=None, device="cuda:0", use_silverman=False):
-    if use_dbscan or segmentwise:
-        raise NotImplementedError("HDBSCAN / segment-wise clustering are CPU post-processing variants not built here "
-                                  "(hdbscan is absent from this image); use MeanShift or --cached_centroids_path")
+    if use_dbscan:
+        raise NotImplementedError("--use_dbscan needs the hdbscan package, which is not installed in this image; use MeanShift "
+                                  "(default, optionally --segmentwise / --use_silverman) or --cached_centroids_path")
     out = output_dirname(config, trajectory_name, test_only, use_dbscan, segmentwise)
     out.mkdir(exist_ok=True, parents=True)
     # launched under torch.distributed.run: one process per GPU, every frame rendered as row-tiles (one per rank) and
@@ -136,7 +136,10 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
             cents = pickle.load(f)
         insts = inf.assign_clusters(all_thing, sems, cents, device, num_images=len(rgbs))
     else:
-        insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
+        if not segmentwise:
+            insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
+        else:
+            insts, _ = inf.cluster_segmentwise(all_thing, sems, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
     for d in ("vis_semantics_and_surrogate", "pred_semantics", "pred_surrogateid"):
         (out / d).mkdir(exist_ok=True)
     for j, frame_name in enumerate(names):

@@ -772,6 +772,15 @@ def g17_meanshift_clustering():
             onehot = RP.cluster(all_thing.copy(), kw["bandwidth"], torch.device("cpu"), num_images=n_img, use_silverman=kw.get("use_silverman", False))
         out[f"{tag}.labels"] = onehot.argmax(-1).reshape(-1).numpy().astype(np.int16)
         out[f"{tag}.width"] = onehot.shape[-1]
+    # segment-wise variant (RP:265-368): one clustering per predicted thing class, incl. a class below the 100-point minimum
+    from make_fake_predictions import fake_semantics_for
+    sems = fake_semantics_for(all_thing, n_img)
+    np.random.seed(4321)
+    with quiet():
+        onehot, cents = RP.cluster_segmentwise(all_thing.copy(), sems, 0.15, torch.device("cpu"), num_images=n_img)
+    out["seg.labels"] = onehot.argmax(-1).reshape(-1).numpy().astype(np.int16)
+    out["seg.width"] = onehot.shape[-1]
+    out["seg.centroids"] = cents
     npz("g17_meanshift_clustering", **out)
 
 

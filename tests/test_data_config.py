@@ -168,3 +168,21 @@ def test_g17_meanshift_clustering_vs_reference():
         onehot, cents = cluster(all_thing.copy(), 0.15, torch.device("cpu"), num_images=n_img, use_silverman=silver)
         assert onehot.shape == (n_img, all_thing.shape[0] // n_img, int(g[f"{tag}.width"])) and cents.shape[0] + 1 == onehot.shape[-1]
         assert np.array_equal(onehot.argmax(-1).reshape(-1).numpy().astype(np.int16), g[f"{tag}.labels"])
+
+
+def test_g17_segmentwise_clustering_vs_reference():
+    """inference.cluster_segmentwise against the REFERENCE's cluster_segmentwise (RP:265-368): per-class MeanShift with disjoint
+    label offsets, a class below the 100-point minimum, the returned centroid list (incl. the reference's re-appended ones)."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from make_fake_predictions import fake_thing_features, fake_semantics_for
+    from contrastive_lift_amd.inference import cluster_segmentwise
+    g = load_golden("g17_meanshift_clustering")
+    all_thing, n_img = fake_thing_features(int(g["seed"]))
+    sems = fake_semantics_for(all_thing, n_img)
+    np.random.seed(4321)
+    onehot, cents = cluster_segmentwise(all_thing.copy(), sems, 0.15, torch.device("cpu"), num_images=n_img)
+    assert onehot.shape[-1] == int(g["seg.width"])
+    assert np.array_equal(onehot.argmax(-1).reshape(-1).numpy().astype(np.int16), g["seg.labels"])
+    np.testing.assert_allclose(cents, g["seg.centroids"], rtol=1e-6, atol=1e-7)

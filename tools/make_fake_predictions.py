@@ -32,3 +32,19 @@ def fake_thing_features(seed=171, n_img=2, per=36000):
     thing = rng.uniform(0, 1, feats.shape[0]) < 0.85                   # 61 k thing pixels >= the reference's 50 k subsample
     first = np.where(thing, -np.inf, np.inf).astype(np.float32)
     return np.concatenate([first[:, None], feats], 1), n_img
+
+
+def fake_semantics_for(all_thing, n_img, seed=181, n_classes=5):
+    """Per-image (P, n_classes) semantic score tensors consistent with ``all_thing``: stuff rows score highest on class 0 or 1,
+    thing rows on class 2, 3 or 4 -- class 2 by the sign of the first embedding coordinate, class 4 for ~60 rows only (so that
+    one class falls under the 100-point MeanShift minimum)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    thing = all_thing[:, 0] == -np.inf
+    cls = np.where(thing, np.where(all_thing[:, 1] > 0.3, 2, 3), rng.integers(0, 2, all_thing.shape[0]))
+    few = np.flatnonzero(thing)[rng.permutation(int(thing.sum()))[:60]]
+    cls[few] = 4
+    scores = rng.standard_normal((all_thing.shape[0], n_classes)).astype(np.float32)
+    scores[np.arange(all_thing.shape[0]), cls] += 6.0
+    per = all_thing.shape[0] // n_img
+    return [torch.from_numpy(scores[i * per:(i + 1) * per].copy()) for i in range(n_img)]
