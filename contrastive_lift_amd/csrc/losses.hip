@@ -100,6 +100,63 @@ extern "C" int clift_pixel_losses(const float* rgb, const float* rgb_gt, const f
     return clift_check_launch("clift_pixel_losses");
 }
 
+// ============================================================================ segment consistency (T:185-197)
+// The per-segment mean of the rendered semantic features (torch_scatter.scatter_mean) picks one class per 2D segment; every
+// ray of the segment is pulled towards it with the class-weighted, confidence-weighted cross entropy.
+__global__ __launch_bounds__(256) void k_segment_sums(const float* __restrict__ f, int ld, const int* __restrict__ group, int B, int C,
+                                                       float* __restrict__ sums, float* __restrict__ counts) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)B * C) return;
+    const int i = (int)(gid / C), c = (int)(gid - (long)i * C);
+    const int g = group[i];
+    unsafeAtomicAdd(sums + (size_t)g * C + c, f[(size_t)i * ld + c]);
+    if (c == 0) unsafeAtomicAdd(counts + g, 1.f);
+}
+
+__global__ __launch_bounds__(256) void k_segment_ce(const float* __restrict__ f, int ld, const int* __restrict__ group, const float* __restrict__ conf,
+                                                     const float* __restrict__ cw, int B, int C, const float* __restrict__ sums, float scale,
+                                                     float* __restrict__ loss, float* __restrict__ grad, int ldg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (i < B) {
+        const float* x = f + (size_t)i * ld;
+        const float* m = sums + (size_t)group[i] * C;      // argmax of the sums = argmax of the means (first maximum, like torch)
+        int t = 0;
+        float best = m[0], mx = x[0];
+        for (int c = 1; c < C; ++c) {
+            if (m[c] > best) { best = m[c]; t = c; }
+            mx = fmaxf(mx, x[c]);
+        }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+        const float lse = mx + logf(se);
+        const float w = cw[t] * conf[i];
+        li = -w * (x[t] - lse);
+        if (grad) {
+            const float k = scale * w / (float)B;
+            float* gr = grad + (size_t)i * ldg;
+            for (int c = 0; c < C; ++c) gr[c] = k * (expf(x[c] - lse) - (c == t ? 1.f : 0.f));
+        }
+    }
+    // block reduction of the loss
+    __shared__ float sh[4];
+    for (int d = 32; d > 0; d >>= 1) li += __shfl_xor(li, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = li;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (sh[0] + sh[1] + sh[2] + sh[3]) / (float)B);
+}
+
+extern "C" int clift_segment_loss(const float* feats, int ld, const int* group, const float* conf, const float* class_w, int B, int C, int G,
+                                  float scale, float* work, float* loss, float* grad, int ldg, clift_stream_t s) {
+    CLIFT_REQUIRE(C >= 1 && G >= 1, "clift_segment_loss: C and G must be positive");
+    if (B <= 0) return 0;
+    hipStream_t st = as_stream(s);
+    CLIFT_REQUIRE(hipMemsetAsync(work, 0, sizeof(float) * ((size_t)G * C + G), st) == hipSuccess, "clift_segment_loss: memset of the work buffer failed");
+    k_segment_sums<<<cdiv((long)B * C, 256), 256, 0, st>>>(feats, ld, group, B, C, work, work + (size_t)G * C);
+    k_segment_ce<<<cdiv(B, 256), 256, 0, st>>>(feats, ld, group, conf, class_w, B, C, work, scale, loss, grad, ldg);
+    return clift_check_launch("clift_segment_loss");
+}
+
 // ============================================================================ contrastive_loss (model/loss/loss.py:62-82)
 // l_ij = exp(exp(-d2_ij / tau_ij)), tau = temperature for positive pairs (same label, i != j) and 1 otherwise;
 // p_i = sum_j l_ij [pos], Z_i = sum_j l_ij (diagonal included); loss = -sum_{p_i != 0} log(p_i / Z_i) / B.

@@ -112,6 +112,41 @@ class SceneTables:
                                                  confidences=conf[m]))
         return self.tables
 
+    def build_segment_tables(self):
+        """Segment*Dataset (many_object_scenes.py:334-395, panopli.py:372-432): for every training frame and every non-zero id
+        of its 2D segment map, the rays of that segment and their confidences (room-masked pixels at 0).  The reference
+        builds this at a FIXED (128, 128) image size (dataset/__init__.py:70,78); call it on a scene constructed that way."""
+        H, W = self.image_dim
+        self.segment_items = []
+        for i in self.train_indices:
+            rays = self.rays_for(i)
+            t = self.load_targets(i)
+            conf = (t["confidences"] * t["mask"].to(torch.float32)).to(self.device)
+            seg = self.load_segments(i).to(self.device)
+            for sid in torch.unique(seg).tolist():
+                if sid != 0:
+                    m = seg == sid
+                    self.segment_items.append(dict(rays=rays[m], confidences=conf[m]))
+        return self.segment_items
+
+    def segment_batch(self, batch_size_segments, max_rays, batch_index):
+        """One collated batch[2] (DataLoader(shuffle=False, drop_last=True) + collate_fn): ``batch_size_segments`` consecutive
+        segments, each subsampled to ``max_rays`` rays, group = position of the segment in the batch."""
+        n_batches = len(self.segment_items) // batch_size_segments
+        if n_batches == 0:
+            return None
+        b0 = (batch_index % n_batches) * batch_size_segments
+        rays, conf, group = [], [], []
+        for j in range(batch_size_segments):
+            it = self.segment_items[b0 + j]
+            n = it["rays"].shape[0]
+            if n > max_rays:
+                sel = torch.randperm(n, device=self.device)[:max_rays]
+                it = {k: v[sel] for k, v in it.items()}
+            rays.append(it["rays"]); conf.append(it["confidences"])
+            group.append(torch.full((it["rays"].shape[0],), j, dtype=torch.int32, device=self.device))
+        return dict(rays=torch.cat(rays).contiguous(), confidences=torch.cat(conf).contiguous(), group=torch.cat(group), n_groups=batch_size_segments)
+
     def pixel_batch(self, batch_size, generator=None):
         n = self.tables["rays"].shape[0]
         idx = torch.randint(0, n, (batch_size,), device=self.device, generator=generator)
@@ -168,6 +203,12 @@ class MOSScene(SceneTables):
         self._finish_cameras(K, poses, img_h, img_w, max_depth)
         self.segmentation_data = type("Seg", (), dict(fg_classes=[1], bg_classes=[0], num_semantic_classes=2, num_instances=1))()
         self.num_semantics = 2
+
+    def load_segments(self, sample_index):
+        """:349-351: the 2D segment map of a frame = the machine-generated instance map (detic_instance), NEAREST-resized."""
+        H, W = self.image_dim
+        seg = np.load(os.path.join(self.root, "detic_instance", f"{self.all_frame_names[sample_index]}.npy"))
+        return torch.from_numpy(np.array(Image.fromarray(seg.astype(np.int16)).resize((W, H), Image.NEAREST))).long().reshape(-1)
 
     def load_targets(self, sample_index):
         """:146-207 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,2), confidences (HW,)."""

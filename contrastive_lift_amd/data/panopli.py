@@ -58,6 +58,12 @@ class PanopLiScene(SceneTables):
                                                       num_semantic_classes=len(fg) + len(bg), num_instances=len(fg)))()
         self.num_semantics = len(fg) + len(bg)
 
+    def load_segments(self, sample_index):
+        """:387-388: m2f_segments/<frame>.png, NEAREST-resized."""
+        H, W = self.image_dim
+        seg = Image.open(os.path.join(self.root, "m2f_segments", f"{self.all_frame_names[sample_index]}.png"))
+        return torch.from_numpy(np.array(seg.resize((W, H), Image.NEAREST))).long().reshape(-1)
+
     def load_targets(self, sample_index):
         """:129-198 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,C), confidences (HW,), mask."""
         H, W = self.image_dim

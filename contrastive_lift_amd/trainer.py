@@ -26,6 +26,8 @@ def default_config(**over):
              max_rays_instances=1024, max_instances=3, instance_loss_mode="slow_fast", use_DINO_style=True,
              semantic_weight_mode="softmax", stop_semantic_grad=True, probabilistic_ce_mode="TTAConf", weight_class_0=0.0,
              decay_step=[9, 10], decay_gamma=0.5, temperature=100.0,
+             lambda_segment=1.2, segment_grouping_mode="argmax_conf", segment_optimization_epoch=6, batch_size_segments=32,
+             max_rays_segments=1024,
              mlp_dtype="fp32")     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
     c.update(over)
     return types.SimpleNamespace(**c)
@@ -93,9 +95,11 @@ class HotPathTrainer:
             g.mul_(1.0 / self.world)
 
     # ------------------------------------------------------------------ main pass (T:151-208)
-    def main_pass(self, batch, jitter=None, white_bg=None, lean=False):
+    def main_pass(self, batch, jitter=None, white_bg=None, lean=False, segments=None, segment_jitter=None):
         """batch: dict with rays (B,8), rgbs (B,3), probabilities (B,C), confidences (B,), mask (B,) bool/float.
-        ``lean`` skips the instance heads, whose output the reference's main pass computes and discards (T:155)."""
+        ``lean`` skips the instance heads, whose output the reference's main pass computes and discards (T:155).
+        ``segments``: dict with rays (Bs,8), group (Bs,) int segment index, confidences (Bs,), n_groups -- the segment-consistency
+        term of T:185-197 (batch[2]); it is part of the main loss, i.e. its gradient joins this pass's backward and Adam step."""
         c, m, r = self.config, self.model, self.renderer
         rays = batch["rays"]
         B = rays.shape[0]
@@ -131,12 +135,37 @@ class HotPathTrainer:
         for k, ctx in enumerate(ctxs):
             s = slice(k * chunk, k * chunk + ctx.N)
             engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True)
+        if segments is not None and sem_on and float(getattr(c, "lambda_segment", 0.0)) != 0.0:
+            self._segment_term(segments, segment_jitter, gv, w_sem * float(c.lambda_segment))
         tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         self.losses[2] = tv
         self._allreduce(self.main_range)
         self.opt_main.step()
         self.last_outputs = (rgb, sem)
         return ctxs
+
+    def _segment_term(self, seg, jitter, gv, weight):
+        """T:185-197: render the semantic features of the segment rays (renderer.forward_segment_feature), take the class of
+        the per-segment mean feature, cross entropy of every ray against it (class weights, confidences); ``weight`` =
+        lambda_semantics * lambda_segment scales the gradient that is accumulated into the semantic head."""
+        c, m, r = self.config, self.model, self.renderer
+        rays = seg["rays"]
+        n = rays.shape[0]
+        if n == 0:
+            return
+        if jitter is None and c.perturb != 0:
+            jitter = c.perturb * torch.rand(n, device=self.device)
+        feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic")
+        C = feats.shape[1]
+        G = int(seg["n_groups"])
+        group = seg["group"].to(device=self.device, dtype=torch.int32).contiguous()
+        conf = seg["confidences"].to(self.device, torch.float32).contiguous()
+        work = torch.empty((G * C + G,), dtype=torch.float32, device=self.device)
+        grad = torch.empty_like(feats)
+        self.loss_segment = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.call("clift_segment_loss", _lib.ptr(feats), feats.stride(0), _lib.ptr(group), _lib.ptr(conf), _lib.ptr(self.class_weights), n, C, G,
+                  float(weight), _lib.ptr(work), _lib.ptr(self.loss_segment), _lib.ptr(grad), grad.stride(0), _lib.stream())
+        engine.feature_backward(m, ctx, gv, grad)
 
     # ------------------------------------------------------------------ instance pass (T:210-222, 256-310)
     def instance_pass(self, inst_batch, jitter=None):
@@ -178,7 +207,9 @@ class HotPathTrainer:
 
     def training_step(self, batch, lean=False):
         """batch[0] = pixel batch dict, batch[1] = list of instance-image dicts (reference CombinedLoader layout)."""
-        self.main_pass(batch[0], lean=lean)
+        seg = batch.get(2) if (getattr(self.config, "segment_grouping_mode", "none") != "none" and
+                               self.current_epoch >= self.config.segment_optimization_epoch) else None
+        self.main_pass(batch[0], lean=lean, segments=seg)
         if self.current_epoch >= self.config.instance_optimization_epoch and batch.get(1):
             self.instance_pass(batch[1])
 

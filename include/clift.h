@@ -210,6 +210,13 @@ int clift_pixel_losses(const float* rgb, const float* rgb_gt, const float* sem, 
                        const float* conf, const float* class_w, const float* maskf, int N, int C, float w_rgb,
                        float w_sem, float* out2, float* g_rgb, float* g_sem, clift_stream_t s);
 
+/* ---- segment-consistency term of training_step (trainer/train_panopli_tensorf.py:185-197): feats (B, ld) rendered semantic
+ * features of the rays of G 2D segments, group (B) segment index of each ray.  target class of a segment = argmax of the mean
+ * feature row (torch_scatter.scatter_mean); loss[0] += mean_i( class_w[t_i] conf_i CE(feats_i, t_i) ); grad (B, ldg), nullable,
+ * = scale * d loss / d feats.  work >= G*C + G floats (zeroed by the call). */
+int clift_segment_loss(const float* feats, int ld, const int* group, const float* conf, const float* class_w, int B,
+                       int C, int G, float scale, float* work, float* loss, float* grad, int ldg, clift_stream_t s);
+
 /* ---- a16: model/loss/loss.py:62-82.  loss[0] = value; g_feat (B,E) = d loss / d features (nullable). */
 int clift_contrastive(const float* feat, const int* labels, int B, int E, float temperature, float* loss,
                       float* g_feat, float* work /* >= 4*B floats */, clift_stream_t s);

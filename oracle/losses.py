@@ -80,3 +80,13 @@ def semantic_ce(log_probs, target_probs, conf, class_weight):
     """CrossEntropyLoss(reduction='none', weight=w) applied to the renderer's log-probabilities with soft
     targets, times per-pixel confidence, mean (trainer/train_panopli_tensorf.py:75,177-178)."""
     return (F.cross_entropy(log_probs, target_probs, weight=class_weight, reduction="none") * conf).mean()
+
+
+def segment_consistency(seg_features, group, conf, class_weight, n_groups):
+    """trainer/train_panopli_tensorf.py:189-194: the per-segment mean of the rendered semantic features (torch_scatter.scatter_mean
+    restated: sum / max(count, 1)) picks ONE class per 2D segment (argmax); every ray of the segment is then pulled towards it:
+    mean over rays of CrossEntropyLoss(reduction='none', weight=w)(features, class) * confidence."""
+    mean = torch.zeros(n_groups, seg_features.shape[1]).index_add_(0, group, seg_features)
+    cnt = torch.zeros(n_groups).index_add_(0, group, torch.ones(group.shape[0])).clamp_(min=1)
+    target = (mean / cnt[:, None])[group].argmax(-1)
+    return (F.cross_entropy(seg_features, target, weight=class_weight, reduction="none") * conf).mean()

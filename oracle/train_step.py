@@ -19,10 +19,11 @@ GRID_KEYS = ("density_plane", "density_line", "appearance_plane", "appearance_li
 class CpuTrainer:
     def __init__(self, P, cfg, lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
                  lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True,
-                 instance_loss_mode="slow_fast", temperature=100.0, use_delta=False):
+                 instance_loss_mode="slow_fast", temperature=100.0, use_delta=False, lambda_segment=1.2):
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
         self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
         self.inst_mode, self.temperature, self.use_delta = instance_loss_mode, temperature, use_delta
+        self.l_seg = lambda_segment
         self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
         self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
         grids = [v for k, v in self.P.items() if k.startswith(GRID_KEYS)]
@@ -39,7 +40,9 @@ class CpuTrainer:
         if class_weights is None:
             self.cw[0] = 0.0
 
-    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None):
+    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None, segments=None):
+        """``segments`` = dict(rays, group, conf, jitter, n_groups): the segment-consistency term of T:185-197 (active from
+        segment_optimization_epoch on in the shipped configs)."""
         self.opt_main.zero_grad(set_to_none=True)
         for p in self.fast + self.slow:
             p.grad = None
@@ -57,9 +60,15 @@ class CpuTrainer:
         l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva)
         l_sem = olosses.semantic_ce(sem, probs, conf, self.cw)
         loss = self.l_rgb * (l_rgb + l_tv + dreg * self.l_dist) + self.l_sem * l_sem
+        l_seg = torch.zeros(())
+        if segments is not None:
+            feats = orender.render_segment_feature(self.P, segments["rays"], self.cfg, segments["jitter"])
+            l_seg = olosses.segment_consistency(feats, segments["group"], segments["conf"], self.cw, segments["n_groups"])
+            loss = loss + self.l_sem * self.l_seg * l_seg
         loss.backward()
         self.opt_main.step()
-        return dict(rgb=rgb.detach(), sem=sem.detach(), loss_rgb=l_rgb.detach(), loss_sem=l_sem.detach(), loss_tv=l_tv.detach())
+        return dict(rgb=rgb.detach(), sem=sem.detach(), loss_rgb=l_rgb.detach(), loss_sem=l_sem.detach(), loss_tv=l_tv.detach(),
+                    loss_segment=l_seg.detach())
 
     def instance_pass(self, rays, labels, conf, jitter):
         self.opt_inst.zero_grad(set_to_none=True)

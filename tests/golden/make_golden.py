@@ -75,7 +75,15 @@ def install_stand_ins():
           DummyExperiment=_Inert, rank_zero_experiment=lambda f: f)
     _fake("hydra", main=lambda **k: (lambda f: f))
     _fake("omegaconf", OmegaConf=_Inert)
-    _fake("torch_scatter", scatter_mean=_Inert())
+    def _scatter_mean(src, index, dim=0, out=None):
+        """torch_scatter.scatter_mean(src, index, 0, out) restated (third-party, requirements.txt:36): per-index mean of the
+        rows of src written into out (sum / max(count, 1))."""
+        assert dim == 0 and out is not None
+        out.index_add_(0, index, src)
+        cnt = torch.zeros(out.shape[0], dtype=src.dtype).index_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype)).clamp_(min=1)
+        out.div_(cnt[:, None])
+        return out
+    _fake("torch_scatter", scatter_mean=_scatter_mean)
 
 
 def quiet():
@@ -439,7 +447,7 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
-def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3):
+def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -457,10 +465,11 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     B, Bi, epoch = 96, 64, 4
     cfg = _t.SimpleNamespace(
         lr=5e-4, weight_decay=1e-8, decay_step=[9, 10], decay_gamma=0.5, warmup_epochs=0, chunk=40, perturb=1.0,
-        optimize_instance_only=False, lambda_rgb=1.0, lambda_semantics=0.1, lambda_feat=0.0, lambda_segment=0.0,
+        optimize_instance_only=False, lambda_rgb=1.0, lambda_semantics=0.1, lambda_feat=0.0, lambda_segment=(1.2 if segments else 0.0),
         lambda_tv_density=0.1, lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02,
         use_distilled_features_semantic=False, use_distilled_features_instance=False, feature_optimization_end_epoch=0,
-        late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=100, segment_grouping_mode="none",
+        late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=(2 if segments else 100),
+        segment_grouping_mode=("argmax_conf" if segments else "none"), batch_size_segments=6, chunk_segment=50,
         probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E)
     m = build_reference_model(P, res, C, E, shift=-3.0, slow_fast=(mode == "slow_fast"))
     rr = build_reference_renderer(aabb, res, "softmax")
@@ -471,6 +480,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
         configure_optimizers = T.TensoRFTrainer.configure_optimizers
         forward = T.TensoRFTrainer.forward
         forward_instance = T.TensoRFTrainer.forward_instance
+        forward_segments = T.TensoRFTrainer.forward_segments
         training_step = T.TensoRFTrainer.training_step
         calculate_instance_clustering_loss = T.TensoRFTrainer.calculate_instance_clustering_loss
         ema_update_slownet = T.TensoRFTrainer.ema_update_slownet
@@ -543,11 +553,25 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
                         f"s{st}.mask": mask.clone(), f"s{st}.irays": irays.clone(), f"s{st}.labels": labels.clone(), f"s{st}.iconf": iconf.clone()})
             batch = {0: dict(rays=rays, rgbs=rgbs, semantics=sem, probabilities=probs, confidences=confs, mask=mask, feats=torch.zeros(B, 1)),
                      1: dict(rays=[irays], instances=[labels], confidences=[iconf])}
+            if segments:       # batch[2] in the collate layout of Segment*Dataset (:389-395): per-segment ray lists, group = segment index
+                sizes = [int(x) for x in rng.integers(5, 40, size=cfg.batch_size_segments)]
+                sr = [pool[torch.from_numpy(rng.choice(pool.shape[0], size=n, replace=False))].clone() for n in sizes]
+                sc = [torch.from_numpy(rng.uniform(0, 1, (n,)).astype(np.float32)) for n in sizes]
+                sg = [torch.ones(n).long() * i for i, n in enumerate(sizes)]
+                out.update({f"s{st}.srays": torch.cat(sr), f"s{st}.sconf": torch.cat(sc), f"s{st}.sgroup": torch.cat(sg)})
+                batch[2] = dict(rays=sr, confidences=sc, group=sg)
             draws.clear()
             torch.manual_seed(1000 + st)
             sh.training_step(batch, st)
-            jit = torch.cat([v for k, v in draws if k == "jit"][: (B + cfg.chunk - 1) // cfg.chunk])
-            ijit = torch.cat([v for k, v in draws if k == "jit"][(B + cfg.chunk - 1) // cfg.chunk:])
+            nmain = (B + cfg.chunk - 1) // cfg.chunk
+            jits = [v for k, v in draws if k == "jit"]
+            jit = torch.cat(jits[:nmain])
+            if segments:       # draw order inside training_step: main chunks, segment chunks, instance chunks
+                nseg = (out[f"s{st}.srays"].shape[0] + cfg.chunk_segment - 1) // cfg.chunk_segment
+                out[f"s{st}.sjitter"] = torch.cat(jits[nmain:nmain + nseg])
+                out[f"s{st}.loss_segment"] = np.float32(sh.logged["train/loss_segment"][-1])
+                jits = jits[:nmain] + jits[nmain + nseg:]
+            ijit = torch.cat(jits[nmain:])
             coins = torch.cat([v for k, v in draws if k == "coin"])
             assert jit.numel() == B and ijit.numel() == Bi and coins.numel() == (B + cfg.chunk - 1) // cfg.chunk, (jit.shape, ijit.shape, coins.shape)
             out.update({f"s{st}.jitter": jit, f"s{st}.ijitter": ijit, f"s{st}.white": (coins < 0.5)})
@@ -643,6 +667,15 @@ def g14_mos_dataset():
                             f"{tag}.f{f}.rays": ds.all_rays[sl], f"{tag}.f{f}.rgbs": ds.all_rgbs[sl], f"{tag}.f{f}.semantics": ds.all_semantics[sl],
                             f"{tag}.f{f}.instances": ds.all_instances[sl], f"{tag}.f{f}.probabilities": ds.all_probabilities[sl],
                             f"{tag}.f{f}.confidences": ds.all_confidences[sl], f"{tag}.f{f}.mask": ds.all_masks[sl]})
+            if tag == "native":       # the segment dataset of the segment-consistency loss (many_object_scenes.py:334-395), at (32, 32)
+                from dataset.many_object_scenes import SegmentMOSDataset
+                with quiet():
+                    sd_ = SegmentMOSDataset(pathlib.Path(root), "train", (32, 32), 3.0, max_rays=64, semantics_dir="detic_semantic",
+                                            instance_dir="detic_instance", instance_to_semantic_key=None, create_seg_data_func=None)
+                out["seg.count"] = len(sd_)
+                out["seg.sizes"] = np.array([r.shape[0] for r in sd_.all_rays])
+                for k_ in (0, len(sd_) - 1):
+                    out[f"seg.{k_}.rays"], out[f"seg.{k_}.conf"] = sd_.all_rays[k_], sd_.all_confidences[k_]
             # predefined camera path (dataset/base.py:320-365, as inference/render_panopli.py:71 requests it)
             ts = ds.get_trajectory_set("trajectory_blender", True)
             out[f"{tag}.traj.len"] = len(ts)
@@ -683,6 +716,15 @@ def g15_panopli_dataset():
                         f"{tag}.fg": np.array(sd.fg_classes), f"{tag}.bg": np.array(sd.bg_classes), f"{tag}.num_classes": sd.num_semantic_classes,
                         f"{tag}.num_instances": sd.num_instances,
                         f"{tag}.i2s": np.array(sorted(sd.instance_to_semantics.items()))})
+            if tag == "native":       # the segment dataset (panopli.py:372-432: m2f_segments/*.png), at (32, 32)
+                from dataset.panopli import SegmentPanopLiDataset
+                with quiet():
+                    sd_ = SegmentPanopLiDataset(pathlib.Path(root), "train", (32, 32), 3.0, max_rays=64, semantics_dir="m2f_semantics", instance_dir="m2f_instance",
+                                                instance_to_semantic_key="m2f_instance_to_semantic", create_seg_data_func=create_segmentation_data_panopli)
+                out["seg.count"] = len(sd_)
+                out["seg.sizes"] = np.array([r.shape[0] for r in sd_.all_rays])
+                for k_ in (0, len(sd_) - 1):
+                    out[f"seg.{k_}.rays"], out[f"seg.{k_}.conf"] = sd_.all_rays[k_], sd_.all_confidences[k_]
             for f in (1, 6):
                 j = ds.train_indices.index(f)
                 sl = slice(j * hw, (j + 1) * hw)
@@ -802,6 +844,7 @@ def main():
     g11_metrics()
     g12_training_steps()
     g12_training_steps(mode="contrastive", use_delta=True, fname="g12c_training_steps_contrastive", steps=2)
+    g12_training_steps(fname="g12s_training_steps_segments", steps=2, segments=True)
     g13_postprocess()
     g14_mos_dataset()
     g15_panopli_dataset()

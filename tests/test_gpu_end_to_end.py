@@ -98,7 +98,8 @@ def test_train_cli_on_panopli_layout(tmp_path, monkeypatch):
     train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli_p")
     run_dir = train.main(["+experiment=contrastive_lift", f"dataset_root={scene_dir}", "image_dim=48", "min_grid_dim=32", "max_grid_dim=48",
                           "max_epoch=6", "steps_per_epoch=400", "batch_size=2048", "chunk=0", "max_depth=3", "seed=3", "max_rays_instances=256",
-                          "decay_step=[4,5]", "late_semantic_optimization=0", "instance_optimization_epoch=1"])
+                          "decay_step=[4,5]", "late_semantic_optimization=0", "instance_optimization_epoch=1",
+                          "segment_optimization_epoch=3"])          # epochs 3..5 also run the segment-consistency term on m2f_segments
     ckpts = sorted(os.listdir(os.path.join(run_dir, "checkpoints")))
     ck = torch.load(os.path.join(run_dir, "checkpoints", ckpts[-1]), map_location="cpu", weights_only=False)
     sd = ck["state_dict"]

@@ -661,7 +661,7 @@ def test_psnr_parity_over_a_training_trajectory():
     print(f"PSNR after {steps} steps: oracle {p_cpu:.3f} dB, HIP {p_gpu:.3f} dB; worst |delta| along the trajectory {worst:.4f} dB")
 
 
-@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive"])
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
@@ -688,7 +688,13 @@ def test_g12_reference_training_steps_on_gpu(fixture):
         assert len(set(white)) == 1          # the recorded coin flips of one step happen to agree: one flag per main pass
         batch0 = dict(rays=d(g[f"s{st}.rays"]), rgbs=d(g[f"s{st}.rgbs"]), probabilities=d(g[f"s{st}.probs"]),
                       confidences=d(g[f"s{st}.confs"]), mask=d(g[f"s{st}.mask"]))
-        tr.main_pass(batch0, jitter=d(g[f"s{st}.jitter"]), white_bg=white[0])
+        seg, sjit = None, None
+        if f"s{st}.srays" in g:          # third fixture: the segment-consistency term (batch[2], T:185-197)
+            seg = dict(rays=d(g[f"s{st}.srays"]), group=d(g[f"s{st}.sgroup"]), confidences=d(g[f"s{st}.sconf"]), n_groups=6)
+            sjit = d(g[f"s{st}.sjitter"])
+        tr.main_pass(batch0, jitter=d(g[f"s{st}.jitter"]), white_bg=white[0], segments=seg, segment_jitter=sjit)
+        if seg is not None:
+            rel_close(tr.loss_segment[0], g[f"s{st}.loss_segment"], 1e-3, what=f"step {st} loss_segment")
         rel_close(tr.losses[0], g[f"s{st}.loss_rgb"], 1e-3, what=f"step {st} loss_rgb")
         rel_close(tr.losses[1], g[f"s{st}.loss_sem"], 1e-3, what=f"step {st} loss_sem")
         tr.instance_pass([dict(rays=d(g[f"s{st}.irays"]), instances=d(g[f"s{st}.labels"]), confidences=d(g[f"s{st}.iconf"]))],
@@ -716,6 +722,18 @@ def test_g13_assign_clusters_vs_reference():
         got = assign_clusters(feats, sems, cents, torch.device(DEV), num_images=n)
         assert tuple(got.shape) == tuple(want.shape)
         assert torch.equal(got.cpu().to(torch.float64), torch.from_numpy(want))
+
+
+def _check_segment_tables(sc, g):
+    """build_segment_tables against the reference's Segment*Dataset: segment count and order, per-segment ray sets / confidences."""
+    items = sc.build_segment_tables()
+    assert len(items) == int(g["seg.count"]) and [it["rays"].shape[0] for it in items] == list(g["seg.sizes"])
+    for k in (0, len(items) - 1):
+        rel_close(items[k]["rays"][:, 0:6], g[f"seg.{k}.rays"][:, 0:6], 1e-5, atol=1e-6, what="segment rays")
+        rel_close(items[k]["confidences"], g[f"seg.{k}.conf"], 1e-6, what="segment confidences")
+    b = sc.segment_batch(4, 10, 1)
+    assert b["n_groups"] == 4 and b["rays"].shape[0] == b["group"].shape[0] == b["confidences"].shape[0] and int(b["group"].max()) == 3
+    assert all(int((b["group"] == j).sum()) <= 10 for j in range(4))
 
 
 def test_g14_mos_ray_tables_vs_reference_dataset(tmp_path):
@@ -753,6 +771,7 @@ def test_g14_mos_ray_tables_vs_reference_dataset(tmp_path):
         rel_close(tabs["rays"][j * hw:(j + 1) * hw], g[f"{tag}.f5.rays"], 1e-4, atol=1e-6, what="table rays")
         assert torch.equal(tabs["mask"][:hw].cpu(), torch.from_numpy(g[f"{tag}.f0.mask"]))
         assert len(sc.instance_images) > 0 and all(int((im["instances"] == 0).sum()) == 0 for im in sc.instance_images)
+    _check_segment_tables(MOSScene(root, "train", (32, 32), float(g["max_depth"]), device=DEV), g)
 
 
 def test_g15_panopli_ray_tables_vs_reference_dataset(tmp_path):
@@ -775,6 +794,7 @@ def test_g15_panopli_ray_tables_vs_reference_dataset(tmp_path):
             rel_close(rays[:, 6:8], ref[:, 6:8], 1e-4, what="near/far")
         tabs = sc.build_train_tables()
         assert tabs["probabilities"].shape[1] == int(g[f"{tag}.num_classes"]) and len(sc.instance_images) > 0
+    _check_segment_tables(PanopLiScene(root, "train", (32, 32), float(g["max_depth"]), device=DEV), g)
 
 
 # ============================================================================ field point API + grid surgery (8f rank 1)

@@ -193,7 +193,7 @@ def test_g11_metrics_vs_reference():
         panoptic_quality(T(g["pq0.preds"]), T(g["pq0.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=False)
 
 
-@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive"])
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -219,8 +219,14 @@ def test_g12_three_reference_training_steps(fixture):
     assert tr.opt_main.param_groups[0]["betas"] == (0.9, 0.99) and tr.opt_inst.param_groups[0]["betas"] == (0.9, 0.999)
     assert all(abs(x["weight_decay"] - og[0, 1]) < 1e-20 for x in tr.opt_main.param_groups + tr.opt_inst.param_groups)
     for st in range(int(g["steps"])):
+        seg = None
+        if f"s{st}.srays" in g:          # third fixture: the segment-consistency term of T:185-197 (batch[2])
+            seg = dict(rays=T(g[f"s{st}.srays"]), group=torch.from_numpy(g[f"s{st}.sgroup"]), conf=T(g[f"s{st}.sconf"]),
+                       jitter=T(g[f"s{st}.sjitter"]), n_groups=6)
         o = tr.main_pass(T(g[f"s{st}.rays"]), T(g[f"s{st}.rgbs"]), T(g[f"s{st}.probs"]), T(g[f"s{st}.confs"]), T(g[f"s{st}.jitter"]),
-                         [bool(x) for x in g[f"s{st}.white"]], mask=torch.from_numpy(g[f"s{st}.mask"]))
+                         [bool(x) for x in g[f"s{st}.white"]], mask=torch.from_numpy(g[f"s{st}.mask"]), segments=seg)
+        if seg is not None:
+            rel_close(o["loss_segment"], g[f"s{st}.loss_segment"], 1e-4, what=f"step {st} loss_segment")
         rel_close(o["loss_rgb"], g[f"s{st}.loss_rgb"], 1e-4, what=f"step {st} loss_rgb")
         rel_close(o["loss_sem"], g[f"s{st}.loss_sem"], 1e-4, what=f"step {st} loss_sem")
         oi = tr.instance_pass(T(g[f"s{st}.irays"]), torch.from_numpy(g[f"s{st}.labels"]), T(g[f"s{st}.iconf"]), T(g[f"s{st}.ijitter"]))

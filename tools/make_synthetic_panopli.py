@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Write a small synthetic scene in the PanopLi on-disk layout (color/*.jpg, intrinsic/intrinsic_color.txt, pose/*.txt,
-m2f_semantics/*.png, m2f_instance/*.png, m2f_probabilities/*.npz, rs_semantics / rs_instance, splits.json,
+m2f_semantics/*.png, m2f_instance/*.png, m2f_segments/*.png, m2f_probabilities/*.npz, rs_semantics / rs_instance, splits.json,
 segmentation_data.pkl, optional invalid/*.jpg): the analytic sphere scene of make_synthetic_mos.py with one semantic class
 per sphere group.  Used by the reader tests; no dataset is available offline.
 Usage: tools/make_synthetic_panopli.py <out_dir> [n_frames] [size]"""
@@ -18,7 +18,7 @@ from make_synthetic_mos import look_at_cv  # noqa: E402
 
 def make_scene(out, n_frames=12, size=32, seed=0, invalid_frames=(), n_classes=5):
     rng = np.random.default_rng(seed)
-    for d in ("color", "intrinsic", "pose", "m2f_semantics", "m2f_instance", "m2f_probabilities", "rs_semantics", "rs_instance"):
+    for d in ("color", "intrinsic", "pose", "m2f_semantics", "m2f_instance", "m2f_segments", "m2f_probabilities", "rs_semantics", "rs_instance"):
         os.makedirs(os.path.join(out, d), exist_ok=True)
     centers = np.array([[0.0, 0.0, 0.35], [0.75, 0.15, 0.3], [-0.6, 0.55, 0.28], [-0.2, -0.75, 0.3], [0.5, -0.6, 0.25]])
     radii = np.array([0.35, 0.3, 0.28, 0.3, 0.25])
@@ -69,7 +69,8 @@ def make_scene(out, n_frames=12, size=32, seed=0, invalid_frames=(), n_classes=5
         pose[:3, :3], pose[:3, 3] = Rcv, eye                # camera-to-world, OpenCV axes
         np.savetxt(os.path.join(out, "pose", name + ".txt"), pose)
         perm = np.concatenate([[0], 1 + rng.permutation(len(centers))])      # per-view inconsistent machine ids
-        for dname, arr in (("m2f_semantics", sem), ("rs_semantics", sem), ("rs_instance", inst), ("m2f_instance", perm[inst])):
+        segs = np.where(sem == 1, len(centers) + 1, perm[inst])              # 2D segments: every sphere + the floor region
+        for dname, arr in (("m2f_semantics", sem), ("rs_semantics", sem), ("rs_instance", inst), ("m2f_instance", perm[inst]), ("m2f_segments", segs)):
             Image.fromarray(arr.reshape(size, size).astype(np.uint8)).save(os.path.join(out, dname, name + ".png"))
         logits = rng.standard_normal((size, size, n_classes)) + 4.0 * np.eye(n_classes)[sem.reshape(size, size)]
         prob = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)

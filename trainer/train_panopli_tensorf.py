@@ -62,6 +62,10 @@ def main(argv):
     cfg.segment_optimization_epoch = cfg.segment_optimization_epoch + cfg.late_semantic_optimization       # T:47
     scene = get_scene(cfg, "train", dev)
     scene.build_train_tables()
+    seg_scene = None
+    if cfg.segment_grouping_mode != "none" and int(cfg.segment_optimization_epoch) < int(cfg.max_epoch):
+        seg_scene = get_scene(cfg, "train", dev, image_dim=(128, 128))         # get_segment_dataset: always (128, 128) (dataset/__init__.py:70,78)
+        seg_scene.build_segment_tables()
     val = get_scene(cfg, "val", dev)
     total_classes = len(scene.segmentation_data.bg_classes) + len(scene.segmentation_data.fg_classes)      # T:51
     slow_fast = cfg.instance_loss_mode == "slow_fast"
@@ -107,6 +111,10 @@ def main(argv):
             batch = {0: scene.pixel_batch(per_rank, gen)}
             if epoch >= cfg.instance_optimization_epoch and scene.instance_images:
                 batch[1] = scene.instance_batch(int(cfg.max_rays_instances), gstep * world + rank)
+            if seg_scene is not None and epoch >= cfg.segment_optimization_epoch:                                   # T:458-459
+                sb = seg_scene.segment_batch(int(cfg.batch_size_segments), int(cfg.max_rays_segments), gstep * world + rank)
+                if sb is not None:
+                    batch[2] = sb
             tr.training_step(batch)
             gstep += 1
             if rank == 0 and gstep % int(cfg.save_every_n_train_steps) == 0:
@@ -114,7 +122,9 @@ def main(argv):
             if rank == 0 and (it % 50 == 0 or it == steps_per_epoch - 1):
                 l = tr.losses.tolist()
                 print(f"epoch {epoch} it {it}/{steps_per_epoch} loss_rgb {l[0]:.5f} (psnr {-10 * math.log10(max(l[0], 1e-12)):.2f}) "
-                      f"loss_sem {l[1]:.4f} tv {l[2]:.5f} clustering {l[3]:.4f} S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
+                      f"loss_sem {l[1]:.4f} tv {l[2]:.5f} clustering {l[3]:.4f}"
+                      + (f" segment {float(tr.loss_segment[0]):.4f}" if 2 in batch else "")
+                      + f" S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
         if rank == 0:
             tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep)
             from contrastive_lift_amd.inference import render_rays
