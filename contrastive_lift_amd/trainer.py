@@ -58,6 +58,14 @@ class HotPathTrainer:
 
     def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
+        # config variants of the reference that this trainer does not implement fail loudly instead of being ignored
+        unsupported = [(k, v) for k, v in (("probabilistic_ce_mode", "TTAConf"), ("use_symmetric_ce", False), ("optimize_instance_only", False),
+                                            ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
+                                            ("use_proj", False), ("use_feature_regularization", False))
+                       if getattr(config, k, v) != v]
+        if unsupported:
+            raise NotImplementedError("HotPathTrainer: config options outside the contrastive-lift hot path: " +
+                                      ", ".join(f"{k}={getattr(config, k)!r} (only {v!r} is built)" for k, v in unsupported))
         self.white_bg = bool(white_bg)            # dataset attribute in the reference (train_set.white_bg, T:109)
         engine.set_mlp_precision(getattr(config, "mlp_dtype", "fp32") or "fp32")    # process-wide switch of the matrix-core launches
         self.device = model.param_flat.device

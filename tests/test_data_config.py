@@ -186,3 +186,17 @@ def test_g17_segmentwise_clustering_vs_reference():
     assert onehot.shape[-1] == int(g["seg.width"])
     assert np.array_equal(onehot.argmax(-1).reshape(-1).numpy().astype(np.int16), g["seg.labels"])
     np.testing.assert_allclose(cents, g["seg.centroids"], rtol=1e-6, atol=1e-7)
+
+
+def test_trainer_rejects_unbuilt_config_variants():
+    """Options of the reference's config tree that the hot-path trainer does not implement raise instead of being ignored."""
+    import pytest
+    import contrastive_lift_amd as cl
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    m = cl.TensorVMSplit([6, 7, 8], num_semantic_classes=3, dim_feature_instance=6, use_semantic_mlp=True, use_instance_mlp=True,
+                         slow_fast_mode=True, device="cpu")
+    r = cl.TensoRFRenderer(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), [6, 7, 8], semantic_weight_mode="softmax")
+    HotPathTrainer(m, r, default_config())                                   # the shipped settings construct fine
+    for k, v in (("probabilistic_ce_mode", "NoTTAConf"), ("use_symmetric_ce", True), ("optimize_instance_only", True)):
+        with pytest.raises(NotImplementedError):
+            HotPathTrainer(m, r, default_config(**{k: v}))
