@@ -112,10 +112,11 @@ def main():
         if world == 1:
             t_main = timed(lambda: tr.main_pass(batches[0][0], lean=a.lean))
             t_inst = timed(lambda: tr.instance_pass(batches[0][1]))
+            t_lean = timed(lambda: tr.main_pass(batches[0][0], lean=True))     # informational: main pass without the discarded instance heads
             ctxs = tr.main_pass(batches[0][0], lean=a.lean)
             M = sum(c.M for c in ctxs)
             inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
-            extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
+            extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3), lean_main_pass_ms=round(t_lean * 1e3, 3),
                          main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                          f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
             roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
