@@ -132,7 +132,7 @@ def main():
                 "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
                                         "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype == "fp32" else
                                        (f"BASELINE configs[2]-style bf16 mode on the configs[1] shapes (C={a.classes}, E=3/D=6, grid {a.grid}^3): MLP "
-                                        "operands rounded to bf16 in-kernel, fp32 accumulate, fp32 tensors in HBM; everything else fp32"),
+                                        "operands bf16 (weights rounded in-kernel, hidden activations / gradients bf16-stored), fp32 accumulate; everything else fp32"),
                            "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
                            "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean),
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
@@ -202,11 +202,12 @@ def roofline(tr, batch, lean, engine, dtype="fp32"):
     tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ach = tf(dom_f, dom_ms)
     if dtype == "bf16":
-        # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its fp32
-        # activations.  Algorithmic bytes per launch = A read (M x 256 x 4) + C written (M x 256 x 4) + weights (256 KB, L2).
-        dom_b = sum(4.0 * M * K + 4.0 * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec if kind == "fwd" and N > 128)
+        # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its
+        # activations.  Algorithmic bytes per launch = A read + C written (M x 256 x 2 bytes each, bf16-stored) + weights (256 KB, L2).
+        esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
+        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec if kind == "fwd" and N > 128)
         gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "k_gemm_bf16<128,256,2,4,false,false,true> (v_mfma_f32_32x32x16_bf16; 256x256 forward MLP layers)",
+        return {"bound": "hbm", "kernel": "k_gemm_bf16<128,256,2,4,false,false,true,true> (v_mfma_f32_32x32x16_bf16; 256x256 forward MLP layers, bf16-stored activations)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                 "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
                 "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec), "ms_per_step": tot_ms,

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -40,7 +40,8 @@ class Gemm(C.Structure):
                 ("bias", C.c_void_p), ("act", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p),
-                ("precision", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long)]
+                ("precision", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+                ("a_bf16", C.c_int), ("b_bf16", C.c_int), ("c_bf16", C.c_int), ("mask_bf16", C.c_int)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
@@ -63,12 +64,12 @@ _SIGNATURES = {
     "clift_app_gather_fwd": ([_P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_active_xyz": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
     "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
-    "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P], C.c_int),
+    "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_app_encode_bwd": ([_P, _I, _I, _I, _P, _I, _I, _P, _I, _P], C.c_int),
     "clift_gemm": ([_P, _P], C.c_int),
-    "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _P], C.c_int),
-    "clift_linear_k3_bwd": ([_P, _P, _I, _I, _I, _P, _I, _P, _P], C.c_int),
-    "clift_wgrad_narrow": ([_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P], C.c_int),
+    "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P], C.c_int),
+    "clift_linear_k3_bwd": ([_P, _P, _I, _I, _I, _P, _I, _P, _I, _P], C.c_int),
+    "clift_wgrad_narrow": ([_P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_colsum": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "clift_rows_act_fwd": ([_P, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "clift_rows_act_bwd": ([_P, _I, _P, _I, _I, _I, _I, _P, _I, _P], C.c_int),

@@ -210,7 +210,7 @@ extern "C" long clift_gemm_workspace_bytes(int N, int K) { return clift_gemm_spl
 extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     CLIFT_REQUIRE(h->M >= 0 && h->N >= 0 && h->K >= 0, "clift_gemm: negative dimension");
     if (h->M == 0 || h->N == 0) return 0;
-    CLIFT_REQUIRE(h->lda % 4 == 0 && h->ldb % 4 == 0, "clift_gemm: lda/ldb must be multiples of 4 (got %d, %d)", h->lda, h->ldb);
+    CLIFT_REQUIRE((h->a_bf16 || h->lda % 4 == 0) && (h->b_bf16 || h->ldb % 4 == 0), "clift_gemm: lda/ldb of fp32 operands must be multiples of 4 (got %d, %d)", h->lda, h->ldb);
     CLIFT_REQUIRE(((uintptr_t)h->A & 15) == 0 && ((uintptr_t)h->B & 15) == 0, "clift_gemm: A/B must be 16-byte aligned");
     int splits = h->split_k > 1 ? h->split_k : 1;
     CLIFT_REQUIRE(splits == 1 || h->accumulate, "clift_gemm: split_k > 1 requires accumulate");
@@ -221,6 +221,10 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     p.A = h->A; p.lda = h->lda; p.B = h->B; p.ldb = h->ldb; p.C = h->C; p.ldc = h->ldc;
     p.bias = h->bias; p.act = h->act; p.mask = h->mask; p.ldmask = h->ldmask; p.accumulate = h->accumulate;
     p.c_trans = h->c_trans; p.colsum = h->colsum;
+    p.a_bf16 = h->a_bf16; p.b_bf16 = h->b_bf16; p.c_bf16 = h->c_bf16; p.mask_bf16 = h->mask_bf16;
+    CLIFT_REQUIRE(h->precision == 1 || !(h->a_bf16 || h->b_bf16 || h->c_bf16 || h->mask_bf16),
+                  "clift_gemm: bf16-stored tensors (a/b/c/mask_bf16) are only supported with precision 1");
+    CLIFT_REQUIRE(!h->c_bf16 || (!h->accumulate && !h->c_trans), "clift_gemm: a bf16-stored output cannot be accumulated into or transposed");
     int kper = cdiv(cdiv(h->K, splits), BK) * BK;
     if (kper < BK) kper = BK;
     splits = cdiv(h->K, kper);
@@ -247,7 +251,7 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
 // out[m][n] = act(W[n][0] x + W[n][1] y + W[n][2] z + b[n]); pure store-bandwidth kernel (tensoRF.py:475,576).
 __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W, int ldw,
                                                         const float* __restrict__ b, int M, int Nout, int relu,
-                                                        float* __restrict__ out, int ldo) {
+                                                        float* __restrict__ out, int ldo, int out_bf16) {
     const int nq = Nout / 4;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)M * nq) return;
@@ -260,20 +264,27 @@ __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__
         float v = fmaf(w[2], x.z, fmaf(w[1], x.y, fmaf(w[0], x.x, b[n + j])));
         o[j] = relu ? fmaxf(v, 0.f) : v;
     }
-    *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if (out_bf16) {      // bf16-stored hidden activation (bf16 mode)
+        const unsigned lo = (unsigned)float_to_bf16_bits(o[0]) | ((unsigned)float_to_bf16_bits(o[1]) << 16);
+        const unsigned hi = (unsigned)float_to_bf16_bits(o[2]) | ((unsigned)float_to_bf16_bits(o[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + (size_t)m * ldo + n) = make_uint2(lo, hi);
+    } else {
+        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b, int M, int Nout, int relu,
-                                   float* out, int ldo, clift_stream_t s) {
+                                   float* out, int ldo, int out_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
     if (M <= 0) return 0;
-    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo);
+    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
     return clift_check_launch("clift_linear_k3_fwd");
 }
 
 // dW[n][0..2] += sum_m dH[m][n] x[m][:], db[n] += sum_m dH[m][n].  Thread = column n, block = slab of rows.
 __global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__ x4, const float* __restrict__ dH, int ldh, int M,
-                                                        int Nout, int rows_per_block, float* __restrict__ dW, int ldw, float* __restrict__ db) {
+                                                        int Nout, int rows_per_block, float* __restrict__ dW, int ldw, float* __restrict__ db,
+                                                        int dh_bf16) {
     const int n = blockIdx.y * 256 + threadIdx.x;
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     __shared__ float4 xs[64];
@@ -285,7 +296,8 @@ __global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__
         const int lim = min(64, me - mc);
         if (n < Nout)
             for (int j = 0; j < lim; ++j) {
-                const float d = dH[(size_t)(mc + j) * ldh + n];
+                const float d = dh_bf16 ? bf16_bits_to_float(reinterpret_cast<const unsigned short*>(dH)[(size_t)(mc + j) * ldh + n])
+                                        : dH[(size_t)(mc + j) * ldh + n];
                 const float4 x = xs[j];
                 a0 = fmaf(d, x.x, a0); a1 = fmaf(d, x.y, a1); a2 = fmaf(d, x.z, a2); a3 += d;
             }
@@ -299,10 +311,10 @@ __global__ __launch_bounds__(256) void k_linear_k3_bwd(const float* __restrict__
 }
 
 extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
-                                   clift_stream_t s) {
+                                   int dh_bf16, clift_stream_t s) {
     if (M <= 0) return 0;
     const int rpb = 512;
-    k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 256, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, ldw, db);
+    k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 256, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, ldw, db, dh_bf16);
     return clift_check_launch("clift_linear_k3_bwd");
 }
 
@@ -313,8 +325,9 @@ extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, in
 // registers, dY rows are broadcast from LDS; one atomic per (c, j) per block.
 template <int NO>
 __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ dY, int ldd, int no, const float* __restrict__ X, int ldx, int ni,
-                                                       int M, int rows_per_block, float* __restrict__ gW, int ldw, float* __restrict__ gb) {
+                                                       int M, int rows_per_block, float* __restrict__ gW, int ldw, float* __restrict__ gb, int x_bf16) {
     __shared__ __attribute__((aligned(16))) float ds[64 * NO];
+    const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
     const int j = blockIdx.y * 256 + threadIdx.x;
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     float acc[NO];
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ 
             for (; r + 4 <= lim; r += 4) {        // 4 rows in flight per thread: independent 1 KB-per-wave loads
                 float x[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = X[(size_t)(mc + r + q) * ldx + j];
+                for (int q = 0; q < 4; ++q) x[q] = x_bf16 ? bf16_bits_to_float(X16[(size_t)(mc + r + q) * ldx + j]) : X[(size_t)(mc + r + q) * ldx + j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ 
                     }
             }
             for (; r < lim; ++r) {
-                const float xv = X[(size_t)(mc + r) * ldx + j];
+                const float xv = x_bf16 ? bf16_bits_to_float(X16[(size_t)(mc + r) * ldx + j]) : X[(size_t)(mc + r) * ldx + j];
 #pragma unroll
                 for (int c = 0; c < NO; ++c) acc[c] = fmaf(ds[r * NO + c], xv, acc[c]);
             }
@@ -362,16 +375,16 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ 
 }
 
 extern "C" int clift_wgrad_narrow(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw, float* gb,
-                                  clift_stream_t s) {
+                                  int x_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_wgrad_narrow: out_features must be in [1,32] (got %d)", no);
     if (M <= 0 || ni <= 0) return 0;
     const int rpb = 128;
     const dim3 grid(cdiv(M, rpb), cdiv(ni, 256));
     hipStream_t st = as_stream(s);
-    if (no <= 4) k_wgrad_narrow<4><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
-    else if (no <= 8) k_wgrad_narrow<8><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
-    else if (no <= 16) k_wgrad_narrow<16><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
-    else k_wgrad_narrow<32><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb);
+    if (no <= 4) k_wgrad_narrow<4><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
+    else if (no <= 8) k_wgrad_narrow<8><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
+    else if (no <= 16) k_wgrad_narrow<16><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
+    else k_wgrad_narrow<32><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
     return clift_check_launch("clift_wgrad_narrow");
 }
 

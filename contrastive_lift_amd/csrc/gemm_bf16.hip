@@ -1,6 +1,8 @@
 // gemm_bf16.hip -- the same nn.Linear forward / dgrad / wgrad contract as gemm.hip with bf16 OPERANDS and fp32
-// accumulation ("bf16 mode", BASELINE config 3): tensors stay fp32 in HBM, every operand tile is rounded to bf16
-// (round-to-nearest-even, v_cvt_pk_bf16_f32) on its way into LDS, and the products run on
+// accumulation ("bf16 mode", BASELINE config 3): an operand stored as fp32 is rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) on its way into LDS; an operand already STORED as bf16 (a_bf16 / b_bf16: the hidden activations and their
+// gradients, which then cost half the HBM bytes) is copied; the output and the ReLU mask can be bf16-stored too (c_bf16 /
+// mask_bf16).  The products run on
 // v_mfma_f32_32x32x16_bf16 -- 16x the fp32 MFMA rate, so these launches are bound by streaming the fp32 activations
 // (HBM), not by the matrix cores.  Result == fp32 GEMM of the bf16-rounded operands up to summation order.
 //
@@ -84,6 +86,71 @@ struct StagerH {
             }
         }
     }
+    // ---- operand STORED as bf16 (activation storage of the bf16 mode): 8 elements per 16-byte entry.
+    //   plain: entry = 8 consecutive k of one row              -> copied to LDS unchanged (two 8-byte stores)
+    //   trans: entry = rows 8 r8 .. +7 at k = 2 kp and 2 kp + 1 -> eight packed k-pairs (4-byte stores); 2 row-groups x 16 k-pairs
+    //          per 32 lanes = 32 distinct banks
+    static constexpr int NEH = TR ? 2 * ROWS : 4 * ROWS;
+    static constexpr int NVH = (NEH + NT - 1) / NT;
+    static __device__ __forceinline__ void coords_h(int e, int& a, int& b) {
+        if (!TR) { a = e >> 2; b = (e & 3) * 8; }                                    // row, first k
+        else { a = (((e >> 5) << 1) | (e & 1)) * 8; b = ((e >> 1) & 15) * 2; }        // first row, first k
+    }
+    __device__ __forceinline__ void load_half(const unsigned short* __restrict__ P, int ld, int m0, int mlim, int k0, int klim, int tid) {
+        const bool fast = fast_ok(m0, mlim, k0, klim) && (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+        uint4* u = reinterpret_cast<uint4*>(v);
+#pragma unroll
+        for (int p = 0; p < NVH; ++p) {
+            const int e = tid + p * NT;
+            int a, b;
+            coords_h(e, a, b);
+#pragma unroll
+            for (int h = 0; h < (TR ? 2 : 1); ++h) {
+                uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                if (NEH % NT == 0 || e < NEH) {
+                    const unsigned short* q = TR ? P + (size_t)(k0 + b + h) * ld + m0 + a : P + (size_t)(m0 + a) * ld + k0 + b;
+                    if (fast) x = *reinterpret_cast<const uint4*>(q);
+                    else {                                   // ragged tile: element-wise with zero fill
+                        unsigned w[4] = {0u, 0u, 0u, 0u};
+                        const bool line_ok = TR ? (k0 + b + h < klim) : (m0 + a < mlim);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const bool ok = line_ok && (TR ? (m0 + a + j < mlim) : (k0 + b + j < klim));
+                            const unsigned val = ok ? (unsigned)q[j] : 0u;
+                            w[j >> 1] |= val << (16 * (j & 1));
+                        }
+                        x = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+                u[TR ? 2 * p + h : p] = x;
+            }
+        }
+    }
+    __device__ __forceinline__ void store_half(unsigned* __restrict__ L, int tid) const {
+        const uint4* u = reinterpret_cast<const uint4*>(v);
+#pragma unroll
+        for (int p = 0; p < NVH; ++p) {
+            const int e = tid + p * NT;
+            if (NEH % NT == 0 || e < NEH) {
+                int a, b;
+                coords_h(e, a, b);
+                if (!TR) {
+                    uint2* q = reinterpret_cast<uint2*>(L + a * LPD + (b >> 1));
+                    q[0] = make_uint2(u[p].x, u[p].y);
+                    q[1] = make_uint2(u[p].z, u[p].w);
+                } else {
+                    const uint4 lo = u[2 * p], hi = u[2 * p + 1];
+                    const unsigned l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
+                    unsigned* q = L + a * LPD + (b >> 1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned el = (l4[j >> 1] >> (16 * (j & 1))) & 0xffffu, eh = (h4[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                        q[j * LPD] = el | (eh << 16);
+                    }
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void store(unsigned* __restrict__ L, int tid) const {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -111,7 +178,9 @@ static __device__ __forceinline__ bf16x8 frag_h(const unsigned* __restrict__ L, 
     return __builtin_bit_cast(bf16x8, u);
 }
 
-template <int BM, int BN, int WM, int WN, bool AT, bool BT, bool SWAP>
+// ST: the STREAMED operands are bf16-stored -- A always, B too in the wgrad form (AT && BT); weights (B of the forward / dgrad
+// forms) are always fp32-stored.  A compile-time switch: carrying both load paths in one kernel spilled and cost 10 %.
+template <int BM, int BN, int WM, int WN, bool AT, bool BT, bool SWAP, bool ST>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm_bf16(GemmP g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -141,11 +210,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm_b
 
     StagerH<BM, NT, AT> sa;
     StagerH<BN, NT, BT> sb;
-    sa.load_any(g.A, g.lda, m0, g.M, kbeg, kend, tid);
-    sb.load_any(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+    constexpr bool a16 = ST, b16 = ST && AT && BT;
+    const unsigned short* A16 = reinterpret_cast<const unsigned short*>(g.A);
+    const unsigned short* B16 = reinterpret_cast<const unsigned short*>(g.B);
+    if (a16) sa.load_half(A16, g.lda, m0, g.M, kbeg, kend, tid); else sa.load_any(g.A, g.lda, m0, g.M, kbeg, kend, tid);
+    if (b16) sb.load_half(B16, g.ldb, n0, g.N, kbeg, kend, tid); else sb.load_any(g.B, g.ldb, n0, g.N, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BKH) {
-        sa.store(As, tid);
-        sb.store(Bs, tid);
+        if (a16) sa.store_half(As, tid); else sa.store(As, tid);
+        if (b16) sb.store_half(Bs, tid); else sb.store(Bs, tid);
         __syncthreads();
         if (AT && do_colsum && tid < BM) {       // bias gradient from the (bf16-rounded) dY tile
 #pragma unroll
@@ -155,8 +227,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm_b
             }
         }
         if (k0 + BKH < kend) {
-            sa.load_any(g.A, g.lda, m0, g.M, k0 + BKH, kend, tid);
-            sb.load_any(g.B, g.ldb, n0, g.N, k0 + BKH, kend, tid);
+            if (a16) sa.load_half(A16, g.lda, m0, g.M, k0 + BKH, kend, tid); else sa.load_any(g.A, g.lda, m0, g.M, k0 + BKH, kend, tid);
+            if (b16) sb.load_half(B16, g.ldb, n0, g.N, k0 + BKH, kend, tid); else sb.load_any(g.B, g.ldb, n0, g.N, k0 + BKH, kend, tid);
         }
         const int arow = wm * (BM / WM) + li, brow = wn * (BN / WN) + li;
 #pragma unroll
@@ -175,14 +247,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm_b
         }
         __syncthreads();
     }
-    gemm_epilogue<BM, BN, WM, WN, SWAP>(g, acc, m0, n0, wm, wn, li, lh, tid, do_colsum, csum);
+    gemm_epilogue<BM, BN, WM, WN, SWAP, true>(g, acc, m0, n0, wm, wn, li, lh, tid, do_colsum, csum);
 }
 
 template <int BM, int BN, int WM, int WN, bool AT, bool BT>
 static int launch_one_h(const GemmP& p, int splits, hipStream_t st) {
-    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits);
-    if (!gemm_vector_epilogue_ok(p)) k_gemm_bf16<BM, BN, WM, WN, AT, BT, false><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
-    else k_gemm_bf16<BM, BN, WM, WN, AT, BT, true><<<grid, dim3(WM * WN * 64), 0, st>>>(p);
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, splits), block(WM * WN * 64);
+    const bool vec = gemm_vector_epilogue_ok(p);
+    if (p.a_bf16) {
+        if (AT != BT) {            // (a_trans, !b_trans) / (!a_trans, b_trans with bf16 B) forms have no bf16-stored instantiation
+            CLIFT_REQUIRE(!AT, "clift_gemm(bf16): a bf16-stored transposed A needs the wgrad form (b_trans = 1)");
+        }
+        if (!vec) k_gemm_bf16<BM, BN, WM, WN, AT, BT, false, true><<<grid, block, 0, st>>>(p);
+        else k_gemm_bf16<BM, BN, WM, WN, AT, BT, true, true><<<grid, block, 0, st>>>(p);
+    } else {
+        if (!vec) k_gemm_bf16<BM, BN, WM, WN, AT, BT, false, false><<<grid, block, 0, st>>>(p);
+        else k_gemm_bf16<BM, BN, WM, WN, AT, BT, true, false><<<grid, block, 0, st>>>(p);
+    }
     return clift_check_launch("clift_gemm(bf16)");
 }
 
@@ -195,6 +276,9 @@ static int launch_gemm_h(const GemmP& p, int a_trans, int b_trans, int splits, h
 }
 
 int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st) {
+    // storage combinations that exist: streamed operands bf16-stored together (A; and B exactly in the wgrad form), weights fp32
+    CLIFT_REQUIRE(!p.b_bf16 || (p.a_bf16 && a_trans && b_trans), "clift_gemm(bf16): a bf16-stored B needs the wgrad form with a bf16-stored A");
+    CLIFT_REQUIRE(!(p.a_bf16 && a_trans && b_trans) || p.b_bf16, "clift_gemm(bf16): the wgrad form takes both streamed operands bf16-stored or neither");
     if (p.N > 128) return launch_gemm_h<128, 256, 2, 4>(p, a_trans, b_trans, splits, st);
     if (p.N > 32) return launch_gemm_h<128, 128, 2, 2>(p, a_trans, b_trans, splits, st);
     return launch_gemm_h<256, 32, 4, 1>(p, a_trans, b_trans, splits, st);

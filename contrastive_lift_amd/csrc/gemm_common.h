@@ -18,7 +18,15 @@ struct GemmP {
     int k_per_split;
     int c_trans;      // write C[n*ldc + m] instead of C[m*ldc + n]
     float* colsum;    // nullable: colsum[m] += sum_k A(m,k)   (bias gradient fused into the wgrad, a_trans only)
+    // bf16 mode only (gemm_bf16.hip): which of the tensors are STORED as bf16 (2 bytes per element, pitches in elements)
+    int a_bf16, b_bf16, c_bf16, mask_bf16;
 };
+
+static __device__ __forceinline__ float bf16_bits_to_float(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+static __device__ __forceinline__ unsigned short float_to_bf16_bits(float v) {
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+static __device__ __forceinline__ bool bf16_bits_positive(unsigned short u) { return (u & 0x7fffu) != 0 && !(u & 0x8000u); }
 
 // swapped-operand (16-byte store) epilogue only where every row can take aligned float4 stores; accumulating, transposed
 // and odd-pitch (narrow head outputs) launches keep lanes along the output row
@@ -33,10 +41,20 @@ int clift_gemm_split_launch(const GemmP& p, int a_trans, int b_trans, void* work
 
 // acc[x][y] = 32x32 accumulator tile (x, y) of this wave; (wm, wn) = wave coordinates in the block; li = lane & 31,
 // lh = lane >> 5.  csum = this thread's partial bias-gradient (column sum of A) when do_colsum.
-template <int BM, int BN, int WM, int WN, bool SWAP>
+// HALF = true compiles in the bf16-stored output / mask forms (selected at run time by g.c_bf16 / g.mask_bf16).
+template <int BM, int BN, int WM, int WN, bool SWAP, bool HALF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0, int wm, int wn,
                                               int li, int lh, int tid, bool do_colsum, float csum) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const bool c16 = HALF && g.c_bf16, m16 = HALF && g.mask_bf16;
+    auto mask_on = [&](size_t idx) {
+        return m16 ? bf16_bits_positive(reinterpret_cast<const unsigned short*>(g.mask)[idx]) : (g.mask[idx] > 0.f);
+    };
+    auto put = [&](size_t idx, float v) {
+        if (c16) reinterpret_cast<unsigned short*>(g.C)[idx] = float_to_bf16_bits(v);
+        else if (g.accumulate) unsafeAtomicAdd(g.C + idx, v);
+        else g.C[idx] = v;
+    };
     // Epilogue.  The MFMAs were issued with swapped operands (weight fragment first), so the accumulator tile is C^T in
     // the standard C/D layout: lane l owns output ROW m = tile_m + (l & 31) and, per group q = reg >> 2, the four CONSECUTIVE
     // columns n = tile_n + 8q + 4(l >> 5) + (reg & 3).  That lets every lane move 16 bytes per store / mask load: a
@@ -58,17 +76,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, f32x16 (&acc)[BM /
                     if (m >= g.M) continue;
                     float v = acc[x][y][r] + bv;
                     if (g.act == 1) v = fmaxf(v, 0.f);
-                    if (g.mask && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
-                    float* c = g.c_trans ? g.C + (size_t)n * g.ldc + m : g.C + (size_t)m * g.ldc + n;
-                    if (g.accumulate) unsafeAtomicAdd(c, v);
-                    else *c = v;
+                    if (g.mask && !mask_on((size_t)m * g.ldmask + n)) v = 0.f;
+                    put(g.c_trans ? (size_t)n * g.ldc + m : (size_t)m * g.ldc + n, v);
                 }
             }
         if (do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
         return;
     }
     const bool vec_ok = !g.accumulate && !g.c_trans && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) &&
-                        (!g.mask || ((g.ldmask % 4 == 0) && (((uintptr_t)g.mask & 15) == 0)));
+                        (!g.mask || ((g.ldmask % 4 == 0) && (((uintptr_t)g.mask & 15) == 0)));     // (16-byte bases also cover the 8-byte bf16 forms)
 #pragma unroll
     for (int x = 0; x < TM; ++x) {
         const int m = m0 + wm * (BM / WM) + x * 32 + li;
@@ -84,10 +100,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, f32x16 (&acc)[BM /
                     if (g.bias) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
                     if (g.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                     if (g.mask) {
-                        const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)m * g.ldmask + n);
-                        if (!(mk.x > 0.f)) v[0] = 0.f; if (!(mk.y > 0.f)) v[1] = 0.f; if (!(mk.z > 0.f)) v[2] = 0.f; if (!(mk.w > 0.f)) v[3] = 0.f;
+                        if (m16) {
+                            const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.mask) + (size_t)m * g.ldmask + n);
+                            if (!bf16_bits_positive((unsigned short)(mk.x & 0xffffu))) v[0] = 0.f; if (!bf16_bits_positive((unsigned short)(mk.x >> 16))) v[1] = 0.f;
+                            if (!bf16_bits_positive((unsigned short)(mk.y & 0xffffu))) v[2] = 0.f; if (!bf16_bits_positive((unsigned short)(mk.y >> 16))) v[3] = 0.f;
+                        } else {
+                            const float4 mk = *reinterpret_cast<const float4*>(g.mask + (size_t)m * g.ldmask + n);
+                            if (!(mk.x > 0.f)) v[0] = 0.f; if (!(mk.y > 0.f)) v[1] = 0.f; if (!(mk.z > 0.f)) v[2] = 0.f; if (!(mk.w > 0.f)) v[3] = 0.f;
+                        }
                     }
-                    *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (c16) {
+                        const unsigned lo = (unsigned)float_to_bf16_bits(v[0]) | ((unsigned)float_to_bf16_bits(v[1]) << 16);
+                        const unsigned hi = (unsigned)float_to_bf16_bits(v[2]) | ((unsigned)float_to_bf16_bits(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + (size_t)m * g.ldc + n) = make_uint2(lo, hi);
+                    } else {
+                        *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -95,10 +123,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, f32x16 (&acc)[BM /
                         if (ne >= g.N) continue;
                         float val = v[e] + (g.bias ? g.bias[ne] : 0.f);
                         if (g.act == 1) val = fmaxf(val, 0.f);
-                        if (g.mask && !(g.mask[(size_t)m * g.ldmask + ne] > 0.f)) val = 0.f;
-                        float* c = g.c_trans ? g.C + (size_t)ne * g.ldc + m : g.C + (size_t)m * g.ldc + ne;
-                        if (g.accumulate) unsafeAtomicAdd(c, val);
-                        else *c = val;
+                        if (g.mask && !mask_on((size_t)m * g.ldmask + ne)) val = 0.f;
+                        put(g.c_trans ? (size_t)ne * g.ldc + m : (size_t)m * g.ldc + ne, val);
                     }
                 }
             }

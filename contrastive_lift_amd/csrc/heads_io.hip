@@ -228,44 +228,47 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
 // neighbouring columns in every block of the row.
 __global__ __launch_bounds__(256) void k_app_encode_fwd(const float* __restrict__ feat, int ldf, int nf, int pef, int pev,
                                                          const float* __restrict__ rays, const int* __restrict__ act, int S, long total,
-                                                         float* __restrict__ X, int ldx) {
+                                                         float* __restrict__ X, int ldx, int x_bf16) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int J = nf + 4;
     const int s = (int)(gid / J), j = (int)(gid - (long)s * J);
-    float* x = X + (size_t)s * ldx;
+    // the row is written through `put` so that it can be bf16-stored (bf16 mode: it is only ever a matrix-core operand)
+    float* xf = X + (size_t)s * ldx;
+    unsigned short* xh = reinterpret_cast<unsigned short*>(X) + (size_t)s * ldx;
+    auto put = [&](int c, float v) { if (x_bf16) xh[c] = __builtin_bit_cast(unsigned short, (__bf16)v); else xf[c] = v; };
     const int b0 = nf, b1 = b0 + 3, b2 = b1 + nf * pef, b3 = b2 + nf * pef, b4 = b3 + 3 * pev, b5 = b4 + 3 * pev;
     if (j < nf) {
         const float v = feat[(size_t)s * ldf + j];
-        x[j] = v;
+        put(j, v);
         for (int p = 0; p < pef; ++p) {
             float sn, cs;
             sincosf(v * (float)(1 << p), &sn, &cs);
-            x[b1 + j * pef + p] = sn;
-            x[b2 + j * pef + p] = cs;
+            put(b1 + j * pef + p, sn);
+            put(b2 + j * pef + p, cs);
         }
     } else if (j < nf + 3) {
         const int a = j - nf;
         const float v = rays[(size_t)(act[s] / S) * 8 + 3 + a];
-        x[b0 + a] = v;
+        put(b0 + a, v);
         for (int p = 0; p < pev; ++p) {
             float sn, cs;
             sincosf(v * (float)(1 << p), &sn, &cs);
-            x[b3 + a * pev + p] = sn;
-            x[b4 + a * pev + p] = cs;
+            put(b3 + a * pev + p, sn);
+            put(b4 + a * pev + p, cs);
         }
     } else {
-        for (int c = b5; c < ldx; ++c) x[c] = 0.f;       // alignment padding of the GEMM operand row stays zero
+        for (int c = b5; c < ldx; ++c) put(c, 0.f);       // alignment padding of the GEMM operand row stays zero
     }
 }
 
 extern "C" int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* rays,
-                                    const int* act_idx, int S, int M, float* X, int ldx, clift_stream_t s) {
+                                    const int* act_idx, int S, int M, float* X, int ldx, int x_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(ldx >= nf + 3 + 2 * pe_feat * nf + 2 * pe_view * 3, "clift_app_encode_fwd: ldx %d too small", ldx);
     CLIFT_REQUIRE(pe_feat >= 1 && pe_view >= 1, "clift_app_encode_fwd: pe_feat/pe_view must be >= 1");
     if (M <= 0) return 0;
     const long total = (long)M * (nf + 4);
-    k_app_encode_fwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, pe_view, rays, act_idx, S, total, X, ldx);
+    k_app_encode_fwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, pe_view, rays, act_idx, S, total, X, ldx, x_bf16);
     return clift_check_launch("clift_app_encode_fwd");
 }
 

@@ -97,6 +97,15 @@ _PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32x6": 2}
 MLP_PRECISION = _PRECISIONS[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
 
 
+def act_dtype():
+    """Storage type of the hidden activations / hidden gradients of the xyz-MLP heads: bf16 in bf16 mode (they are only ever
+    consumed as bf16 matrix-core operands or as ReLU masks there), fp32 otherwise."""
+    return torch.bfloat16 if (MLP_PRECISION == 1 and BF16_STORAGE) else torch.float32
+
+
+BF16_STORAGE = os.environ.get("CLIFT_BF16_STORAGE", "1") == "1"
+
+
 def set_mlp_precision(name):
     """'fp32', 'bf16' or 'fp32x6'; returns the previous setting's name."""
     global MLP_PRECISION
@@ -107,11 +116,13 @@ def set_mlp_precision(name):
 
 def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=0, mask=None, ldmask=0,
          accumulate=0, split_k=1, a_off=0, c_off=0, c_trans=0, colsum=None):
+    """One clift_gemm launch.  Pitches and offsets are in ELEMENTS of the respective tensor; a tensor of dtype bfloat16 is
+    passed as bf16-stored (bf16 mode only: hidden activations and their gradients)."""
     g = Gemm()
     g.M, g.N, g.K = int(M), int(N), int(K)
-    g.A, g.lda, g.a_trans = A.data_ptr() + 4 * a_off, int(lda), int(a_trans)
+    g.A, g.lda, g.a_trans = A.data_ptr() + A.element_size() * a_off, int(lda), int(a_trans)
     g.B, g.ldb, g.b_trans = B.data_ptr(), int(ldb), int(b_trans)
-    g.C, g.ldc = Cm.data_ptr() + 4 * c_off, int(ldc)
+    g.C, g.ldc = Cm.data_ptr() + Cm.element_size() * c_off, int(ldc)
     g.bias = bias.data_ptr() if bias is not None else None
     g.act = int(act)
     g.mask = mask.data_ptr() if mask is not None else None
@@ -120,6 +131,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
     g.precision = MLP_PRECISION
+    g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
+    g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
     if MLP_PRECISION == 2 and not a_trans and not accumulate and not c_trans:
         nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)          # split weight planes (stream-ordered scratch)
@@ -134,7 +147,9 @@ def wgrad(no, ni, M, dY, ldd, X, ldx, gW, gb):
     if no > 32:
         gemm(no, ni, M, dY, ldd, X, ldx, gW, _pitch(gW), a_trans=1, b_trans=1, accumulate=1, split_k=_splits(no, ni, M), colsum=gb)
     else:
-        call("clift_wgrad_narrow", ptr(dY), ldd, no, ptr(X), ldx, ni, M, ptr(gW), _pitch(gW), ptr(gb), stream())
+        if dY.dtype != torch.float32:
+            raise _lib.CliftError("narrow wgrad: the output-side gradient must be fp32")
+        call("clift_wgrad_narrow", ptr(dY), ldd, no, ptr(X), ldx, ni, M, ptr(gW), _pitch(gW), ptr(gb), int(X.dtype == torch.bfloat16), stream())
 
 
 def _splits(out_rows, out_cols, K):
@@ -207,11 +222,12 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
     dev = xa.device
     acts = []
     W0, b0 = layers[0]
-    h = torch.empty((M, W0.shape[0]), dtype=torch.float32, device=dev)
-    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], stream())
+    hdt = act_dtype()                     # bf16 mode stores the hidden activations as bf16 (half the HBM stream of these layers)
+    h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)
+    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
     acts.append(h)
     for W, b in layers[1:-1]:
-        hn = torch.empty((M, W.shape[0]), dtype=torch.float32, device=dev)
+        hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
         gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
         acts.append(hn)
         h = hn
@@ -234,12 +250,13 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         h = acts[li - 1]
         no, ni = W.shape
         wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
-        dn = torch.empty((M, ni), dtype=torch.float32, device=dev)
+        dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
         gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
         keep.append(d)
     gW, gb = glayers[0]
-    call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), _pitch(gW), ptr(gb), stream())
+    call("clift_linear_k3_bwd", ptr(xa), ptr(d), d.shape[1], M, layers[0][0].shape[0], ptr(gW), _pitch(gW), ptr(gb),
+         int(d.dtype == torch.bfloat16), stream())
 
 
 # ----------------------------------------------------------------------------- forward
@@ -321,12 +338,13 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
             (W1, b1), (W2, b2), (W3, b3) = _lin_params(None, "render_appearance_mlp.mlp", views)
             ldx = _pitch(W1)
-            X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
+            hdt = act_dtype() if ldx % 8 == 0 else torch.float32      # bf16 mode: encoded input and hidden activations bf16-stored
+            X = torch.empty((M, ldx), dtype=hdt, device=dev)
             call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
-                 ptr(X), ldx, stream())
-            H1 = torch.empty((M, W1.shape[0]), dtype=torch.float32, device=dev)
+                 ptr(X), ldx, int(hdt == torch.bfloat16), stream())
+            H1 = torch.empty((M, W1.shape[0]), dtype=hdt, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
-            H2 = torch.empty((M, W2.shape[0]), dtype=torch.float32, device=dev)
+            H2 = torch.empty((M, W2.shape[0]), dtype=hdt, device=dev)
             gemm(M, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
             pre = torch.empty((M, 3), dtype=torch.float32, device=dev)
             gemm(M, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
@@ -441,11 +459,11 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
             n2 = W3.shape[1]
             wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
-            dH2 = torch.empty((M, n2), dtype=torch.float32, device=dev)
+            dH2 = torch.empty((M, n2), dtype=H2.dtype, device=dev)
             gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
             n1 = W2.shape[1]
             wgrad(n2, n1, M, dH2, n2, H1, n1, gW2, gb2)
-            dH1 = torch.empty((M, n1), dtype=torch.float32, device=dev)
+            dH1 = torch.empty((M, n1), dtype=H1.dtype, device=dev)
             gemm(M, n1, n2, dH2, n2, W2, _pitch(W2), dH1, n1, b_trans=1, mask=H1, ldmask=n1)
             wgrad(n1, ldx, M, dH1, n1, X, ldx, gW1, gb1)
             dX = torch.empty((M, ldx), dtype=torch.float32, device=dev)
@@ -455,7 +473,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
-            call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, stream())
+            call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
             gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             va = vm_struct(views, "appearance", ctx.res)

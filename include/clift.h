@@ -126,7 +126,7 @@ int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, cons
 /* ---- a10 input assembly: tensoRF.py:400-408,413-418.  X (M, ldx) = [feat(nf), dir(3), sin/cos PE(feat),
  * sin/cos PE(dir), zero pad]; ldx >= nf + 3 + 2*pe_feat*nf + 2*pe_view*3. */
 int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe_view, const float* rays,
-                         const int* act_idx, int S, int M, float* X, int ldx, clift_stream_t s);
+                         const int* act_idx, int S, int M, float* X, int ldx, int x_bf16 /* X is bf16-stored */, clift_stream_t s);
 int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const float* dX, int ldx, int M,
                          float* dfeat, int lddf, clift_stream_t s);
 
@@ -156,6 +156,8 @@ typedef struct {
     int precision;                  /* 0 fp32 operands, 1 bf16 operands (fp32 accumulate), 2 fp32x6 split (see above) */
     void* workspace;                /* precision 2 only: device scratch for the split weight planes, 16-byte aligned */
     long workspace_bytes;           /* >= clift_gemm_workspace_bytes(N, K) */
+    int a_bf16, b_bf16, c_bf16, mask_bf16;  /* precision 1 only: the tensor is STORED as bf16 (2-byte elements, pitches in elements);
+                                     * the pointers are passed through the float* fields */
 } clift_gemm_t;
 long clift_gemm_workspace_bytes(int N, int K);
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
@@ -163,15 +165,15 @@ int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 /* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4), W (Nout, 3)
  * with row pitch ldw. */
 int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b, int M, int Nout, int relu,
-                        float* out, int ldo, clift_stream_t s);
+                        float* out, int ldo, int out_bf16 /* out is bf16-stored (bf16 mode) */, clift_stream_t s);
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
-                        clift_stream_t s);
+                        int dh_bf16 /* dH is bf16-stored */, clift_stream_t s);
 /* Narrow weight gradient (out_features no <= 32: the last layer of every head, tensoRF.py:395,480,581, and the basis
  * Linear :65 seen from its narrow side): gW (no, ni; pitch ldw) += dY^T X over M samples, gb (no; nullable) += colsum(dY).
  * A streaming VALU reduction at HBM rate instead of a mostly-padding matrix-core tile. */
 int clift_wgrad_narrow(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw,
-                       float* gb, clift_stream_t s);
+                       float* gb, int x_bf16 /* X is bf16-stored */, clift_stream_t s);
 /* db (N) += colsum(dY (M,N)). */
 int clift_colsum(const float* dY, int ld, int M, int N, float* db, clift_stream_t s);
 

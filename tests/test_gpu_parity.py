@@ -164,6 +164,50 @@ def test_gemm_fp32x6_split_is_fp32_faithful(bt, M, N, K):
     rel_close(outs["fp32x6"][1], torch.relu(ref) * (mask > 0), 2e-5, atol=2e-5 * float(ref.abs().max()), what="fp32x6 relu+mask")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 128, 152), (517, 24, 256), (130, 256, 24), (128 * 3 + 5, 256, 64)])
+def test_gemm_bf16_stored_operands(M, N, K):
+    """bf16 mode with bf16-STORED tensors (hidden activations / gradients): forward with A and C stored as bf16, dgrad with a
+    bf16 mask and bf16 output, wgrad with both streamed operands stored as bf16 -- against fp64 products of the same bf16
+    values (outputs compared after their own bf16 rounding where they are bf16-stored)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    bf = torch.bfloat16
+    Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    A = torch.randn((M, Kp), generator=g).to(bf)
+    W = torch.randn((N, (K + 3) // 4 * 4), generator=g)                     # weights stay fp32 (rounded in-kernel)
+    bias = torch.randn(N, generator=g)
+    Wr = W[:, :K].to(bf).double()
+    ref = A[:, :K].double() @ Wr.T + bias.double()
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+        out = torch.zeros((M, Np), dtype=bf, device=DEV)
+        engine.gemm(M, N, K, Ad, Kp, Wd, W.shape[1], out, Np, bias=bd, act=1)                       # fwd: bf16 A -> bf16 C, ReLU
+        want = torch.relu(ref)
+        got = out[:, :N].double().cpu()
+        assert float((got - want).abs().max()) <= 1.0 / 128 * float(want.abs().max()) + 1e-6          # one bf16 rounding of the output
+        out32 = torch.zeros((M, N), device=DEV)
+        engine.gemm(M, N, K, Ad, Kp, Wd, W.shape[1], out32, N, bias=bd)                               # fwd: bf16 A -> fp32 C
+        rel_close(out32, ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="bf16-stored A, fp32 C")
+        # dgrad: dX (M,K) = (dY (M,N) bf16) W, masked by a bf16 activation, bf16 output
+        dY = torch.randn((M, Np), generator=g).to(bf)
+        mask = torch.relu(torch.randn((M, Kp), generator=g)).to(bf)
+        dX = torch.zeros((M, Kp), dtype=bf, device=DEV)
+        engine.gemm(M, K, N, dY.to(DEV), Np, Wd, W.shape[1], dX, Kp, b_trans=1, mask=mask.to(DEV), ldmask=Kp)
+        refd = (dY[:, :N].double() @ W[:, :K].to(bf).double()) * (mask[:, :K].double() > 0)
+        assert float((dX[:, :K].double().cpu() - refd).abs().max()) <= 1.0 / 128 * float(refd.abs().max()) + 1e-6
+        # wgrad: dW (N,K) += dY^T A, both streamed operands bf16-stored, fp32 accumulate + fused bias sums
+        gW = torch.zeros((N, (K + 3) // 4 * 4), device=DEV)
+        gb = torch.zeros(N, device=DEV)
+        if N > 32:
+            engine.wgrad(N, K, M, dY.to(DEV), Np, Ad, Kp, gW, gb)
+            refw = dY[:, :N].double().T @ A[:, :K].double()
+            rel_close(gW[:, :K], refw, 1e-4, atol=1e-4 * float(refw.abs().max()), what="wgrad bf16-stored operands")
+            rel_close(gb, dY[:, :N].double().sum(0), 1e-4, atol=1e-4 * M ** 0.5, what="bias sums")
+    finally:
+        engine.set_mlp_precision(prev)
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine

@@ -6,8 +6,9 @@ import torch
 from contrastive_lift_amd import engine
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 265000
+stored = len(sys.argv) > 2 and sys.argv[2] == "bf16s"       # bf16 mode with bf16-STORED streamed operands / outputs
 if len(sys.argv) > 2:
-    engine.set_mlp_precision(sys.argv[2])      # fp32 | bf16 | fp32x6
+    engine.set_mlp_precision("bf16" if stored else sys.argv[2])      # fp32 | bf16 | fp32x6 | bf16s
 dev = "cuda"
 shapes = [("fwd 256x256", M, 256, 256, 0, 0), ("dgrad 256x256", M, 256, 256, 0, 1), ("wgrad 256x256", 256, 256, M, 1, 1),
           ("fwd 152->128", M, 128, 152, 0, 0), ("fwd 128->128", M, 128, 128, 0, 0), ("fwd 256->22", M, 22, 256, 0, 0),
@@ -21,6 +22,14 @@ for name, m, n, k, at, bt in shapes:
         B = torch.randn(k, n, device=dev) if bt else torch.randn(n, (k + 3) // 4 * 4, device=dev)
         lda, ldb = A.shape[1], B.shape[1]
     Cm = torch.zeros(m, n, device=dev)
+    if stored:       # streamed operands (activations / gradients) and non-accumulated outputs as bf16; weights stay fp32
+        if at:
+            A, B = A.to(torch.bfloat16), B.to(torch.bfloat16)
+        else:
+            A = A.to(torch.bfloat16)
+            Cm = Cm.to(torch.bfloat16) if n % 8 == 0 else Cm
+        if (A.shape[1] % 8) or (at and B.shape[1] % 8):
+            continue
     kw = dict(a_trans=at, b_trans=bt)
     if at:
         kw.update(accumulate=1, split_k=engine._splits(m, n, k))
