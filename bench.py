@@ -100,7 +100,10 @@ def main():
     extra = {}
     roof = None
     cpu = None
-    if rank == 0:
+    # ---- roofline of the dominant kernel: one instrumented step outside the timed region.  With several ranks every rank runs
+    # it (the step contains the gradient all-reduce), rank 0 reports.
+    roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
+    if rank == 0 and world == 1:
         # ---- per-pass split and sample statistics (outside the timed region)
         def timed(fn, n=5):
             torch.cuda.synchronize()
@@ -109,20 +112,18 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
-        if world == 1:
-            t_main = timed(lambda: tr.main_pass(batches[0][0], lean=a.lean))
-            t_inst = timed(lambda: tr.instance_pass(batches[0][1]))
-            t_lean = timed(lambda: tr.main_pass(batches[0][0], lean=True))     # informational: main pass without the discarded instance heads
-            ctxs = tr.main_pass(batches[0][0], lean=a.lean)
-            M = sum(c.M for c in ctxs)
-            inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
-            extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3), lean_main_pass_ms=round(t_lean * 1e3, 3),
-                         main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
-                         f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
-            roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
-            if a.inference_probe:
-                extra.update(inference_probe(cl, model, renderer, pool))
-        if world == 1 and not a.no_cpu_baseline:
+        t_main = timed(lambda: tr.main_pass(batches[0][0], lean=a.lean))
+        t_inst = timed(lambda: tr.instance_pass(batches[0][1]))
+        t_lean = timed(lambda: tr.main_pass(batches[0][0], lean=True))     # informational: main pass without the discarded instance heads
+        ctxs = tr.main_pass(batches[0][0], lean=a.lean)
+        M = sum(c.M for c in ctxs)
+        inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
+        extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3), lean_main_pass_ms=round(t_lean * 1e3, 3),
+                     main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
+                     f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
+        if a.inference_probe:
+            extra.update(inference_probe(cl, model, renderer, pool))
+        if not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
