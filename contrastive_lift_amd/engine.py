@@ -153,9 +153,11 @@ def wgrad(no, ni, M, dY, ldd, X, ldx, gW, gb):
 
 
 def _splits(out_rows, out_cols, K):
-    """Split the (huge) sample-reduction of a wgrad over blockIdx.z so that ~1024 workgroups are in flight."""
+    """Split the (huge) sample-reduction of a wgrad over blockIdx.z so that the launch is ONE resident wave of workgroups
+    (256 CUs x 2 blocks = 512): measured at 265 k samples, 256x256 / 128x128 / 128x152 outputs: 512 blocks 332 / 125 / 208 us,
+    1024 blocks 378 / 165 / 261 us, 384 or 640 blocks worse than either (partial second wave, twice the atomics)."""
     tiles = ((out_rows + 127) // 128) * ((out_cols + 255) // 256 if out_cols > 128 else (out_cols + 127) // 128 if out_cols > 32 else 1)
-    return max(1, min((K + 255) // 256, (1024 + tiles - 1) // tiles))
+    return max(1, min((K + 255) // 256, (512 + tiles - 1) // tiles))
 
 
 def _lin_params(seq, views_prefix, views):

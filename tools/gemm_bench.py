@@ -11,7 +11,7 @@ if len(sys.argv) > 2:
     engine.set_mlp_precision("bf16" if stored else sys.argv[2])      # fp32 | bf16 | fp32x6 | bf16s
 dev = "cuda"
 shapes = [("fwd 256x256", M, 256, 256, 0, 0), ("dgrad 256x256", M, 256, 256, 0, 1), ("wgrad 256x256", 256, 256, M, 1, 1),
-          ("fwd 152->128", M, 128, 152, 0, 0), ("fwd 128->128", M, 128, 128, 0, 0), ("fwd 256->22", M, 22, 256, 0, 0),
+          ("fwd 152->128", M, 128, 152, 0, 0), ("fwd 128->128", M, 128, 128, 0, 0), ("wgrad 128x128", 128, 128, M, 1, 1), ("wgrad 128x152", 128, 152, M, 1, 1), ("fwd 256->22", M, 22, 256, 0, 0),
           ("fwd 144->27", M, 27, 144, 0, 0), ("dgrad 22->256", M, 256, 22, 0, 1), ("wgrad 22x256", 22, 256, M, 1, 1)]
 for name, m, n, k, at, bt in shapes:
     if at:   # wgrad: A = dY (K x m) stored (K, m) row-major; B = X (K x n)
