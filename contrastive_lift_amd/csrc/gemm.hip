@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ 
         __syncthreads();
         if (j < ni) {
             int r = 0;
-            for (; r + 4 <= lim; r += 4) {        // 4 rows in flight per thread: independent 1 KB-per-wave loads
-                float x[4];
+            for (; r + 8 <= lim; r += 8) {        // 8 rows in flight per thread: independent 1 KB-per-wave loads (latency-bound otherwise)
+                float x[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = x_bf16 ? bf16_bits_to_float(X16[(size_t)(mc + r + q) * ldx + j]) : X[(size_t)(mc + r + q) * ldx + j];
+                for (int q = 0; q < 8; ++q) x[q] = x_bf16 ? bf16_bits_to_float(X16[(size_t)(mc + r + q) * ldx + j]) : X[(size_t)(mc + r + q) * ldx + j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 8; ++q)
 #pragma unroll
                     for (int c = 0; c < NO; c += 4) {
                         const float4 d = *reinterpret_cast<const float4*>(ds + (r + q) * NO + c);   // LDS broadcast
@@ -378,12 +378,13 @@ extern "C" int clift_wgrad_narrow(const float* dY, int ldd, int no, const float*
                                   int x_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_wgrad_narrow: out_features must be in [1,32] (got %d)", no);
     if (M <= 0 || ni <= 0) return 0;
-    const int rpb = 128;
+    const int rpb = 128;        // (insensitive between 64 and 520 rows per block: the kernel is FMA-bound, not launch-shape-bound)
     const dim3 grid(cdiv(M, rpb), cdiv(ni, 256));
     hipStream_t st = as_stream(s);
     if (no <= 4) k_wgrad_narrow<4><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
     else if (no <= 8) k_wgrad_narrow<8><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
     else if (no <= 16) k_wgrad_narrow<16><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
+    else if (no <= 24) k_wgrad_narrow<24><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);   // 22 ScanNet classes
     else k_wgrad_narrow<32><<<grid, 256, 0, st>>>(dY, ldd, no, X, ldx, ni, M, rpb, gW, ldw, gb, x_bf16);
     return clift_check_launch("clift_wgrad_narrow");
 }

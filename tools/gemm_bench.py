@@ -43,3 +43,20 @@ for name, m, n, k, at, bt in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:16s} M={m:7d} N={n:4d} K={k:7d}  {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:7.1f} TFLOP/s")
+
+# narrow weight gradients go through engine.wgrad (clift_wgrad_narrow: VALU streaming kernel), not clift_gemm
+for no, ni in ((22, 256), (3, 256), (3, 128), (27, 144)):
+    ldd = (no + 3) // 4 * 4
+    dY = torch.randn(M, ldd, device=dev); X = torch.randn(M, ni, device=dev)
+    if stored and ni % 8 == 0:
+        X = X.to(torch.bfloat16)
+    gW = torch.zeros(no, ni, device=dev); gb = torch.zeros(no, device=dev)
+    for _ in range(3):
+        engine.wgrad(no, ni, M, dY, ldd, X, ni, gW, gb)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(10):
+        engine.wgrad(no, ni, M, dY, ldd, X, ni, gW, gb)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"narrow wgrad {no}x{ni:<4d} M={M:7d}  {ms*1e3:8.1f} us  {X.element_size()*M*ni/ms/1e6:7.1f} GB/s of X")
