@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--dtype", choices=["fp32", "bf16", "fp32x6"], default="fp32",
                     help="MLP operand precision: fp32 (headline, BASELINE configs[1]) or bf16 operands / fp32 accumulate (configs[2])")
     ap.add_argument("--inference-probe", action="store_true",
-                    help="also report frame-render throughput (adds larger launches of the same kernels: keep it out of profiled runs)")
+                    help="also report frame-render throughput and the lean main-pass time (both change the launch mix of the dominant "
+                         "kernel: keep them out of profiled runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -83,12 +84,51 @@ def main():
 
     for i in range(a.warmup):
         tr.training_step(batches[i % n_batches], lean=a.lean)
+    # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
+    # replays exactly these steps with per-launch events
+    snap = (model.param_flat.clone(), tr.opt_main.m.clone(), tr.opt_main.v.clone(), tr.opt_main.t,
+            tr.opt_inst.m.clone(), tr.opt_inst.v.clone(), tr.opt_inst.t)
     sync_all()
     t0 = time.perf_counter()
     for i in range(a.steps):
         tr.training_step(batches[i % n_batches], lean=a.lean)
     sync_all()
     dt = time.perf_counter() - t0
+    # ---- roofline pass: the SAME steps again from the same state (the active-sample count drifts while the field trains, so
+    # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
+    # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
+    # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
+    real_gemm = engine.gemm
+
+    def replay(select):
+        """Re-run the timed steps from the snapshot with the selected clift_gemm launches bracketed by HIP events."""
+        model.param_flat.copy_(snap[0])
+        tr.opt_main.m.copy_(snap[1]); tr.opt_main.v.copy_(snap[2]); tr.opt_main.t = snap[3]
+        tr.opt_inst.m.copy_(snap[4]); tr.opt_inst.v.copy_(snap[5]); tr.opt_inst.t = snap[6]
+        out = []
+
+        def recorded_gemm(M, N, K, *args, **kw):
+            kind = "wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd"
+            if not select(kind, N):
+                return real_gemm(M, N, K, *args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            real_gemm(M, N, K, *args, **kw)
+            e1.record()
+            out.append((kind, M, N, K, e0, e1))
+        engine.gemm = recorded_gemm
+        try:
+            for i in range(a.steps):
+                tr.training_step(batches[i % n_batches], lean=a.lean)
+            sync_all()
+        finally:
+            engine.gemm = real_gemm
+        return out
+    # pass 1: only the dominant kernel's launches (11 per step) -- few enough events that the step stays GPU-bound, so an event
+    # pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the informational all_gemm split (the
+    # ~80 events per step make that pass host-bound, so its per-launch times are upper bounds).
+    rec = replay(lambda kind, N: kind == "fwd" and N > 128)
+    rec_all = replay(lambda kind, N: True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -100,28 +140,28 @@ def main():
     extra = {}
     roof = None
     cpu = None
-    # ---- roofline of the dominant kernel: one instrumented step outside the timed region.  With several ranks every rank runs
-    # it (the step contains the gradient all-reduce), rank 0 reports.
-    roof = roofline(tr, batches[0], a.lean, engine, a.dtype)
+    if rank == 0:
+        roof = roofline(rec, rec_all, a.steps, engine, a.dtype)
     if rank == 0 and world == 1:
         # ---- per-pass split and sample statistics (outside the timed region)
-        def timed(fn, n=5):
+        def timed(fn, n=n_batches):          # cycles through the same batches as the timed loop
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for _ in range(n):
-                fn()
+            for i in range(n):
+                fn(batches[i % n_batches])
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
-        t_main = timed(lambda: tr.main_pass(batches[0][0], lean=a.lean))
-        t_inst = timed(lambda: tr.instance_pass(batches[0][1]))
-        t_lean = timed(lambda: tr.main_pass(batches[0][0], lean=True))     # informational: main pass without the discarded instance heads
+        t_main = timed(lambda b: tr.main_pass(b[0], lean=a.lean))
+        t_inst = timed(lambda b: tr.instance_pass(b[1]))
         ctxs = tr.main_pass(batches[0][0], lean=a.lean)
         M = sum(c.M for c in ctxs)
         inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
-        extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3), lean_main_pass_ms=round(t_lean * 1e3, 3),
+        extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
                      main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                      f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
-        if a.inference_probe:
+        if a.inference_probe:       # opt-in probes: they change the launch mix of the dominant kernel, so they stay out of profiled runs
+            t_lean = timed(lambda b: tr.main_pass(b[0], lean=True))            # main pass without the discarded instance heads
+            extra["lean_main_pass_ms"] = round(t_lean * 1e3, 3)
             extra.update(inference_probe(cl, model, renderer, pool))
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
@@ -165,30 +205,13 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
                 inference_samples_per_ray=S, inference_probe=f"{rays.shape[0]} rays, chunk {chunk}, fp32 outputs rgb/sem/inst/dist")
 
 
-def roofline(tr, batch, lean, engine, dtype="fp32"):
-    """Instrumented step (outside the timed region, same workload): every clift_gemm launch is bracketed by HIP events on
-    the stream it is launched on (torch's current stream; the side-stream mode is off by default).  The dominant kernel
-    by time is the instantiation k_gemm<128,256,2,4,false,false> = the 256x256 forward layers of the semantic / fast /
-    slow instance MLPs (rocprofv3 lists it under exactly that name, profiles/r01_*): achieved = its algorithmic FLOPs
-    (2*M*256*256 per launch, M = active samples of the pass) / its summed launch durations; peak = dense fp32 MFMA.
-    ``all_gemm`` is the same ratio over every matrix-core launch of the step (forward, dgrad, wgrad, narrow layers)."""
-    rec = []
-    real = engine.gemm
-
-    def wrapped(M, N, K, *args, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        real(M, N, K, *args, **kw)
-        e1.record()
-        kind = ("wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd")
-        rec.append((kind, M, N, K, e0, e1))
-    engine.gemm = wrapped
-    try:
-        tr.main_pass(batch[0], lean=lean)
-        tr.instance_pass(batch[1])
-        torch.cuda.synchronize()
-    finally:
-        engine.gemm = real
+def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
+    """``rec`` = the (kind, M, N, K, start event, end event) records of every clift_gemm launch of the ``nb`` timed steps.  The
+    dominant kernel by time is the instantiation k_gemm<128,256,2,4,false,false,true> = the 256x256 forward layers of the
+    semantic / fast / slow instance MLPs (rocprofv3 lists it under exactly that name, profiles/r01_*): achieved = its
+    algorithmic FLOPs (2*M*256*256 per launch, M = active samples of the pass) / its summed launch durations; peak = dense fp32
+    MFMA.  ``all_gemm`` is the same ratio over every matrix-core launch (forward, dgrad, wgrad, narrow layers).  The active-sample
+    count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
     tot_f, tot_ms, by = 0.0, 0.0, {}
     dom_f, dom_ms, dom_n = 0.0, 0.0, 0
     for kind, M, N, K, e0, e1 in rec:
@@ -198,22 +221,22 @@ def roofline(tr, batch, lean, engine, dtype="fp32"):
         tot_ms += ms
         b = by.setdefault(kind, [0.0, 0.0, 0])
         b[0] += fl; b[1] += ms; b[2] += 1
-        if kind == "fwd" and N > 128:
-            dom_f += fl; dom_ms += ms; dom_n += 1
+    for kind, M, N, K, e0, e1 in rec_dom:
+        dom_f += 2.0 * M * N * K; dom_ms += e0.elapsed_time(e1); dom_n += 1
     tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ach = tf(dom_f, dom_ms)
     if dtype == "bf16":
         # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its
         # activations.  Algorithmic bytes per launch = A read + C written (M x 256 x 2 bytes each, bf16-stored) + weights (256 KB, L2).
         esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
-        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec if kind == "fwd" and N > 128)
+        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec_dom)
         gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         return {"bound": "hbm", "kernel": "k_gemm_bf16<128,256,2,4,false,false,true,true> (v_mfma_f32_32x32x16_bf16; 256x256 forward MLP layers, bf16-stored activations)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
-                "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec), "ms_per_step": tot_ms,
-                             "gflop_per_step": tot_f / 1e9,
-                             "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+                "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
+                "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
+                             "gflop_per_step": tot_f / 1e9 / nb,
+                             "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
     return {"bound": "mfma", "kernel": "k_gemm<128,256,2,4,false,false> (fp32 v_mfma_f32_32x32x2_f32; 256x256 forward MLP layers)",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
             # HBM bytes per (average) launch of the dominant kernel: PMC ratio measured offline with separate rocprofv3 --pmc
@@ -221,10 +244,10 @@ def roofline(tr, batch, lean, engine, dtype="fp32"):
             # 543 MB algorithmic = A read + C written, weights L2-resident), applied to this run's average launch size
             "traffic": (541.0 / 543.0) * (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0,
             "traffic_unit": "bytes/launch (PMC ratio 541/543 from profiles/r01_gemm_pmc_notes.txt x algorithmic 8 B per output element)",
-            "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
-            "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec),
-                         "ms_per_step": tot_ms, "gflop_per_step": tot_f / 1e9,
-                         "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1], "launches": v[2]} for k, v in by.items()}}}
+            "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
+            "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
+                         "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
+                         "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
 
 
 def usable_cores():
