@@ -136,6 +136,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     if MLP_PRECISION == 2 and not a_trans and not accumulate and not c_trans:
         nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)          # split weight planes (stream-ordered scratch)
+        if _lib._launch_stream is not None:       # launched on a side stream (Branches): the allocator must not recycle it earlier
+            ws.record_stream(_lib._launch_stream)
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     call("clift_gemm", C.byref(g), stream())
 
