@@ -887,3 +887,83 @@ def test_shrink_and_upsample_golden_g10():
     rays = torch.tensor([[0.0, 0.0, -0.9, 0.0, 0.0, 1.0, 0.01, 1.9]], device=DEV)
     rgb, *_ = r.forward(m, rays, 0, False, False)
     assert bool(torch.isfinite(rgb).all())
+
+
+def test_pq_scene_parity_after_training():
+    """north_star: "PSNR/PQ_scene within 0.1".  The HIP trainer learns a scene whose labels are functions of the 3-D surface
+    point (300 steps: main pass with one-hot semantic targets + slow-fast instance pass); the trained weights are then rendered
+    on a held-out 40x40 view by the HIP renderer and by the CPU oracle, the instance embeddings of each render are clustered
+    with the MeanShift pipeline (inference.cluster, same numpy seed) and scored with the panoptic-quality evaluator (pinned by
+    goldens G11/G16) against the ground-truth panoptic map: PQ / SQ / RQ / mIoU (x100) and PSNR (dB) of the two renders of the
+    same checkpoint agree to 0.1.  (Parity of the training trajectory itself is the previous tests' subject.)"""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from contrastive_lift_amd.inference import render_rays, create_instances_from_semantics, cluster, ConfusionMatrix
+    from contrastive_lift_amd.metrics import panoptic_quality
+    res, C_, E, B, Bi, steps = (24, 28, 32), 5, 3, 640, 256, 300
+    things, stuff = [3, 4], [0, 1, 2]
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P = op.add_blob(op.make_params(123, res, C_, E), res, amplitude=2.3, sigma_g=0.42)
+    rng = np.random.default_rng(124)
+    cfg_o = orender.RenderCfg(aabb, res, density_shift=-3.0)
+
+    def view_rays(eye, img):
+        eye = np.asarray(eye, np.float64); f = -eye / np.linalg.norm(eye)
+        rt = np.cross(f, [0.0, 1.0, 0.0]); rt /= np.linalg.norm(rt)
+        M = np.eye(4); M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = rt, np.cross(f, rt), f, eye
+        K = torch.tensor([[img * 0.8, 0, img / 2], [0, img * 0.8, img / 2], [0, 0, 1]])
+        return orays.ray_table(img, img, K, torch.tensor(M, dtype=torch.float32)).contiguous()
+    pool = torch.cat([view_rays(e, 48) for e in ((0.0, 0.1, -0.9), (0.35, -0.1, -0.8), (-0.35, 0.2, -0.78), (0.0, 0.45, -0.75))], 0)
+
+    def ground_truth(rays):          # labels from the surface point of the INITIAL field (identical on both sides)
+        with torch.no_grad():
+            out, aux = orender.render_forward(P, rays, cfg_o, return_aux=True)
+        p = rays[:, :3] + out[3][:, None] / aux["opacity"].clamp_min(1e-3)[:, None] * rays[:, 3:6]     # expected termination point
+        sem = 1 + (p[:, 0] > 0).long() + 2 * (p[:, 1] > 0).long()              # classes 1..4 by quadrant; 3 and 4 are things
+        inst = torch.where(sem >= 3, (sem - 3) * 2 + (p[:, 0].abs() > 0.1).long() + 1, torch.zeros_like(sem))   # two bands per thing class
+        rgb = 0.5 + 0.5 * torch.sin(4.0 * p + torch.tensor([0.0, 1.0, 2.0]))
+        return sem, inst, rgb.contiguous()
+    sem_all, inst_all, rgb_all = ground_truth(pool)
+    thing_idx = torch.nonzero(inst_all > 0)[:, 0]
+    assert thing_idx.numel() > 4 * Bi // 2 and len(torch.unique(inst_all[thing_idx])) == 4
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    tr = HotPathTrainer(m, r, default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0), current_epoch=4)
+    for step in range(steps):
+        pick = torch.from_numpy(rng.choice(pool.shape[0], B, replace=False))
+        ipick = thing_idx[torch.from_numpy(rng.choice(thing_idx.numel(), Bi, replace=False))]
+        rays_main, rays_inst = pool[pick].contiguous(), pool[ipick].contiguous()
+        rgbs = rgb_all[pick].contiguous()
+        probs = (torch.nn.functional.one_hot(sem_all[pick], C_).float() * 0.9 + 0.02).contiguous()
+        conf = torch.ones(B)
+        labels, iconf = inst_all[ipick].contiguous(), torch.ones(Bi)
+        jit = torch.from_numpy(rng.uniform(0, 1, B).astype(np.float32))
+        jit_i = torch.from_numpy(rng.uniform(0, 1, Bi).astype(np.float32))
+        tr.main_pass(dict(rays=rays_main.to(DEV), rgbs=rgbs.to(DEV), probabilities=probs.to(DEV), confidences=conf.to(DEV), mask=None),
+                     jitter=jit.to(DEV), white_bg=True)
+        tr.instance_pass([dict(rays=rays_inst.to(DEV), instances=labels.to(DEV), confidences=iconf.to(DEV))], jitter=jit_i.to(DEV))
+    # held-out view
+    view = view_rays((0.1, 0.05, -0.88), 40)
+    gt_sem, gt_inst, gt_rgb = ground_truth(view)
+    target = torch.stack([gt_sem, gt_inst], -1)
+    with torch.no_grad():
+        trained = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if k in P}
+        o_rgb, o_sem, o_inst, *_ = orender.render_forward(trained, view, cfg_o, white_bg=True)
+    g_rgb, g_sem, g_inst, _ = render_rays(m, r, view.to(DEV), 0, white_bg=True)
+
+    def score(rgb, sem, inst):
+        sem, inst = sem.detach().cpu(), inst.detach().cpu()
+        feats = create_instances_from_semantics(inst[:, :E], sem, things)
+        np.random.seed(7)
+        onehot, _ = cluster(feats.numpy(), 0.15, "cpu", 1)
+        ids = onehot[0].argmax(-1)
+        pq, sq, rq = panoptic_quality(torch.stack([sem.argmax(-1), ids], -1), target, things, stuff)
+        cm = ConfusionMatrix(C_, ignore_class=[])
+        cm.add_batch(sem.argmax(-1).numpy(), gt_sem.numpy())
+        ps = float(-10.0 * torch.log10(((rgb.detach().cpu() - gt_rgb) ** 2).mean()))
+        return 100 * float(pq), 100 * float(sq), 100 * float(rq), 100 * float(cm.get_miou()), ps
+    so, sg = score(o_rgb, o_sem, o_inst), score(g_rgb, g_sem, g_inst)
+    print("PQ/SQ/RQ/mIoU/PSNR  oracle %s   HIP %s" % (["%.3f" % x for x in so], ["%.3f" % x for x in sg]))
+    assert so[0] > 20.0, so                      # the scene was learned well enough for PQ to mean something
+    for a, b, what in zip(so, sg, ("PQ", "SQ", "RQ", "mIoU", "PSNR")):
+        assert abs(a - b) <= 0.1, (what, a, b)
