@@ -279,6 +279,10 @@ int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits,
     // storage combinations that exist: streamed operands bf16-stored together (A; and B exactly in the wgrad form), weights fp32
     CLIFT_REQUIRE(!p.b_bf16 || (p.a_bf16 && a_trans && b_trans), "clift_gemm(bf16): a bf16-stored B needs the wgrad form with a bf16-stored A");
     CLIFT_REQUIRE(!(p.a_bf16 && a_trans && b_trans) || p.b_bf16, "clift_gemm(bf16): the wgrad form takes both streamed operands bf16-stored or neither");
+    if (!a_trans && p.N == 256 && p.K == 256 && p.M >= 64 && p.a_bf16 && p.c_bf16 && splits == 1 && !p.accumulate && !p.c_trans &&
+        p.lda % 8 == 0 && p.ldc % 8 == 0 && ((((uintptr_t)p.A) | ((uintptr_t)p.C)) & 15) == 0 && p.ldb % 4 == 0 && (((uintptr_t)p.B) & 15) == 0 &&
+        (b_trans ? (p.mask && p.mask_bf16 && !p.bias && p.act == 0 && p.ldmask % 8 == 0 && (((uintptr_t)p.mask) & 15) == 0) : !p.mask))
+        return clift_layer_bf16_launch(p, b_trans, st);             // streamed hidden layer: persistent blocks, weights in registers
     if (p.N > 128) return launch_gemm_h<128, 256, 2, 4>(p, a_trans, b_trans, splits, st);
     if (p.N > 32) return launch_gemm_h<128, 128, 2, 2>(p, a_trans, b_trans, splits, st);
     return launch_gemm_h<256, 32, 4, 1>(p, a_trans, b_trans, splits, st);

@@ -1,0 +1,181 @@
+// layer_bf16.hip -- the 256 -> 256 hidden layers of the bf16 mode (forward: C = relu(A W^T + b); dgrad: C = mask . (A W)), with the
+// streamed tensors (A, C, mask) bf16-STORED.  At bf16 MFMA rate a 64 x 256 x 256 tile is ~1 us of matrix-core time, so these
+// launches are HBM streams (512 B in + 512 B out per row, + 512 B of mask in the dgrad) and the generic tiled kernel
+// (gemm_bf16.hip: 8 k-tiles per block, one global round trip each, 256 KB of weights re-read per 128 rows) spends its time on
+// latency, not bandwidth.  Here instead:
+//   * one persistent 8-wave block per CU, each owning a contiguous range of rows (balanced to 32 rows: no tail wave of tiles);
+//   * the whole weight matrix lives in REGISTERS: wave w owns output columns 32 w .. +31 for all 256 k, i.e. sixteen bf16x8
+//     B-fragments = 64 VGPRs, loaded (and rounded from fp32) once per block;
+//   * the activation rows (and the mask rows) stream through a ring of 32 KB LDS buffers filled by LDS-DMA
+//     (global_load_lds_dwordx4: no staging VGPRs), DEPTH tiles ahead of the multiply; waits are counted (s_waitcnt vmcnt(N) with
+//     N = the vector-memory instructions this wave issued after the tile's DMA: later DMAs and the 16-byte output stores, which
+//     complete in order on gfx9-family hardware) so neither the stores nor the younger DMAs are drained at the tile boundary.
+//     The LDS image is lane-linear (a DMA constraint), so the bank swizzle is applied at the SOURCE: 16-byte chunk c of row r
+//     lands in slot c ^ (r & 15), which makes the ds_read_b128 fragment reads (16 consecutive rows, same k) conflict-free;
+//   * operands swapped in the MFMA (weights first): a lane owns one output row; v_permlane32_swap pairs the two half-waves'
+//     4-column groups into 8 consecutive bf16 so that every store / mask read is 16 bytes per lane.
+#include "gemm_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int LY_ROWS = 64;                 // rows per streamed tile (two 32-row MFMA tiles per wave)
+constexpr int LY_TILE = LY_ROWS * 32;       // uint4 per tile: 64 rows x 512 B
+
+static __device__ __forceinline__ bf16x8 cvt8(const float4 a, const float4 b) {
+    bf16x8 r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+}
+static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    return (unsigned)float_to_bf16_bits(lo) | ((unsigned)float_to_bf16_bits(hi) << 16);
+}
+static __device__ __forceinline__ unsigned keep_positive(unsigned v, unsigned mk) {      // per 16-bit half: v where the mask half is > 0
+    const unsigned lo = bf16_bits_positive((unsigned short)(mk & 0xffffu)) ? 0x0000ffffu : 0u;
+    const unsigned hi = bf16_bits_positive((unsigned short)(mk >> 16)) ? 0xffff0000u : 0u;
+    return v & (lo | hi);
+}
+template <int N>
+static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+static __device__ __forceinline__ void wait_vm_upto(int n) {       // wave-uniform n, a multiple of 4 (everything here issues in fours)
+    if (n >= 36) wait_vm<36>();
+    else if (n >= 32) wait_vm<32>();
+    else if (n >= 28) wait_vm<28>();
+    else if (n >= 24) wait_vm<24>();
+    else if (n >= 20) wait_vm<20>();
+    else if (n >= 16) wait_vm<16>();
+    else if (n >= 12) wait_vm<12>();
+    else if (n >= 8) wait_vm<8>();
+    else if (n >= 4) wait_vm<4>();
+    else wait_vm<0>();
+}
+
+// DGRAD = false: forward, weights stored [n][k], bias + ReLU;  DGRAD = true: weights stored [k][n], bf16-stored ReLU mask.
+// DEPTH = tiles in flight ahead of the multiply; the ring has DEPTH + 1 stages of 32 KB (A) [+ 32 KB (mask)].
+template <bool DGRAD, int DEPTH>
+__global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_block) {
+    constexpr int NST = DEPTH + 1, STAGE = (DGRAD ? 2 : 1) * LY_TILE, PER_DMA = DGRAD ? 8 : 4;
+    __shared__ __attribute__((aligned(16))) uint4 lds[NST * STAGE];        // the only LDS object of the kernel
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + LY_ROWS - 1) / LY_ROWS;
+
+    bf16x8 w[16];
+    float bias[16];
+    {
+        const int n = 32 * wave + li;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 16 * s + 8 * lh;
+            if (!DGRAD) {
+                const float4* q = reinterpret_cast<const float4*>(g.B + (size_t)n * g.ldb + k);
+                w[s] = cvt8(q[0], q[1]);
+            } else {
+                const float* q = g.B + (size_t)k * g.ldb + n;
+                const size_t ld = (size_t)g.ldb;
+                w[s] = cvt8(make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]), make_float4(q[4 * ld], q[5 * ld], q[6 * ld], q[7 * ld]));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = (!DGRAD && g.bias) ? g.bias[32 * wave + 8 * q + 4 * lh + e] : 0.f;
+    }
+    wait_vm<0>();                                                           // ordinary loads are done before the first DMA is issued
+    const unsigned short* A16 = reinterpret_cast<const unsigned short*>(g.A);
+    const unsigned short* K16 = reinterpret_cast<const unsigned short*>(g.mask);
+    unsigned short* C16 = reinterpret_cast<unsigned short*>(g.C);
+    auto dma = [&](int t) {                                                 // tile t of this block -> stage t % NST
+        const int r0 = rbeg + t * LY_ROWS;
+        uint4* st = lds + (t % NST) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int inst = wave * 4 + i;                                  // wave-uniform: 1 KB = two rows per instruction
+            const int row = inst * 2 + lh, c = li ^ (row & 15);              // LDS slot li of the row <- source chunk c
+            const int gr = min(r0 + row, rend - 1);                          // rows past the range re-read its last row (never stored)
+            __builtin_amdgcn_global_load_lds(A16 + (size_t)gr * g.lda + c * 8, (lds_ptr_t)(st + inst * 64), 16, 0, 0);
+            if (DGRAD) __builtin_amdgcn_global_load_lds(K16 + (size_t)gr * g.ldmask + c * 8, (lds_ptr_t)(st + LY_TILE + inst * 64), 16, 0, 0);
+        }
+    };
+    // vector-memory instructions issued by this wave after the DMA of tile t, at the time tile t is needed:
+    //   DMAs of tiles t+1 .. min(t+DEPTH, ntiles-1)  and the stores (4 per tile) of tiles max(0, t-DEPTH) .. t-1
+    for (int t = 0; t < DEPTH && t < ntiles; ++t) dma(t);
+    for (int t = 0; t < ntiles; ++t) {
+        const int younger = PER_DMA * (min(t + DEPTH, ntiles - 1) - t) + 4 * (t - max(0, t - DEPTH));
+        wait_vm_upto(younger);                                              // this wave's part of tile t has landed
+        __builtin_amdgcn_s_barrier();                                        // ... and everyone's; everyone is done reading stage (t-1) % NST
+        asm volatile("" ::: "memory");
+        if (t + DEPTH < ntiles) dma(t + DEPTH);                              // refill the stage that tile t-1 just vacated
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        const uint4* T = lds + (t % NST) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int slot = (2 * s + lh) ^ (li & 15);
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, T[li * 32 + slot]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, T[(li + 32) * 32 + slot]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], a0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], a1, acc[1], 0, 0, 0);
+        }
+        // epilogue: lane (li, lh) holds row li of each 32-row tile, columns 32 wave + 8 q + 4 lh + (0..3) for q = 0..3
+        const int r0 = rbeg + t * LY_ROWS;
+        uint4 mk[4];
+        if (DGRAD) {
+            // the mask rows were DMA'd next to the A rows.  Read them with inline asm: beside an in-flight LDS-DMA the compiler
+            // guards every ordinary read of this array with s_waitcnt vmcnt(0) -- which would drain the prefetched tile and the stores
+            unsigned ad[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = (4 * wave + 2 * (j & 1) + lh) ^ (li & 15);
+                ad[j] = (unsigned)(uintptr_t)(lds_ptr_t)(T + LY_TILE + (32 * (j >> 1) + li) * 32 + slot);
+            }
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(mk[0]), "=&v"(mk[1]), "=&v"(mk[2]), "=&v"(mk[3])
+                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                         : "memory");
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int m = r0 + 32 * x + li;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                unsigned P0[2], P1[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = 2 * qp + h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[x][4 * q + e] + bias[4 * q + e];
+                        if (!DGRAD && g.act == 1) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    (h ? P1 : P0)[0] = pack_bf16(v[0], v[1]);
+                    (h ? P1 : P0)[1] = pack_bf16(v[2], v[3]);
+                }
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap(P0[0], P1[0], false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap(P0[1], P1[1], false, false);
+                uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);          // 8 consecutive columns from 32 wave + 8 (2 qp + lh)
+                if (DGRAD) {
+                    const uint4 k4 = mk[2 * x + qp];
+                    o.x = keep_positive(o.x, k4.x); o.y = keep_positive(o.y, k4.y);
+                    o.z = keep_positive(o.z, k4.z); o.w = keep_positive(o.w, k4.w);
+                }
+                if (m < rend) *reinterpret_cast<uint4*>(C16 + (size_t)m * g.ldc + 32 * wave + 8 * (2 * qp + lh)) = o;
+            }
+        }
+    }
+}
+
+// Eligibility is decided by the caller (gemm_bf16.hip): N = K = 256, plain A, bf16-stored A / C (/ mask), 16-byte-aligned rows.
+int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st) {
+    const int tiles = cdiv(p.M, LY_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;                    // one persistent block per CU
+    const int rpb = cdiv(cdiv(p.M, blocks), 32) * 32;
+    if (b_trans) k_layer_bf16<true, 1><<<blocks, 512, 0, st>>>(p, rpb);
+    else k_layer_bf16<false, 3><<<blocks, 512, 0, st>>>(p, rpb);
+    return clift_check_launch("clift_gemm(bf16 layer)");
+}

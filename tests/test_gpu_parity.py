@@ -208,6 +208,42 @@ def test_gemm_bf16_stored_operands(M, N, K):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("M", [64, 65, 97, 300, 8191, 33000, 174001])
+def test_streamed_bf16_hidden_layer(M):
+    """layer_bf16.hip (persistent blocks, weights in registers, LDS-DMA ring, counted waits): the 256 -> 256 forward (bias + ReLU)
+    and masked dgrad with bf16-stored tensors, element by element against fp64 products of the same bf16 values -- every row of
+    ragged row ranges, tile boundaries and multi-tile blocks; rows beyond M and the pad columns stay untouched."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M)
+    bf = torch.bfloat16
+    A = torch.randn((M, 256), generator=g).to(bf)
+    W = (torch.randn((256, 256), generator=g) / 16).contiguous()
+    bias = torch.randn(256, generator=g)
+    Wr = W.to(bf).double()
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        Ad, Wd = A.to(DEV), W.to(DEV)
+        out = torch.full((M + 3, 256), -7.0, dtype=bf, device=DEV)
+        engine.gemm(M, 256, 256, Ad, 256, Wd, 256, out, 256, bias=bias.to(DEV), act=1)
+        want = torch.relu(A.double() @ Wr.T + bias.double())
+        got = out[:M].double().cpu()
+        tol = want.abs() / 256 + 2e-5 * float(want.abs().max())               # one bf16 rounding of the output + summation order
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() - tol).max())
+        assert bool((out[M:] == -7.0).all())
+        dY = torch.randn((M, 256), generator=g).to(bf)
+        mask = torch.relu(torch.randn((M, 256), generator=g)).to(bf)
+        dX = torch.full((M + 3, 256), -7.0, dtype=bf, device=DEV)
+        engine.gemm(M, 256, 256, dY.to(DEV), 256, Wd, 256, dX, 256, b_trans=1, mask=mask.to(DEV), ldmask=256)
+        wantd = (dY.double() @ Wr) * (mask.double() > 0)
+        gotd = dX[:M].double().cpu()
+        told = wantd.abs() / 256 + 2e-5 * float(wantd.abs().max())
+        assert bool(((gotd - wantd).abs() <= told).all()), float(((gotd - wantd).abs() - told).max())
+        assert bool((dX[M:] == -7.0).all())
+        assert bool((gotd[mask.double() <= 0] == 0).all())
+    finally:
+        engine.set_mlp_precision(prev)
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine

@@ -31,6 +31,10 @@ for name, m, n, k, at, bt in shapes:
         if (A.shape[1] % 8) or (at and B.shape[1] % 8):
             continue
     kw = dict(a_trans=at, b_trans=bt)
+    if not at and bt and n % 8 == 0:      # dgrad of a hidden layer: ReLU mask of the layer input (same storage as the output)
+        kw.update(mask=torch.relu(torch.randn(m, n, device=dev)).to(Cm.dtype), ldmask=n)
+    if not at and not bt:
+        kw.update(bias=torch.randn(n, device=dev), act=1)
     if at:
         kw.update(accumulate=1, split_k=engine._splits(m, n, k))
     for _ in range(3):
