@@ -283,6 +283,9 @@ int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits,
         p.lda % 8 == 0 && p.ldc % 8 == 0 && ((((uintptr_t)p.A) | ((uintptr_t)p.C)) & 15) == 0 && p.ldb % 4 == 0 && (((uintptr_t)p.B) & 15) == 0 &&
         (b_trans ? (p.mask && p.mask_bf16 && !p.bias && p.act == 0 && p.ldmask % 8 == 0 && (((uintptr_t)p.mask) & 15) == 0) : !p.mask))
         return clift_layer_bf16_launch(p, b_trans, st);             // streamed hidden layer: persistent blocks, weights in registers
+    if (a_trans && b_trans && p.M == 256 && p.N == 256 && p.K >= 64 && p.a_bf16 && p.b_bf16 && p.accumulate && !p.c_trans && !p.bias && !p.mask &&
+        p.lda % 8 == 0 && p.ldb % 8 == 0 && ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) == 0)
+        return clift_wgrad_bf16_stream_launch(p, st);              // streamed weight gradient: persistent blocks, transposed LDS reads
     if (p.N > 128) return launch_gemm_h<128, 256, 2, 4>(p, a_trans, b_trans, splits, st);
     if (p.N > 32) return launch_gemm_h<128, 128, 2, 2>(p, a_trans, b_trans, splits, st);
     return launch_gemm_h<256, 32, 4, 1>(p, a_trans, b_trans, splits, st);

@@ -179,3 +179,141 @@ int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st) {
     else k_layer_bf16<false, 3><<<blocks, 512, 0, st>>>(p, rpb);
     return clift_check_launch("clift_gemm(bf16 layer)");
 }
+
+// ============================================================================ streamed weight gradient of the same layers
+// gW[n][k] += sum_m dY[m][n] X[m][k]  (+ gb[n] += sum_m dY[m][n]),  dY and X bf16-stored [m][256].  Both MFMA operands want 8
+// consecutive m per lane, i.e. a COLUMN of the row-major tiles: the fragments are gathered with ds_read_b64_tr_b16 (a 16-lane
+// group reads a [4 m][16 col] block, lane q receives column q), two per fragment.  One persistent block per CU owns a
+// contiguous range of rows and the full 256 x 256 product (8 waves = 2 (n) x 4 (k), 128 x 64 per wave = 128 accumulator
+// VGPRs); row tiles of 64 stream through a two-stage LDS ring by LDS-DMA (dY tile + X tile = 64 KB per stage).
+// Swizzle (at the DMA source, the image being lane-linear): 16-byte chunk c of row r sits in slot c ^ ((r & 3) << 2), so the four
+// rows of a transposed read land in four different 64-byte bank spans.  All LDS reads are inline asm (see the mask reads above).
+// The partial products are added to gW with fp32 atomics at the end (the same count as the split-K launch this replaces).
+static __device__ __forceinline__ uint2 tr_read(unsigned addr) {
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+static __device__ __forceinline__ float bf16_pair_sum(unsigned u) { return __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u); }
+
+__global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_per_block) {
+    constexpr int STAGE = 2 * LY_TILE;                                        // uint4 per stage: dY tile then X tile
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * STAGE];            // 128 KB, the only LDS object
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wn = wave >> 2, wk = wave & 3;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(g.K, rbeg + rows_per_block);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + LY_ROWS - 1) / LY_ROWS;
+    const unsigned short* Y16 = reinterpret_cast<const unsigned short*>(g.A);
+    const unsigned short* X16 = reinterpret_cast<const unsigned short*>(g.B);
+    auto dma = [&](int t) {
+        const int r0 = rbeg + t * LY_ROWS;
+        uint4* st = lds + (t & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int inst = wave * 4 + i;
+            const int row = inst * 2 + lh, c = li ^ ((row & 3) << 2);
+            const int gr = min(r0 + row, rend - 1);                          // a ragged last tile is zero-filled after it lands
+            __builtin_amdgcn_global_load_lds(Y16 + (size_t)gr * g.lda + c * 8, (lds_ptr_t)(st + inst * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(X16 + (size_t)gr * g.ldb + c * 8, (lds_ptr_t)(st + LY_TILE + inst * 64), 16, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float csum = 0.f;
+    // lane-constant part of the fragment addresses (bytes): row 8 lh + ((lane & 15) >> 2), column block by tile, 8-byte half
+    const int s = (lane >> 2) & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const unsigned lrow = (unsigned)((8 * lh + ((lane & 15) >> 2)) * 512 + ((lane >> 4) & 1) * 32 + ((lane & 3) >> 1) * 16 + (lane & 1) * 8);
+    unsigned ya[4], xa[2];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) ya[tn] = lds0 + lrow + (unsigned)((16 * wn + 4 * (tn ^ s)) * 16);
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) xa[tk] = lds0 + LY_TILE * 16 + lrow + (unsigned)(((8 * wk + 4 * tk) ^ (4 * s)) * 16);
+
+    dma(0);
+    for (int t = 0; t < ntiles; ++t) {
+        wait_vm<0>();                                                        // tile t (this wave's part) has landed; nothing else is in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntiles) dma(t + 1);
+        const int valid = rend - (rbeg + t * LY_ROWS);
+        if (valid < LY_ROWS) {                                               // zero the rows past the end (only the last tile of the last block)
+            uint4* st = lds + (t & 1) * STAGE;
+            for (int e = tid; e < (LY_ROWS - valid) * 32; e += 512) {
+                st[valid * 32 + e] = make_uint4(0u, 0u, 0u, 0u);
+                st[LY_TILE + valid * 32 + e] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+        }
+        const unsigned so = (unsigned)((t & 1) * STAGE * 16);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            uint2 yr[4][2], xr[2][2];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) yr[tn][p] = tr_read(ya[tn] + so + (unsigned)((16 * ms + 4 * p) * 512));
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xr[tk][p] = tr_read(xa[tk] + so + (unsigned)((16 * ms + 4 * p) * 512));
+            // the wait must be a data dependency of every fragment: a bare asm wait does not stop the compiler from scheduling the
+            // MFMAs (plain register consumers of the read results) above it
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(yr[0][0]), "+v"(yr[0][1]), "+v"(yr[1][0]), "+v"(yr[1][1]), "+v"(yr[2][0]), "+v"(yr[2][1]), "+v"(yr[3][0]), "+v"(yr[3][1]),
+                           "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1])
+                         :
+                         : "memory");
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) a[tn] = __builtin_bit_cast(bf16x8, make_uint4(yr[tn][0].x, yr[tn][0].y, yr[tn][1].x, yr[tn][1].y));
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk) b[tk] = __builtin_bit_cast(bf16x8, make_uint4(xr[tk][0].x, xr[tk][0].y, xr[tk][1].x, xr[tk][1].y));
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < 2; ++tk) acc[tn][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tn], b[tk], acc[tn][tk], 0, 0, 0);
+            if (g.colsum) {      // bias gradient: wave (wn, wk) sums the dY columns of its n-tile tn == wk (spread over the four k-waves)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    if (tn == wk) csum += (bf16_pair_sum(yr[tn][0].x) + bf16_pair_sum(yr[tn][0].y)) + (bf16_pair_sum(yr[tn][1].x) + bf16_pair_sum(yr[tn][1].y));
+            }
+        }
+    }
+    // lane (li, lh) holds gW rows n = 128 wn + 32 tn + 8 q + 4 lh + e, column k = 64 wk + 32 tk + li.  All blocks finish together:
+    // each starts its flush at a different tile (rotation by block index) so that they do not queue up on the same cache lines.
+    const int rot = blockIdx.x & 7;
+    for (int ph = 0; ph < 8; ++ph) {
+        const int idx = (ph + rot) & 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c != idx) continue;
+            const int tn = c >> 1, tk = c & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 128 * wn + 32 * tn + 8 * (r >> 2) + 4 * lh + (r & 3), k = 64 * wk + 32 * tk + li;
+                unsafeAtomicAdd(g.C + (size_t)n * g.ldc + k, acc[tn][tk][r]);
+            }
+        }
+    }
+    if (g.colsum) {          // fold the two m-halves (lanes l, l + 32) first: one atomic per address and wave
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(csum), __float_as_uint(csum), false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (lh == 0) unsafeAtomicAdd(g.colsum + 128 * wn + 32 * wk + li, tot);
+    }
+}
+
+// Eligibility decided by the caller: M = N = 256 (gW is 256 x 256), both streamed operands bf16-stored with 16-byte-aligned rows.
+int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st) {
+    const int tiles = cdiv(p.K, LY_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(p.K, blocks), LY_ROWS) * LY_ROWS;
+    k_wgrad_bf16_stream<<<cdiv(p.K, rpb), 512, 0, st>>>(p, rpb);
+    return clift_check_launch("clift_gemm(bf16 wgrad stream)");
+}

@@ -244,6 +244,29 @@ def test_streamed_bf16_hidden_layer(M):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("M", [64, 65, 200, 4096, 70001, 174001])
+def test_streamed_bf16_weight_gradient(M):
+    """k_wgrad_bf16_stream (persistent blocks, both operands by LDS-DMA, ds_read_b64_tr_b16 fragments): gW += dY^T X and the fused
+    bias sums for the 256 x 256 layers with bf16-stored operands, against fp64 on the same bf16 values; accumulates onto existing
+    contents; ragged row counts (zero-filled last tile)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 11)
+    bf = torch.bfloat16
+    dY = torch.randn((M, 256), generator=g).to(bf)
+    X = torch.relu(torch.randn((M, 256), generator=g)).to(bf)
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        gW = torch.full((256, 256), 0.5, device=DEV)
+        gb = torch.full((256,), -2.0, device=DEV)
+        engine.wgrad(256, 256, M, dY.to(DEV), 256, X.to(DEV), 256, gW, gb)
+        refw = dY.double().T @ X.double() + 0.5
+        refb = dY.double().sum(0) - 2.0
+        rel_close(gW, refw, 1e-4, atol=1e-4 * float(refw.abs().max()), what="streamed wgrad")
+        rel_close(gb, refb, 1e-4, atol=1e-4 * M ** 0.5, what="streamed bias sums")
+    finally:
+        engine.set_mlp_precision(prev)
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
