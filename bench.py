@@ -231,7 +231,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
         esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
         dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec_dom)
         gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "k_gemm_bf16<128,256,2,4,false,false,true,true> (v_mfma_f32_32x32x16_bf16; 256x256 forward MLP layers, bf16-stored activations)",
+        return {"bound": "hbm", "kernel": "k_layer_bf16<false,3> (persistent streamed 256x256 forward layers: weights in registers, LDS-DMA ring, v_mfma_f32_32x32x16_bf16; bf16-stored activations)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                 "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
                 "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
