@@ -38,6 +38,7 @@ static inline bool gemm_vector_epilogue_ok(const GemmP& p) {
 int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st);   // gemm_bf16.hip
 int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_bf16.hip
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st);
+int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st);                             // layer_f32.hip
 long clift_gemm_split_workspace_bytes(int N, int K);                                                // gemm_split.hip
 int clift_gemm_split_launch(const GemmP& p, int a_trans, int b_trans, void* workspace, hipStream_t st);
 

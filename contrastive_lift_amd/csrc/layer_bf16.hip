@@ -100,11 +100,12 @@ __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_blo
             if (DGRAD) __builtin_amdgcn_global_load_lds(K16 + (size_t)gr * g.ldmask + c * 8, (lds_ptr_t)(st + LY_TILE + inst * 64), 16, 0, 0);
         }
     };
-    // vector-memory instructions issued by this wave after the DMA of tile t, at the time tile t is needed:
-    //   DMAs of tiles t+1 .. min(t+DEPTH, ntiles-1)  and the stores (4 per tile) of tiles max(0, t-DEPTH) .. t-1
+    // vector-memory instructions issued by this wave after the DMA of tile t, at the time tile t is needed (the DMA of tile
+    // t + DEPTH is issued only after that wait): DMAs of tiles t+1 .. min(t+DEPTH-1, ntiles-1) and the stores (4 per tile) of
+    // tiles max(0, t-DEPTH) .. t-1.  Anything counted here that was not actually issued would let the wait pass early.
     for (int t = 0; t < DEPTH && t < ntiles; ++t) dma(t);
     for (int t = 0; t < ntiles; ++t) {
-        const int younger = PER_DMA * (min(t + DEPTH, ntiles - 1) - t) + 4 * (t - max(0, t - DEPTH));
+        const int younger = PER_DMA * (min(t + DEPTH - 1, ntiles - 1) - t) + 4 * (t - max(0, t - DEPTH));
         wait_vm_upto(younger);                                              // this wave's part of tile t has landed
         __builtin_amdgcn_s_barrier();                                        // ... and everyone's; everyone is done reading stage (t-1) % NST
         asm volatile("" ::: "memory");

@@ -208,6 +208,44 @@ def test_gemm_bf16_stored_operands(M, N, K):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("M", [4096, 4097, 8191, 40000, 249001])
+def test_persistent_fp32_hidden_layer(M):
+    """layer_f32.hip (exact fp32; persistent blocks, weights in registers, LDS-DMA row stream, bias as an extra MFMA step): the
+    256 -> 256 forward with and without bias / ReLU against fp64, every row of ragged ranges; rows beyond M and the pad column
+    untouched; and bit-for-bit the same sums as the tiled kernel up to summation order (2e-6 relative to the row scale)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 5)
+    A = torch.randn((M, 256), generator=g)
+    W = (torch.randn((256, 256), generator=g) / 16).contiguous()
+    bias = torch.randn(256, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+    out = torch.full((M + 2, 260), -7.0, device=DEV)
+    engine.gemm(M, 256, 256, Ad, 256, Wd, 256, out, 260, bias=bd, act=1)
+    rel_close(out[:M, :256], torch.relu(ref), 2e-5, atol=2e-5 * float(ref.abs().max()), what="persistent fp32 layer, bias + relu")
+    assert bool((out[M:] == -7.0).all()) and bool((out[:, 256:] == -7.0).all())
+    out2 = torch.zeros((M, 256), device=DEV)
+    engine.gemm(M, 256, 256, Ad, 256, Wd, 256, out2, 256)
+    rel_close(out2, ref - bias.double(), 2e-5, atol=2e-5 * float(ref.abs().max()), what="persistent fp32 layer, plain")
+    os.environ["CLIFT_NO_PERSISTENT"] = "1"          # the tiled kernel on the same inputs
+    try:
+        out3 = torch.zeros((M, 256), device=DEV)
+        engine.gemm(M, 256, 256, Ad, 256, Wd, 256, out3, 256)
+    finally:
+        del os.environ["CLIFT_NO_PERSISTENT"]
+    scale = (A.abs().double() @ W.abs().double().T).to(DEV)
+    assert float(((out2 - out3).abs().double() / scale).max()) <= 2e-6
+    # masked dgrad of the same layer (k_layer_f32_dgrad): dX = mask . (dY W), W read along its rows
+    mask = torch.randn((M, 256), generator=g)
+    maskd = mask.to(DEV)
+    dX = torch.full((M + 2, 260), -7.0, device=DEV)
+    engine.gemm(M, 256, 256, Ad, 256, Wd, 256, dX, 260, b_trans=1, mask=maskd, ldmask=256)
+    refd = (A.double() @ W.double()) * (mask.double() > 0)
+    rel_close(dX[:M, :256], refd, 2e-5, atol=2e-5 * float(refd.abs().max()), what="persistent fp32 dgrad")
+    assert bool((dX[M:] == -7.0).all()) and bool((dX[:, 256:] == -7.0).all())
+    assert bool((dX[:M, :256][maskd <= 0] == 0).all())
+
+
 @pytest.mark.parametrize("M", [64, 65, 97, 300, 8191, 33000, 174001])
 def test_streamed_bf16_hidden_layer(M):
     """layer_bf16.hip (persistent blocks, weights in registers, LDS-DMA ring, counted waits): the 256 -> 256 forward (bias + ReLU)
@@ -426,7 +464,12 @@ def test_forward_backward_vs_oracle_mid(mode, white):
         ref = Pg[k].grad
         ref = torch.zeros_like(Pg[k]) if ref is None else ref
         got = torch.zeros_like(ref) if gr is None else gr.detach().cpu()
-        rel_close(got, ref, 2e-3, atol=2e-3 * float(ref.abs().max()) * 0.05 + 1e-10, what=f"grad {k}")
+        # 2e-3 relative + 1e-4 of the tensor's scale for all but <= 0.1 % of the entries, and those within 1e-3 of the scale: a hidden
+        # unit whose pre-activation is zero to round-off for one sample lands on either side of the ReLU kink depending on the
+        # summation order of the layer before it, which moves one row of the next weight gradient by that sample's contribution
+        # (observed: one row of one 256 x 256 gradient differs by 4e-4 of its scale between the tiled and the persistent forward
+        # kernel, everything else to 1e-6)
+        grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-4, outlier_frac=1e-3, outlier_cap=1e-3)
 
 
 def test_forward_backward_vs_oracle_large_grid_no_lds_lines():
