@@ -207,8 +207,8 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
 
 def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
     """``rec`` = the (kind, M, N, K, start event, end event) records of every clift_gemm launch of the ``nb`` timed steps.  The
-    dominant kernel by time is the instantiation k_gemm<128,256,2,4,false,false,true> = the 256x256 forward layers of the
-    semantic / fast / slow instance MLPs (rocprofv3 lists it under exactly that name, profiles/r01_*): achieved = its
+    dominant kernel by time is k_layer_f32<false> (csrc/layer_f32.hip) = the 256x256 forward layers of the semantic / fast /
+    slow instance MLPs as a persistent kernel (rocprofv3 lists it under exactly that name, profiles/r01_v6_*): achieved = its
     algorithmic FLOPs (2*M*256*256 per launch, M = active samples of the pass) / its summed launch durations; peak = dense fp32
     MFMA.  ``all_gemm`` is the same ratio over every matrix-core launch (forward, dgrad, wgrad, narrow layers).  The active-sample
     count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
@@ -237,7 +237,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
                 "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
                              "gflop_per_step": tot_f / 1e9 / nb,
                              "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
-    return {"bound": "mfma", "kernel": "k_gemm<128,256,2,4,false,false> (fp32 v_mfma_f32_32x32x2_f32; 256x256 forward MLP layers)",
+    return {"bound": "mfma", "kernel": "k_layer_f32<false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; 256x256 forward MLP layers)",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
             # HBM bytes per (average) launch of the dominant kernel: PMC ratio measured offline with separate rocprofv3 --pmc
             # passes (profiles/r01_gemm_pmc_notes.txt: FETCH_SIZE x2 (gfx950) + WRITE_SIZE = 541 MB for the M = 265 k launch vs
