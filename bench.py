@@ -241,11 +241,11 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
             # HBM bytes per (average) launch of the dominant kernel = its algorithmic bytes: by construction every activation row is
             # fetched exactly once (one LDS-DMA by the one block that owns it), every output row written once, and the 256 KB weight
-            # matrix is read once per block from L2.  A rocprofv3 --pmc pass over this persistent kernel did not complete on the pool
-            # (timed out twice, profiles/r01_gemm_pmc_notes.txt); the tiled kernel it replaces measured 541 MB vs 543 MB algorithmic.
+            # matrix is read once per block from L2.  The rocprofv3 --pmc passes of the end of the round did not complete on the pool (they
+            # timed out with the tiled kernels as well, profiles/r01_gemm_pmc_notes.txt); the tiled kernel measured 541 MB vs 543 MB algorithmic.
             "traffic": (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0,
             "traffic_unit": "bytes/launch, algorithmic (A read once + C written once = 8 B per output element, + 256 KB weights): exact by construction "
-                            "for the persistent kernel; the PMC pass over it timed out (see profiles/r01_gemm_pmc_notes.txt)",
+                            "for the persistent kernel; PMC re-measurement pending (profiles/r01_gemm_pmc_notes.txt)",
             "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
             "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
                          "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
