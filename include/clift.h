@@ -140,7 +140,12 @@ int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const 
  *   bf16 terms and the six leading cross products are accumulated in fp32 (error below fp32 product rounding).  Applies to
  *   the forward / dgrad forms (a_trans = 0, no accumulate); other forms run as precision 0.  Needs `workspace`.
  * K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
- * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C). */
+ * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C).
+ * Dispatch (no change of contract): the N = K = 256 hidden-layer forms with M >= 4096 -- forward (plain A, [n][k] weights, no
+ *   mask) and masked dgrad (b_trans, fp32 mask, no bias/act) -- run as persistent kernels (csrc/layer_f32.hip: weights in registers,
+ *   rows streamed by LDS-DMA); in precision 1 with bf16-stored A / C (/ mask) the same forms and the 256 x 256 wgrad run as
+ *   streaming kernels (csrc/layer_bf16.hip).  Everything else takes the tiled kernels (csrc/gemm*.hip).  The environment variable
+ *   CLIFT_NO_PERSISTENT=1 forces the tiled fp32 kernels (A/B comparisons in tests/test_gpu_parity.py). */
 typedef struct {
     int M, N, K;
     const float* A; int lda; int a_trans;
