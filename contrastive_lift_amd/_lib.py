@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -30,6 +30,11 @@ class March(C.Structure):
     _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3), ("inv_ext2", C.c_float * 3), ("step_size", C.c_float),
                 ("n_samples", C.c_int), ("distance_scale", C.c_float), ("density_shift", C.c_float),
                 ("weight_thres", C.c_float)]
+
+
+class TVSet(C.Structure):
+    _fields_ = [("n", C.c_int), ("plane", C.c_void_p * 8), ("grad", C.c_void_p * 8), ("H", C.c_int * 8), ("W", C.c_int * 8),
+                ("C", C.c_int * 8), ("weight", C.c_float * 8)]
 
 
 class Gemm(C.Structure):
@@ -77,6 +82,7 @@ _SIGNATURES = {
     "clift_composite_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                              _P, _P, _P], C.c_int),
     "clift_tv_fwd_bwd": ([_P, _I, _I, _I, _F, _P, _P, _P], C.c_int),
+    "clift_tv_fwd_bwd_multi": ([_P, _P, _P], C.c_int),
     "clift_pixel_losses": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
     "clift_contrastive": ([_P, _P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
     "clift_slow_fast": ([_P, _P, _P, _I, _I, _P, _P, _P, _P], C.c_int),

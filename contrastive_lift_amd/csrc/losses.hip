@@ -35,6 +35,45 @@ __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, 
     if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, weight * t);
 }
 
+// all planes of a step in one launch: blockIdx.y selects the plane
+__global__ __launch_bounds__(256) void k_tv_multi(clift_tv_set_t set, float* __restrict__ loss) {
+    __shared__ float sh[4];
+    const int i = blockIdx.y;
+    const float* __restrict__ x = set.plane[i];
+    float* __restrict__ grad = set.grad[i];
+    const int H = set.H[i], W = set.W[i], C = set.C[i];
+    const float weight = set.weight[i];
+    const long total = (long)H * W * C;
+    const float ch = 2.f / ((float)C * (H - 1) * W + 1e-4f), cw = 2.f / ((float)C * H * (W - 1) + 1e-4f);
+    float part = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e / ((long)W * C)), w = (int)((e / C) % W);
+        const float v = x[e];
+        float g = 0.f;
+        if (h + 1 < H) { const float d = x[e + (long)W * C] - v; part += ch * d * d; g -= ch * 2.f * d; }
+        if (h > 0) g += ch * 2.f * (v - x[e - (long)W * C]);
+        if (w + 1 < W) { const float d = x[e + C] - v; part += cw * d * d; g -= cw * 2.f * d; }
+        if (w > 0) g += cw * 2.f * (v - x[e - C]);
+        if (grad) grad[e] += weight * g;
+    }
+    const float t = block_sum_256(part, sh);
+    if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, weight * t);
+}
+
+extern "C" int clift_tv_fwd_bwd_multi(const clift_tv_set_t* set, float* loss_accum, clift_stream_t s) {
+    CLIFT_REQUIRE(set->n >= 0 && set->n <= CLIFT_TV_MAX, "clift_tv_fwd_bwd_multi: n must be in [0,%d]", CLIFT_TV_MAX);
+    if (set->n == 0) return 0;
+    long most = 0;
+    for (int i = 0; i < set->n; ++i) {
+        CLIFT_REQUIRE(set->H[i] > 0 && set->W[i] > 0 && set->C[i] > 0 && set->plane[i], "clift_tv_fwd_bwd_multi: bad plane %d", i);
+        const long t = (long)set->H[i] * set->W[i] * set->C[i];
+        most = t > most ? t : most;
+    }
+    const int bx = (int)((most + 255) / 256 < 1024 ? (most + 255) / 256 : 1024);
+    k_tv_multi<<<dim3(bx, set->n), 256, 0, as_stream(s)>>>(*set, loss_accum);
+    return clift_check_launch("clift_tv_fwd_bwd_multi");
+}
+
 extern "C" int clift_tv_fwd_bwd(const float* plane, int H, int W, int C, float weight, float* grad, float* loss_accum, clift_stream_t s) {
     CLIFT_REQUIRE(H > 0 && W > 0 && C > 0, "clift_tv_fwd_bwd: bad shape");
     const long total = (long)H * W * C;

@@ -9,6 +9,8 @@ Supported configuration: ``use_semantic_mlp=True`` and ``use_instance_mlp=True``
 every shipped contrastive-lift config, config/template/panopli_paper.yaml:36-37).  Grid semantic/instance heads
 and distilled-feature grids (reference tensoRF.py:70-83,91-94) raise NotImplementedError (next).
 """
+import ctypes as C
+
 import torch
 from torch import nn
 
@@ -313,13 +315,18 @@ class TensorVMSplit(nn.Module):
         lam_d = float(getattr(config, "lambda_tv_density", 0.1)) if config is not None else 0.1
         lam_a = float(getattr(config, "lambda_tv_appearance", 0.01)) if config is not None else 0.01
         out = torch.zeros(1, dtype=torch.float32, device=self.param_flat.device)
-        st = _lib.stream()
+        ts = _lib.TVSet()
+        n = 0
         for pre, lam in (("density", lam_d), ("appearance", lam_a)):
             for i in range(3):
                 p = self._views[f"{pre}_plane.{i}"]
                 g = self._gviews[f"{pre}_plane.{i}"] if accumulate_grad else None
                 _, c, h, w = p.shape
-                _lib.call("clift_tv_fwd_bwd", _lib.ptr(p), h, w, c, float(lam * 1e-2 * scale), _lib.ptr(g), _lib.ptr(out), st)
+                ts.plane[n], ts.grad[n] = p.data_ptr(), (g.data_ptr() if g is not None else None)
+                ts.H[n], ts.W[n], ts.C[n], ts.weight[n] = h, w, c, float(lam * 1e-2 * scale)
+                n += 1
+        ts.n = n
+        _lib.call("clift_tv_fwd_bwd_multi", C.byref(ts), _lib.ptr(out), _lib.stream())     # all six planes in one launch
         return out[0] / scale if scale != 1.0 else out[0]
 
     # ------------------------------------------------------------------ checkpoint helpers

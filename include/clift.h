@@ -209,6 +209,17 @@ int clift_composite_bwd(const float* w, const int* ray_start, const int* act_idx
  * grad (nullable) += weight * dTV/dx. */
 int clift_tv_fwd_bwd(const float* plane, int H, int W, int C, float weight, float* grad, float* loss_accum,
                      clift_stream_t s);
+/* The same for up to CLIFT_TV_MAX planes in ONE launch (total_tv_loss, tensoRF.py:248-290: three density + three appearance
+ * planes every step; each of those passes is a few MB, i.e. launch-latency-sized on this chip). */
+#define CLIFT_TV_MAX 8
+typedef struct {
+    int n;
+    const float* plane[CLIFT_TV_MAX];
+    float* grad[CLIFT_TV_MAX];      /* nullable per plane */
+    int H[CLIFT_TV_MAX], W[CLIFT_TV_MAX], C[CLIFT_TV_MAX];
+    float weight[CLIFT_TV_MAX];
+} clift_tv_set_t;
+int clift_tv_fwd_bwd_multi(const clift_tv_set_t* set, float* loss_accum, clift_stream_t s);
 
 /* ---- a19 pixel losses of training_step (trainer/train_panopli_tensorf.py:155-160,177-178):
  * out2[0] += mean((mask*(rgb-gt))^2); out2[1] += mean_i( mask_i conf_i * -sum_c cw_c p_ic log_softmax(sem_i)_c ).
