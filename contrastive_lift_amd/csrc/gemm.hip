@@ -241,11 +241,11 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         return clift_gemm_split_launch(p, h->a_trans, h->b_trans, h->workspace, st);
     }
     if (h->precision == 0 && !h->a_trans && !h->b_trans && h->N == 256 && h->K == 256 && h->M >= 4096 && splits == 1 && !h->accumulate && !h->c_trans &&
-        !h->mask && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr && getenv("CLIFT_NO_PFWD") == nullptr)
+        !h->mask && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_layer_f32_launch(p, 0, st);                    // persistent forward layer: weights in registers, LDS-DMA row stream
     if (h->precision == 0 && !h->a_trans && h->b_trans && h->N == 256 && h->K == 256 && h->M >= 4096 && splits == 1 && !h->accumulate && !h->c_trans &&
         h->mask && !h->bias && h->act == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0 &&
-        getenv("CLIFT_NO_PERSISTENT") == nullptr && getenv("CLIFT_NO_PDGRAD") == nullptr)
+        getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_layer_f32_launch(p, 1, st);                    // persistent masked dgrad of the same layers
     if (h->N > 128) {
         return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
