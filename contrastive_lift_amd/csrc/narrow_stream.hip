@@ -1,0 +1,139 @@
+// narrow_stream.hip -- weight gradient of the narrow OUTPUT layers (out_features <= 32: 22 semantic classes, 3 instance
+// dimensions) over a 256-wide hidden activation:  gW[c][j] += sum_m dY[m][c] X[m][j],  gb[c] += sum_m dY[m][c].
+// One read of X (M x 256, fp32 or bf16-stored) -- an HBM stream.  The VALU kernel (k_wgrad_narrow, gemm.hip) is FMA-bound at
+// ~1/3 of that rate (22 x 256 FMAs per row); here the products run on the fp32 matrix cores instead (v_mfma_f32_32x32x2_f32: the
+// 32 x 32 tile is padded in the class dimension only, which costs MFMA time the stream has to spare): persistent blocks, row tiles
+// by LDS-DMA two tiles ahead, wave w owns columns 32 w .. +31 of X for ALL classes (no cross-wave reduction), each lane reads one
+// dY and one X element per MFMA step (row-contiguous, conflict-free without any swizzle).  bf16-stored X is widened in the
+// register (exact), so both storage modes give fp32 products.
+#include "gemm_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int NS_ROWS = 32;              // rows per tile = 16 MFMA steps of 2 rows
+constexpr int NS_DEPTH = 2;              // tiles in flight ahead of the multiply
+constexpr int NS_STAGES = NS_DEPTH + 1;
+
+static __device__ __forceinline__ void ns_wait_vm(int n) {          // wave-uniform n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+}
+
+// XB = X is bf16-stored.  Stage layout (bytes): X tile (32 rows x 256 elements) then the dY tile (32 rows x ldd floats, ldd <= 32).
+template <bool XB>
+__global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __restrict__ dY, int ldd, int no, const float* __restrict__ X, int ldx,
+                                                                int M, int rows_per_block, float* __restrict__ gW, int ldw, float* __restrict__ gb) {
+    constexpr int XBYTES = NS_ROWS * 256 * (XB ? 2 : 4), STAGE = XBYTES + NS_ROWS * 32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS_STAGES * STAGE];          // the only LDS object
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + NS_ROWS - 1) / NS_ROWS;
+    const int dchunks = NS_ROWS * ldd / 4;                                   // 16-byte chunks of a dY tile (<= 256)
+    const bool has_d = wave * 64 < dchunks;                                   // this wave issues one dY DMA instruction per tile
+    const int per_tile = (XB ? 2 : 4) + (has_d ? 1 : 0);                      // vector-memory instructions of this wave per tile
+    auto dma = [&](int t) {
+        const int r0 = rbeg + t * NS_ROWS;
+        unsigned char* st = lds + (t % NS_STAGES) * STAGE;
+        if (!XB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wave * 4 + i, gr = min(r0 + row, rend - 1);
+                __builtin_amdgcn_global_load_lds(X + (size_t)gr * ldx + lane * 4, (lds_ptr_t)(st + row * 1024), 16, 0, 0);
+            }
+        } else {
+            const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave * 4 + 2 * i + lh, gr = min(r0 + row, rend - 1);
+                __builtin_amdgcn_global_load_lds(X16 + (size_t)gr * ldx + li * 8, (lds_ptr_t)(st + (wave * 4 + 2 * i) * 512), 16, 0, 0);
+            }
+        }
+        if (has_d) {
+            const int id = wave * 64 + lane;
+            if (id < dchunks) {
+                const int e = id * 4, r = e / ldd, c = e - r * ldd;
+                const int gr = min(r0 + r, rend - 1);
+                __builtin_amdgcn_global_load_lds(dY + (size_t)gr * ldd + c, (lds_ptr_t)(st + XBYTES + wave * 1024), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float bsum = 0.f;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const unsigned xoff = (unsigned)(lh * 256 + 32 * wave + li) * (XB ? 2u : 4u);      // element (row lh, column 32 wave + li) of the X tile
+    const unsigned doff = (unsigned)(XBYTES + (lh * ldd + min(li, ldd - 1)) * 4);       // element (row lh, class li) of the dY tile
+    const bool cls = li < ldd;                                                           // lanes past the padded class count feed zeros
+
+    for (int t = 0; t < NS_DEPTH && t < ntiles; ++t) dma(t);
+    for (int t = 0; t < ntiles; ++t) {
+        ns_wait_vm(per_tile * (min(t + NS_DEPTH - 1, ntiles - 1) - t));                  // tile t landed; younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NS_DEPTH < ntiles) dma(t + NS_DEPTH);
+        const unsigned sb = lds0 + (unsigned)((t % NS_STAGES) * STAGE);
+        const int valid = rend - (rbeg + t * NS_ROWS);
+        if (valid < NS_ROWS) {                                                           // last tile of the range: rows past the end contribute nothing
+            float* dt = reinterpret_cast<float*>(lds + (t % NS_STAGES) * STAGE + XBYTES);
+            for (int e = valid * ldd + tid; e < NS_ROWS * ldd; e += 512) dt[e] = 0.f;
+            __syncthreads();
+        }
+        float a[16], b[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                                                   // rows 2 s + lh
+            asm volatile("ds_read_b32 %0, %1" : "=v"(a[s]) : "v"(sb + doff + (unsigned)(2 * s * ldd * 4)) : "memory");
+            if (!XB) asm volatile("ds_read_b32 %0, %1" : "=v"(b[s]) : "v"(sb + xoff + (unsigned)(2 * s * 1024)) : "memory");
+            else asm volatile("ds_read_u16 %0, %1" : "=v"(b[s]) : "v"(sb + xoff + (unsigned)(2 * s * 512)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                     "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]) : : "memory");
+        asm volatile("" : "+v"(a[15]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                     "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]) : : "memory");
+        asm volatile("" : "+v"(b[14]), "+v"(b[15]) : : "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float av = cls ? a[s] : 0.f;
+            const float bv = XB ? __uint_as_float(__float_as_uint(b[s]) << 16) : b[s];
+            if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc0, 0, 0, 0);
+            bsum += av;
+        }
+    }
+    // lane (li, lh) holds gW rows c = 8 q + 4 lh + e, column 32 wave + li
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
+        if (c < no) unsafeAtomicAdd(gW + (size_t)c * ldw + 32 * wave + li, acc0[r] + acc1[r]);
+    }
+    if (gb && wave == 0) {       // every wave read the same dY; wave 0 folds the two row parities and adds the bias gradient
+        const unsigned u = __float_as_uint(bsum);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (lh == 0 && li < no) unsafeAtomicAdd(gb + li, tot);
+    }
+}
+
+// Eligibility decided by the caller (gemm.hip): ni = 256, no <= ldd <= 32, ldd % 4 == 0, M >= 4096, 16-byte-aligned rows.
+int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int M, float* gW, int ldw, float* gb, int x_bf16,
+                                     hipStream_t st) {
+    const int tiles = cdiv(M, NS_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
+    if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, ldw, gb);
+    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, ldw, gb);
+    return clift_check_launch("clift_wgrad_narrow(stream)");
+}

@@ -305,6 +305,40 @@ def test_streamed_bf16_weight_gradient(M):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("xb", [False, True])
+@pytest.mark.parametrize("M,no,ldd", [(4096, 22, 24), (4099, 3, 4), (40001, 22, 24), (249003, 3, 4), (5000, 32, 32), (8191, 6, 8)])
+def test_narrow_wgrad_stream(M, no, ldd, xb):
+    """k_wgrad_narrow_stream (output-layer weight gradients on the fp32 matrix cores, X streamed by LDS-DMA; fp32 or bf16-stored X):
+    gW += dY^T X and gb += column sums against fp64, accumulating onto existing contents, ragged row counts, zero pad columns of
+    dY ignored; and the same numbers as the VALU kernel it replaces."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + no)
+    dY = torch.zeros((M, ldd))
+    dY[:, :no] = torch.randn((M, no), generator=g)
+    X = torch.relu(torch.randn((M, 256), generator=g))
+    if xb:
+        X = X.to(torch.bfloat16)
+    prev = engine.set_mlp_precision("bf16" if xb else "fp32")
+    try:
+        gW = torch.full((no, 256), 0.25, device=DEV)
+        gb = torch.full((no,), -1.0, device=DEV)
+        engine.wgrad(no, 256, M, dY.to(DEV), ldd, X.to(DEV), 256, gW, gb)
+        refw = dY[:, :no].double().T @ X.double() + 0.25
+        refb = dY[:, :no].double().sum(0) - 1.0
+        rel_close(gW, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="narrow wgrad (stream)")
+        rel_close(gb, refb, 2e-5, atol=2e-5 * M ** 0.5, what="narrow bias sums (stream)")
+        os.environ["CLIFT_NO_PERSISTENT"] = "1"
+        try:
+            gW2 = torch.full((no, 256), 0.25, device=DEV)
+            gb2 = torch.full((no,), -1.0, device=DEV)
+            engine.wgrad(no, 256, M, dY.to(DEV), ldd, X.to(DEV), 256, gW2, gb2)
+        finally:
+            del os.environ["CLIFT_NO_PERSISTENT"]
+        rel_close(gW, gW2, 2e-5, atol=2e-5 * float(refw.abs().max()), what="stream vs VALU kernel")
+    finally:
+        engine.set_mlp_precision(prev)
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
