@@ -286,6 +286,10 @@ int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits,
     if (a_trans && b_trans && p.M == 256 && p.N == 256 && p.K >= 64 && p.a_bf16 && p.b_bf16 && p.accumulate && !p.c_trans && !p.bias && !p.mask &&
         p.lda % 8 == 0 && p.ldb % 8 == 0 && ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) == 0)
         return clift_wgrad_bf16_stream_launch(p, st);              // streamed weight gradient: persistent blocks, transposed LDS reads
+    if (!a_trans && b_trans && !p.a_bf16 && !p.b_bf16 && p.c_bf16 && p.mask && p.mask_bf16 && p.N == 256 && p.K <= 32 && p.K <= p.lda && p.lda <= 32 &&
+        p.lda % 4 == 0 && p.M >= 4096 && splits == 1 && !p.accumulate && !p.c_trans && !p.bias && p.act == 0 && p.ldc % 4 == 0 && p.ldmask % 4 == 0 &&
+        ((((uintptr_t)p.C) | ((uintptr_t)p.mask)) & 7) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_dgrad_narrow_stream_launch(p, 1, st);          // output-layer dgrad with bf16-stored mask / result (fp32 products: exact)
     if (p.N > 128) return launch_gemm_h<128, 256, 2, 4>(p, a_trans, b_trans, splits, st);
     if (p.N > 32) return launch_gemm_h<128, 128, 2, 2>(p, a_trans, b_trans, splits, st);
     return launch_gemm_h<256, 32, 4, 1>(p, a_trans, b_trans, splits, st);

@@ -137,3 +137,129 @@ int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const flo
     else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, ldw, gb);
     return clift_check_launch("clift_wgrad_narrow(stream)");
 }
+
+// ============================================================================ dgrad of the narrow output layers
+// C[m][n] = mask[m][n] > 0 ? sum_k dOut[m][k] W[k][n] : 0   for K <= 32 (22 classes / 3 instance dims), N = 256: the first step of
+// the hidden-layer backward.  Writes M x 256 and reads the M x 256 ReLU mask: an HBM stream with a few MFMAs per tile.  Same
+// skeleton as k_layer_f32<true> (layer_f32.hip): persistent blocks, the weight slice of a wave in registers (KJ float4 per lane),
+// 32-row tiles of dOut by LDS-DMA (a linear copy: the tile is contiguous in memory), the mask of a tile prefetched into registers
+// at tile start, swapped MFMA operands so a lane owns one output row and stores 16 bytes (8 when bf16-stored) at a time.
+// HB = the mask and the output are bf16-stored (bf16 mode); the products are fp32 either way.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+template <int KJ, bool HB>
+__global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block) {
+    constexpr int ROWS = 32, TILEB = ROWS * 32 * 4;                          // stage: up to 32 rows x 32 floats
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB];   // the only LDS object
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + ROWS - 1) / ROWS;
+    const int lda = g.lda, K = g.K;
+
+    float4 w[KJ];             // w[j] = W[k = 8 j + 4 lh + 0..3][n = 32 wave + li], zero past K
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * j + 4 * lh + i;
+            v[i] = k < K ? g.B[(size_t)k * g.ldb + 32 * wave + li] : 0.f;
+        }
+        w[j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int dchunks = ROWS * lda / 4;                                      // 16-byte chunks of a tile (<= 256)
+    auto dma = [&](int t) {
+        const int id = wave * 64 + lane;
+        if (wave * 64 < dchunks && id < dchunks) {
+            const int e = id * 4, r = e / lda, c = e - r * lda;
+            const int gr = min(rbeg + t * ROWS + r, rend - 1);
+            __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * lda + c, (lds_ptr_t)(lds + (t & 1) * TILEB + wave * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    unsigned foff[KJ];        // fragment (row li, k = 8 j + 4 lh .. +3); a fragment past the row (its weights are zero) re-reads k = 0..3
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) foff[j] = (unsigned)((li * lda + ((8 * j + 4 * lh + 3 < lda) ? 8 * j + 4 * lh : 0)) * 4);
+    dma(0);
+    for (int t = 0; t < ntiles; ++t) {
+        // the previous epilogue waited for everything older than its stores, the DMA of this tile included
+        if (t > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntiles) dma(t + 1);
+        const int m = rbeg + t * ROWS + li;
+        f32x4 mk[4];
+        u32x2v mh[4];
+        if (!HB) {
+            const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                         : "=&v"(mk[0]), "=&v"(mk[1]), "=&v"(mk[2]), "=&v"(mk[3]) : "v"(mp) : "memory");
+        } else {
+            const unsigned short* mp = reinterpret_cast<const unsigned short*>(g.mask) + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
+            asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx2 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48"
+                         : "=&v"(mh[0]), "=&v"(mh[1]), "=&v"(mh[2]), "=&v"(mh[3]) : "v"(mp) : "memory");
+        }
+        f32x4 fa[KJ];
+        const unsigned sb = lds0 + (unsigned)((t & 1) * TILEB);
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[j]) : "v"(sb + foff[j]) : "memory");
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[j]) : : "memory");
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, fa[j].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].y, fa[j].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, fa[j].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, fa[j].w, acc1, 0, 0, 0);
+        }
+        if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mh[0]), "+v"(mh[1]), "+v"(mh[2]), "+v"(mh[3]) : : "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float o[4] = {acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
+                          acc0[4 * q + 3] + acc1[4 * q + 3]};
+            if (!HB) {
+                o[0] = mk[q].x > 0.f ? o[0] : 0.f; o[1] = mk[q].y > 0.f ? o[1] : 0.f;
+                o[2] = mk[q].z > 0.f ? o[2] : 0.f; o[3] = mk[q].w > 0.f ? o[3] : 0.f;
+                if (m < rend) *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + 32 * wave + 8 * q + 4 * lh) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                const unsigned m0 = mh[q][0], m1 = mh[q][1];
+                if (!bf16_bits_positive((unsigned short)(m0 & 0xffffu))) o[0] = 0.f;
+                if (!bf16_bits_positive((unsigned short)(m0 >> 16))) o[1] = 0.f;
+                if (!bf16_bits_positive((unsigned short)(m1 & 0xffffu))) o[2] = 0.f;
+                if (!bf16_bits_positive((unsigned short)(m1 >> 16))) o[3] = 0.f;
+                const unsigned lo = (unsigned)float_to_bf16_bits(o[0]) | ((unsigned)float_to_bf16_bits(o[1]) << 16);
+                const unsigned hi = (unsigned)float_to_bf16_bits(o[2]) | ((unsigned)float_to_bf16_bits(o[3]) << 16);
+                if (m < rend) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + (size_t)m * g.ldc + 32 * wave + 8 * q + 4 * lh) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
+// Eligibility decided by the callers (gemm.hip / gemm_bf16.hip): plain fp32 A with lda in {4, 8, .., 32} = its row pitch, K <= lda, N = 256,
+// b_trans weights, a mask, no bias / activation, M >= 4096; half = bf16-stored mask and output.
+int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
+    const int tiles = cdiv(p.M, 32);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(p.M, blocks), 32) * 32;
+    const dim3 grid(cdiv(p.M, rpb));
+    const int kj = cdiv(p.K, 8);
+#define CLIFT_DN(KJ)                                                                                     \
+    do {                                                                                                 \
+        if (half) k_dgrad_narrow_stream<KJ, true><<<grid, 512, 0, st>>>(p, rpb);                         \
+        else k_dgrad_narrow_stream<KJ, false><<<grid, 512, 0, st>>>(p, rpb);                             \
+    } while (0)
+    if (kj <= 1) CLIFT_DN(1);
+    else if (kj == 2) CLIFT_DN(2);
+    else if (kj == 3) CLIFT_DN(3);
+    else CLIFT_DN(4);
+#undef CLIFT_DN
+    return clift_check_launch("clift_gemm(narrow dgrad stream)");
+}

@@ -339,6 +339,37 @@ def test_narrow_wgrad_stream(M, no, ldd, xb):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("M,K,lda", [(4096, 22, 24), (4101, 3, 4), (60001, 22, 24), (249003, 3, 4), (5000, 32, 32), (8191, 6, 8)])
+def test_narrow_dgrad_stream(M, K, lda, half):
+    """k_dgrad_narrow_stream (first step of the hidden-layer backward: dX = mask . (dOut W) for the 22-class / 3-dim output layers,
+    fp32 or bf16-stored mask and result): every row of ragged row counts against fp64; rows beyond M and pad columns untouched."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + K)
+    bf = torch.bfloat16
+    dO = torch.zeros((M, lda))
+    dO[:, :K] = torch.randn((M, K), generator=g)
+    W = torch.randn((K, 256), generator=g)
+    mask = torch.relu(torch.randn((M, 256), generator=g))
+    ref = (dO[:, :K].double() @ W.double()) * (mask.double() > 0)
+    prev = engine.set_mlp_precision("bf16" if half else "fp32")
+    try:
+        md = mask.to(bf).to(DEV) if half else mask.to(DEV)
+        refm = ref if not half else (dO[:, :K].double() @ W.double()) * (mask.to(bf).double() > 0)
+        dX = torch.full((M + 2, 260), -7.0, dtype=bf if half else torch.float32, device=DEV)
+        engine.gemm(M, 256, K, dO.to(DEV), lda, W.to(DEV), 256, dX, 260, b_trans=1, mask=md, ldmask=256)
+        got = dX[:M, :256].double().cpu()
+        if half:   # the tiled bf16 kernel rounds both operands to bf16 first; this kernel multiplies in fp32 and rounds the result once
+            tol = refm.abs() / 128 + 1e-2 * float(refm.abs().max()) / 128
+            assert bool(((got - refm).abs() <= tol).all()), float(((got - refm).abs() - tol).max())
+        else:
+            rel_close(got, refm, 2e-5, atol=2e-5 * float(refm.abs().max()), what="narrow dgrad (stream)")
+        assert bool((dX[M:] == -7.0).all()) and bool((dX[:, 256:] == -7.0).all())
+        assert bool((got[(mask.to(bf) if half else mask).double() <= 0] == 0).all())
+    finally:
+        engine.set_mlp_precision(prev)
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
