@@ -260,9 +260,50 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
 
 // ============================================================================ K = 3 first layers
 // out[m][n] = act(W[n][0] x + W[n][1] y + W[n][2] z + b[n]); pure store-bandwidth kernel (tensoRF.py:475,576).
+// Thread = four consecutive output columns, kept for MANY rows: the 12 weights and 4 biases live in registers and a block strides
+// over the rows with four rows in flight per thread (one broadcast 16-byte load of x and one 16-byte store per row).  The first
+// version took one (row, column-quad) per thread and re-fetched its 16 coefficients every time: 18 memory instructions per
+// 16-byte store, 3 TB/s of output.
 __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W, int ldw,
                                                         const float* __restrict__ b, int M, int Nout, int relu,
                                                         float* __restrict__ out, int ldo, int out_bf16) {
+    const int nq = Nout / 4, rpi = 256 / nq;                 // column quads per row; rows per block iteration (nq divides 256)
+    const int q = threadIdx.x % nq, rl = threadIdx.x / nq, n = q * 4;
+    float w0[4], w1[4], w2[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* w = W + (size_t)(n + j) * ldw;
+        w0[j] = w[0]; w1[j] = w[1]; w2[j] = w[2]; bb[j] = b[n + j];
+    }
+    auto emit = [&](int m, const float4 x) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = fmaf(w2[j], x.z, fmaf(w1[j], x.y, fmaf(w0[j], x.x, bb[j])));
+            o[j] = relu ? fmaxf(v, 0.f) : v;
+        }
+        if (out_bf16) {      // bf16-stored hidden activation (bf16 mode)
+            const unsigned lo = (unsigned)float_to_bf16_bits(o[0]) | ((unsigned)float_to_bf16_bits(o[1]) << 16);
+            const unsigned hi = (unsigned)float_to_bf16_bits(o[2]) | ((unsigned)float_to_bf16_bits(o[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + (size_t)m * ldo + n) = make_uint2(lo, hi);
+        } else {
+            *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    const long step = (long)gridDim.x * rpi;
+    long m = (long)blockIdx.x * rpi + rl;
+    for (; m + 3 * step < M; m += 4 * step) {
+        const float4 xa = ld4(x4 + (size_t)m * 4), xb = ld4(x4 + (size_t)(m + step) * 4);
+        const float4 xc = ld4(x4 + (size_t)(m + 2 * step) * 4), xd = ld4(x4 + (size_t)(m + 3 * step) * 4);
+        emit((int)m, xa); emit((int)(m + step), xb); emit((int)(m + 2 * step), xc); emit((int)(m + 3 * step), xd);
+    }
+    for (; m < M; m += step) emit((int)m, ld4(x4 + (size_t)m * 4));
+}
+
+// any width (Nout / 4 not a divisor of 256): one (row, column quad) per thread
+__global__ __launch_bounds__(256) void k_linear_k3_fwd_any(const float* __restrict__ x4, const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ b, int M, int Nout, int relu,
+                                                            float* __restrict__ out, int ldo, int out_bf16) {
     const int nq = Nout / 4;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)M * nq) return;
@@ -272,10 +313,10 @@ __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float* w = W + (size_t)(n + j) * ldw;
-        float v = fmaf(w[2], x.z, fmaf(w[1], x.y, fmaf(w[0], x.x, b[n + j])));
+        const float v = fmaf(w[2], x.z, fmaf(w[1], x.y, fmaf(w[0], x.x, b[n + j])));
         o[j] = relu ? fmaxf(v, 0.f) : v;
     }
-    if (out_bf16) {      // bf16-stored hidden activation (bf16 mode)
+    if (out_bf16) {
         const unsigned lo = (unsigned)float_to_bf16_bits(o[0]) | ((unsigned)float_to_bf16_bits(o[1]) << 16);
         const unsigned hi = (unsigned)float_to_bf16_bits(o[2]) | ((unsigned)float_to_bf16_bits(o[3]) << 16);
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(out) + (size_t)m * ldo + n) = make_uint2(lo, hi);
@@ -288,7 +329,14 @@ extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, con
                                    float* out, int ldo, int out_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
     if (M <= 0) return 0;
-    k_linear_k3_fwd<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
+    if (Nout > 1024 || 256 % (Nout / 4) != 0) {
+        k_linear_k3_fwd_any<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
+        return clift_check_launch("clift_linear_k3_fwd");
+    }
+    const int rpi = 256 / (Nout / 4);
+    const long want = ((long)M + rpi - 1) / rpi;
+    const int blocks = (int)(want < 2048 ? want : 2048);             // 8 blocks per CU, each thread keeps its coefficients for ~M / 8192 rows
+    k_linear_k3_fwd<<<blocks, 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
     return clift_check_launch("clift_linear_k3_fwd");
 }
 

@@ -370,6 +370,31 @@ def test_narrow_dgrad_stream(M, K, lda, half):
         engine.set_mlp_precision(prev)
 
 
+@pytest.mark.parametrize("M,Nout", [(1, 256), (5, 256), (8191, 256), (100003, 256), (40001, 128), (3001, 24), (777, 4)])
+def test_linear_k3_forward(M, Nout):
+    """clift_linear_k3_fwd (first layer of the xyz heads, tensoRF.py:475,576): every row and column against torch, with and without
+    ReLU, fp32 and bf16-stored output, rows beyond M untouched; widths whose column-quad count does not divide 256 take the
+    generic kernel."""
+    from contrastive_lift_amd import _lib
+    g = torch.Generator().manual_seed(M + Nout)
+    x = torch.randn((M, 4), generator=g)
+    W = torch.randn((Nout, 4), generator=g)           # pitch 4, three weights used
+    b = torch.randn(Nout, generator=g)
+    ref = x[:, :3].double() @ W[:, :3].double().T + b.double()
+    xd, Wd, bd = x.to(DEV), W.to(DEV), b.to(DEV)
+    for relu in (0, 1):
+        want = torch.relu(ref) if relu else ref
+        out = torch.full((M + 1, Nout + 4), -7.0, device=DEV)
+        _lib.call("clift_linear_k3_fwd", _lib.ptr(xd), _lib.ptr(Wd), 4, _lib.ptr(bd), M, Nout, relu, _lib.ptr(out), Nout + 4, 0, _lib.stream())
+        rel_close(out[:M, :Nout], want, 1e-5, atol=1e-5 * float(ref.abs().max()), what="k3 fwd")
+        assert bool((out[M:] == -7.0).all()) and bool((out[:, Nout:] == -7.0).all())
+        outh = torch.full((M + 1, Nout + 4), -7.0, dtype=torch.bfloat16, device=DEV)
+        _lib.call("clift_linear_k3_fwd", _lib.ptr(xd), _lib.ptr(Wd), 4, _lib.ptr(bd), M, Nout, relu, _lib.ptr(outh), Nout + 4, 1, _lib.stream())
+        goth = outh[:M, :Nout].double().cpu()
+        assert bool(((goth - want).abs() <= want.abs() / 256 + 1e-5 * float(ref.abs().max())).all())
+        assert bool((outh[M:] == -7.0).all()) and bool((outh[:, Nout:] == -7.0).all())
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
