@@ -384,6 +384,9 @@ __global__ __launch_bounds__(1024) void k_linear_k3_bwd(const float* __restrict_
 extern "C" int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                                    int dh_bf16, clift_stream_t s) {
     if (M <= 0) return 0;
+    if (Nout == 256 && M >= 4096 && db && (((uintptr_t)x4) & 15) == 0 && (((uintptr_t)dH) & 15) == 0 && ldh % (dh_bf16 ? 8 : 4) == 0 &&
+        getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_k3_bwd_stream_launch(x4, dH, ldh, M, dW, ldw, db, dh_bf16, as_stream(s));      // matrix-core stream over dH (narrow_stream.hip)
     const int rpb = 512;
     k_linear_k3_bwd<<<dim3(cdiv(M, rpb), cdiv(Nout, 256)), 1024, 0, as_stream(s)>>>(x4, dH, ldh, M, Nout, rpb, dW, ldw, db, dh_bf16);
     return clift_check_launch("clift_linear_k3_bwd");

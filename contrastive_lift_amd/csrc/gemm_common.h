@@ -42,6 +42,7 @@ int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st);        
 int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int M, float* gW, int ldw, float* gb, int x_bf16,
                                      hipStream_t st);                                             // narrow_stream.hip
 int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st);
+int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M, float* dW, int ldw, float* db, int dh_bf16, hipStream_t st);
 long clift_gemm_split_workspace_bytes(int N, int K);                                                // gemm_split.hip
 int clift_gemm_split_launch(const GemmP& p, int a_trans, int b_trans, void* workspace, hipStream_t st);
 

@@ -33,7 +33,11 @@ static __device__ __forceinline__ void ns_wait_vm(int n) {          // wave-unif
 // XB = X is bf16-stored.  Stage layout (bytes): X tile (32 rows x 256 elements) then the dY tile (32 rows x ldd floats, ldd <= 32).
 template <bool XB>
 __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __restrict__ dY, int ldd, int no, const float* __restrict__ X, int ldx,
-                                                                int M, int rows_per_block, float* __restrict__ gW, int ldw, float* __restrict__ gb) {
+                                                                int M, int rows_per_block, float* __restrict__ gW, long sc, long sn, float* __restrict__ gb,
+                                                                int ones_class, float* __restrict__ ones_row) {
+    // gW[c * sc + j * sn] += sum_m dY[m][c] X[m][j].  ones_class >= 0: that class reads as 1.0 whatever dY holds and its row goes to
+    // ones_row[j] (+= sum_m X[m][j]) instead of gW -- the K = 3 first-layer backward: dY = the sample positions (x, y, z, pad),
+    // X = the hidden gradient, ones_row = the bias gradient.
     constexpr int XBYTES = NS_ROWS * 256 * (XB ? 2 : 4), STAGE = XBYTES + NS_ROWS * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS_STAGES * STAGE];          // the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
         asm volatile("" : "+v"(b[14]), "+v"(b[15]) : : "memory");
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float av = cls ? a[s] : 0.f;
+            const float av = li == ones_class ? ((2 * s + lh < valid) ? 1.f : 0.f) : (cls ? a[s] : 0.f);    // rows past the end count for nothing
             const float bv = XB ? __uint_as_float(__float_as_uint(b[s]) << 16) : b[s];
             if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc0, 0, 0, 0);
@@ -116,7 +120,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
-        if (c < no) unsafeAtomicAdd(gW + (size_t)c * ldw + 32 * wave + li, acc0[r] + acc1[r]);
+        const int j = 32 * wave + li;
+        if (c == ones_class) unsafeAtomicAdd(ones_row + j, acc0[r] + acc1[r]);
+        else if (c < no) unsafeAtomicAdd(gW + (size_t)c * sc + (size_t)j * sn, acc0[r] + acc1[r]);
     }
     if (gb && wave == 0) {       // every wave read the same dY; wave 0 folds the two row parities and adds the bias gradient
         const unsigned u = __float_as_uint(bsum);
@@ -133,9 +139,20 @@ int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const flo
     const int tiles = cdiv(M, NS_ROWS);
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
-    if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, ldw, gb);
-    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, ldw, gb);
+    if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr);
+    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr);
     return clift_check_launch("clift_wgrad_narrow(stream)");
+}
+
+// K = 3 first-layer backward through the same kernel: dW[n][0..2] += sum_m dH[m][n] x[m][0..2], db[n] += sum_m dH[m][n]
+// (x4 = (M, 4) positions, dH = (M, 256) hidden gradient, fp32 or bf16-stored).  Eligibility decided by the caller.
+int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M, float* dW, int ldw, float* db, int dh_bf16, hipStream_t st) {
+    const int tiles = cdiv(M, NS_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
+    if (dh_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db);
+    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db);
+    return clift_check_launch("clift_linear_k3_bwd(stream)");
 }
 
 // ============================================================================ dgrad of the narrow output layers

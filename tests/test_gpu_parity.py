@@ -395,6 +395,30 @@ def test_linear_k3_forward(M, Nout):
         assert bool((outh[M:] == -7.0).all()) and bool((outh[:, Nout:] == -7.0).all())
 
 
+@pytest.mark.parametrize("hb", [False, True])
+@pytest.mark.parametrize("M", [4096, 4100, 40001, 249003, 300])
+def test_linear_k3_backward(M, hb):
+    """clift_linear_k3_bwd (dW[n][0..2] += sum_m dH[m][n] x[m][:], db[n] += sum_m dH[m][n]; for M >= 4096 the matrix-core stream of
+    narrow_stream.hip with the bias as a forced-ones class, below that the VALU kernel): against fp64, accumulating onto existing
+    contents, fp32 and bf16-stored dH, ragged row counts, whatever the pad component of x holds."""
+    from contrastive_lift_amd import _lib
+    g = torch.Generator().manual_seed(M + 17)
+    x = torch.randn((M, 4), generator=g)              # the 4th component is padding: it must not matter
+    dH = torch.randn((M, 256), generator=g)
+    if hb:
+        dH = dH.to(torch.bfloat16)
+    dW = torch.full((256, 4), 0.5, device=DEV)
+    db = torch.full((256,), -1.5, device=DEV)
+    xd, dHd = x.to(DEV), dH.to(DEV)                    # (named: a temporary would be recycled by the allocator before the launch)
+    _lib.call("clift_linear_k3_bwd", _lib.ptr(xd), _lib.ptr(dHd), 256, M, 256, _lib.ptr(dW), 4, _lib.ptr(db), int(hb), _lib.stream())
+    torch.cuda.synchronize()
+    refw = dH.double().T @ x[:, :3].double() + 0.5
+    refb = dH.double().sum(0) - 1.5
+    rel_close(dW[:, :3], refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="k3 bwd dW")
+    rel_close(db, refb, 2e-5, atol=2e-5 * M ** 0.5, what="k3 bwd db")
+    assert bool((dW[:, 3] == 0.5).all())
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
