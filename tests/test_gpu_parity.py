@@ -419,6 +419,32 @@ def test_linear_k3_backward(M, hb):
     assert bool((dW[:, 3] == 0.5).all())
 
 
+@pytest.mark.parametrize("M", [4096, 4100, 70001, 159003])
+def test_persistent_fp32_weight_gradient(M):
+    """k_wgrad_f32_stream (64 row ranges x 4 column slices, LDS-DMA ring): gW += dY^T X and the fused bias sums of the 256 x 256 layers
+    against fp64, accumulating onto existing contents, ragged row counts; and the same numbers as the split-K tiled launch."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 29)
+    dY = torch.randn((M, 256), generator=g)
+    X = torch.relu(torch.randn((M, 256), generator=g))
+    dYd, Xd = dY.to(DEV), X.to(DEV)
+    gW = torch.full((256, 256), 0.5, device=DEV)
+    gb = torch.full((256,), -2.0, device=DEV)
+    engine.wgrad(256, 256, M, dYd, 256, Xd, 256, gW, gb)
+    refw = dY.double().T @ X.double() + 0.5
+    refb = dY.double().sum(0) - 2.0
+    rel_close(gW, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="persistent wgrad")
+    rel_close(gb, refb, 2e-5, atol=2e-5 * M ** 0.5, what="persistent wgrad bias sums")
+    os.environ["CLIFT_NO_PERSISTENT"] = "1"
+    try:
+        gW2 = torch.full((256, 256), 0.5, device=DEV)
+        gb2 = torch.full((256,), -2.0, device=DEV)
+        engine.wgrad(256, 256, M, dYd, 256, Xd, 256, gW2, gb2)
+    finally:
+        del os.environ["CLIFT_NO_PERSISTENT"]
+    rel_close(gW, gW2, 2e-5, atol=2e-5 * float(refw.abs().max()), what="persistent vs tiled wgrad")
+
+
 def test_gemm_tail_split_ctrans_colsum():
     """Large-M launch that takes the main + small-tile remainder path; transposed-output and fused bias-sum modes."""
     from contrastive_lift_amd import engine
