@@ -287,22 +287,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_
             }
         }
     }
-    // lane (li, lh) holds gW rows n = 128 wn + 32 tn + 8 q + 4 lh + e, column k = 64 wk + 32 tk + li.  All blocks finish together:
-    // each starts its flush at a different tile (rotation by block index) so that they do not queue up on the same cache lines.
-    const int rot = blockIdx.x & 7;
-    for (int ph = 0; ph < 8; ++ph) {
-        const int idx = (ph + rot) & 7;
+    // lane (li, lh) holds gW rows n = 128 wn + 32 tn + 8 q + 4 lh + e, column k = 64 wk + 32 tk + li
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c != idx) continue;
-            const int tn = c >> 1, tk = c & 1;
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = 128 * wn + 32 * tn + 8 * (r >> 2) + 4 * lh + (r & 3), k = 64 * wk + 32 * tk + li;
                 unsafeAtomicAdd(g.C + (size_t)n * g.ldc + k, acc[tn][tk][r]);
             }
-        }
-    }
     if (g.colsum) {          // fold the two m-halves (lanes l, l + 32) first: one atomic per address and wave
         const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(csum), __float_as_uint(csum), false, false);
         const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -311,10 +305,111 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_
 }
 
 // Eligibility decided by the caller: M = N = 256 (gW is 256 x 256), both streamed operands bf16-stored with 16-byte-aligned rows.
+int clift_wgrad_bf16_stream2d_launch(const GemmP& p, hipStream_t st);
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st) {
+    if (p.K >= 4096 && getenv("CLIFT_WGRAD_1D") == nullptr) return clift_wgrad_bf16_stream2d_launch(p, st);      // 64 row ranges x 4 column slices
     const int tiles = cdiv(p.K, LY_ROWS);
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(p.K, blocks), LY_ROWS) * LY_ROWS;
     k_wgrad_bf16_stream<<<cdiv(p.K, rpb), 512, 0, st>>>(p, rpb);
     return clift_check_launch("clift_gemm(bf16 wgrad stream)");
+}
+
+// ---------------------------------------------------------------------------- the same weight gradient cut in two dimensions
+// The one-dimensional kernel above ends with every CU adding a full 256 x 256 partial to gW: 1024 atomic wave-instructions per CU,
+// ~45-50 us per launch whatever the atomic scope -- more than the 33 us it takes to stream 249 k rows.  Here: 64 row ranges x 4 column
+// slices of 64 (256 blocks, one per CU); a block streams its rows of dY (all 256 columns) and of its X slice and ends with a 256 x 64
+// partial (a quarter of the atomics).  The four slice-blocks of a range have block ids 8 apart = the same XCD, so dY comes from HBM once
+// and from that L2 three times.  Wave w owns dY columns 32 w .. +31 (gW rows) for both 32-column halves of the slice.
+// X-slice image: rows of 128 B (8 chunks); chunk c of row r sits in slot c ^ (((r >> 1) & 1) << 1), which puts the four rows of a
+// transposed read in four different 32-byte bank spans.
+constexpr int W2_XB = LY_ROWS * 128, W2_STAGE = LY_TILE * 16 + W2_XB, W2_DEPTH = 2, W2_STAGES = W2_DEPTH + 1;     // bytes
+
+__global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream2d(GemmP g, int rows_per_range) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[W2_STAGES * W2_STAGE];          // 120 KB, the only LDS object
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.x, slice = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
+    const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + LY_ROWS - 1) / LY_ROWS;
+    const unsigned short* Y16 = reinterpret_cast<const unsigned short*>(g.A);
+    const unsigned short* X16 = reinterpret_cast<const unsigned short*>(g.B) + 64 * slice;
+    auto dma = [&](int t) {
+        const int r0 = rbeg + t * LY_ROWS;
+        unsigned char* st = lds + (t % W2_STAGES) * W2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int inst = wave * 4 + i;
+            const int row = inst * 2 + lh, c = li ^ ((row & 3) << 2);
+            const int gr = min(r0 + row, rend - 1);
+            __builtin_amdgcn_global_load_lds(Y16 + (size_t)gr * g.lda + c * 8, (lds_ptr_t)(st + inst * 1024), 16, 0, 0);
+        }
+        const int row = wave * 8 + (lane >> 3), c = (lane & 7) ^ (((row >> 1) & 1) << 1);
+        const int gr = min(r0 + row, rend - 1);
+        __builtin_amdgcn_global_load_lds(X16 + (size_t)gr * g.ldb + c * 8, (lds_ptr_t)(st + LY_TILE * 16 + wave * 1024), 16, 0, 0);
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float csum = 0.f;
+    // lane-constant fragment addresses (bytes): row 8 lh + ((lane & 15) >> 2) of a 16-row step, 16-column half (lane >> 4) & 1, 4-column quad lane & 3
+    const int s4 = (lane >> 2) & 3;                 // row & 3
+    const int s2 = (lane >> 3) & 1;                 // (row >> 1) & 1
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const int frow = 8 * lh + ((lane & 15) >> 2);
+    const unsigned ya = lds0 + (unsigned)(frow * 512 + (((4 * wave) ^ (4 * s4)) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) * 16 + (lane & 1) * 8);
+    unsigned xa[2];
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+        xa[tk] = lds0 + (unsigned)(LY_TILE * 16 + frow * 128 + (((4 * tk + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ (2 * s2)) * 16) + (lane & 1) * 8);
+
+    for (int t = 0; t < W2_DEPTH && t < ntiles; ++t) dma(t);
+    for (int t = 0; t < ntiles; ++t) {
+        if (min(t + W2_DEPTH - 1, ntiles - 1) > t) wait_vm<5>(); else wait_vm<0>();           // one younger tile (5 DMAs) stays in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + W2_DEPTH < ntiles) dma(t + W2_DEPTH);
+        const int valid = rend - (rbeg + t * LY_ROWS);
+        if (valid < LY_ROWS) {                                               // zero the dY rows past the end (last tile of a range)
+            uint4* st = reinterpret_cast<uint4*>(lds + (t % W2_STAGES) * W2_STAGE);
+            for (int e = tid; e < (LY_ROWS - valid) * 32; e += 512) st[valid * 32 + e] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
+        const unsigned so = (unsigned)((t % W2_STAGES) * W2_STAGE);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+            uint2 yr[2], xr[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) yr[p] = tr_read(ya + so + (unsigned)((16 * ms + 4 * p) * 512));
+#pragma unroll
+            for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xr[tk][p] = tr_read(xa[tk] + so + (unsigned)((16 * ms + 4 * p) * 128));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yr[0]), "+v"(yr[1]), "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]) : : "memory");
+            const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(yr[0].x, yr[0].y, yr[1].x, yr[1].y));
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, make_uint4(xr[0][0].x, xr[0][0].y, xr[0][1].x, xr[0][1].y));
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, make_uint4(xr[1][0].x, xr[1][0].y, xr[1][1].x, xr[1][1].y));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+            if (g.colsum && slice == 0) csum += (bf16_pair_sum(yr[0].x) + bf16_pair_sum(yr[0].y)) + (bf16_pair_sum(yr[1].x) + bf16_pair_sum(yr[1].y));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = 32 * wave + 8 * (r >> 2) + 4 * lh + (r & 3);
+        float* dst = g.C + (size_t)n * g.ldc + 64 * slice + li;
+        unsafeAtomicAdd(dst, acc0[r]);
+        unsafeAtomicAdd(dst + 32, acc1[r]);
+    }
+    if (g.colsum && slice == 0) {
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(csum), __float_as_uint(csum), false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (lh == 0) unsafeAtomicAdd(g.colsum + 32 * wave + li, tot);
+    }
+}
+
+int clift_wgrad_bf16_stream2d_launch(const GemmP& p, hipStream_t st) {
+    const int rpr = cdiv(cdiv(p.K, 64), LY_ROWS) * LY_ROWS;
+    k_wgrad_bf16_stream2d<<<256, 512, 0, st>>>(p, rpr);
+    return clift_check_launch("clift_gemm(bf16 wgrad stream 2-D)");
 }
