@@ -173,7 +173,7 @@ def _lin_params(seq, views_prefix, views):
 
 
 # ----------------------------------------------------------------------------- concurrent head chains
-MULTI_STREAM = os.environ.get("CLIFT_STREAMS", "0") == "1"   # opt-in: +4 % step throughput, but kernels then overlap in profiles
+MULTI_STREAM = os.environ.get("CLIFT_STREAMS", "0") == "1"   # opt-in; +4 % with the tiled kernels, -3 % with the persistent ones
 _side_streams = {}
 
 
