@@ -57,37 +57,35 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         }
     }
     wait_vmf<0>();
-    auto dma = [&](int t) {
-        const int r0 = rbeg + t * LF_ROWS;
-        float4* st = lds + (t & 1) * LF_TILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 4 + i;                                    // one 1 KB row per wave instruction
-            const int gr = min(r0 + row, rend - 1);                          // rows past the range re-read its last row (never stored)
-            const int c = lane ^ (row & 15);
-            __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(st + row * 64), 16, 0, 0);
-        }
-    };
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     unsigned off8[8];         // slot of chunk 2 jj + lh of this lane's row, low four bits swizzled
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) off8[jj] = (unsigned)(((2 * jj + lh) ^ (li & 15)) * 16);
-    dma(0);
+    // One row of the DMA of tile t (this wave copies rows 4 wave .. +3 of every tile).
+    auto dma_row = [&](int t, int i) {
+        const int row = wave * 4 + i;                                        // one 1 KB row per wave instruction
+        const int gr = min(rbeg + t * LF_ROWS + row, rend - 1);              // rows past the range re-read its last row (never stored)
+        const int c = lane ^ (row & 15);
+        __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(lds + (t & 1) * LF_TILE + row * 64), 16, 0, 0);
+    };
+    // The memory instructions of a tile are SPREAD through its MFMA loop instead of bunched at the tile boundary: eight waves issuing
+    // 4 stores + 4 DMA rows each at the same moment cost 1.3 us of a 8.6 us tile (the MFMA pipe idles while the waves sit in the vector-memory
+    // issue queue); one instruction every other k-step disappears under the MFMAs (probe: 124 -> 145 TFLOP/s for the same work).  So the rows
+    // of tile t+1 are copied at steps 0, 2, 4, 6 of tile t, and the results of tile t-1 -- kept in 16 registers -- are stored at steps 8, 10,
+    // 12, 14 of tile t (dgrad: the mask loads of tile t go at steps 16 .. 22).
+    float4 prev[4];
+    int prev_m = rend;                                                       // row of `prev`; rend = nothing to store yet
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_row(0, i);
     for (int t = 0; t < ntiles; ++t) {
-        // younger than the DMA of tile t (issued after the previous barrier): the 4 stores of tile t-1 (and, in the dgrad, its mask
-        // loads, which the previous epilogue already waited for together with everything older -- tile t included)
-        if (t > 0) wait_vmf<4>(); else wait_vmf<0>();
+        // DMA of tile t: issued during tile t-1; younger than it: the 4 stores of tile t-2 (forward; the dgrad drained everything at the end
+        // of tile t-1 for its mask)
+        if (t >= 2) wait_vmf<4>(); else wait_vmf<0>();
         __builtin_amdgcn_s_barrier();                                        // everyone's rows have landed; everyone is done with the other stage
         asm volatile("" ::: "memory");
-        if (t + 1 < ntiles) dma(t + 1);
         const int m = rbeg + t * LF_ROWS + li;
+        const bool more = t + 1 < ntiles;
         f32x4 mk[4];
-        if (DGRAD) {
-            const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                         : "=&v"(mk[0]), "=&v"(mk[1]), "=&v"(mk[2]), "=&v"(mk[3]) : "v"(mp) : "memory");
-        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -110,7 +108,17 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             f32x4& c0 = fa[j & 1];
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0) : : "memory");
             if (j + 1 < 32) rd(j + 1, fa[(j + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);          // keep the read ahead of this step's MFMAs (the scheduler would sink it behind them)
+            if (j < 8 && (j & 1) == 0) { if (more) dma_row(t + 1, j >> 1); }
+            if (j >= 8 && j < 16 && (j & 1) == 0) {
+                const int q = (j - 8) >> 1;
+                if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
+            }
+            if (DGRAD && j >= 16 && j < 24 && (j & 1) == 0) {
+                const int q = (j - 16) >> 1;
+                const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh + 8 * q;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[q]) : "v"(mp) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the read (and this step's memory instruction) ahead of this step's MFMAs
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].x, c0.x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].y, c0.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, c0.z, acc0, 0, 0, 0);
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             __builtin_amdgcn_sched_barrier(0);          // ... and this step's MFMAs ahead of the next step's wait
         }
         if (DGRAD) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
-        // lane (li, lh) holds row li of the tile, columns 32 wave + 8 q + 4 lh + (0..3) for q = 0..3
+        // lane (li, lh) holds row li of the tile, columns 32 wave + 8 q + 4 lh + (0..3) for q = 0..3: kept for the next tile's loop
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 o = make_float4(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1],
@@ -129,8 +137,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             } else if (g.act == 1) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            if (m < rend) *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + 32 * wave + 8 * q + 4 * lh) = o;
+            prev[q] = o;
         }
+        prev_m = m;
+    }
+    if (prev_m < rend) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
     }
 }
 
