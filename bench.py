@@ -208,7 +208,7 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
 def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
     """``rec`` = the (kind, M, N, K, start event, end event) records of every clift_gemm launch of the ``nb`` timed steps.  The
     dominant kernel by time is k_layer_f32<false> (csrc/layer_f32.hip) = the 256x256 forward layers of the semantic / fast /
-    slow instance MLPs as a persistent kernel (rocprofv3 lists it under exactly that name, profiles/r01_v11_*): achieved = its
+    slow instance MLPs as a persistent kernel (rocprofv3 lists it under exactly that name, profiles/r01_v12_*): achieved = its
     algorithmic FLOPs (2*M*256*256 per launch, M = active samples of the pass) / its summed launch durations; peak = dense fp32
     MFMA.  ``all_gemm`` is the same ratio over every matrix-core launch (forward, dgrad, wgrad, narrow layers).  The active-sample
     count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
