@@ -86,8 +86,7 @@ def main():
         tr.training_step(batches[i % n_batches], lean=a.lean)
     # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
     # replays exactly these steps with per-launch events
-    snap = (model.param_flat.clone(), tr.opt_main.m.clone(), tr.opt_main.v.clone(), tr.opt_main.t,
-            tr.opt_inst.m.clone(), tr.opt_inst.v.clone(), tr.opt_inst.t)
+    snap = (model.param_flat.clone(), tr.opt_main.state_dict(), tr.opt_inst.state_dict())
     sync_all()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -103,8 +102,8 @@ def main():
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected clift_gemm launches bracketed by HIP events."""
         model.param_flat.copy_(snap[0])
-        tr.opt_main.m.copy_(snap[1]); tr.opt_main.v.copy_(snap[2]); tr.opt_main.t = snap[3]
-        tr.opt_inst.m.copy_(snap[4]); tr.opt_inst.v.copy_(snap[5]); tr.opt_inst.t = snap[6]
+        tr.opt_main.load_state_dict(snap[1])
+        tr.opt_inst.load_state_dict(snap[2])
         out = []
 
         def recorded_gemm(M, N, K, *args, **kw):

@@ -240,7 +240,9 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
                       "clift_gemm: precision 2 needs a 16-byte aligned workspace of %ld bytes (got %ld)", need, h->workspace_bytes);
         return clift_gemm_split_launch(p, h->a_trans, h->b_trans, h->workspace, st);
     }
-    if (h->precision == 0 && !h->a_trans && !h->b_trans && h->N == 256 && h->K == 256 && h->M >= 4096 && splits == 1 && !h->accumulate && !h->c_trans &&
+    // (every M: a row's result must not depend on how many rows share its launch -- a frame rendered in row tiles over several GPUs
+    // has to be bit-identical to the unsharded render, and the tiled kernel sums k in a different order)
+    if (h->precision == 0 && !h->a_trans && !h->b_trans && h->N == 256 && h->K == 256 && splits == 1 && !h->accumulate && !h->c_trans &&
         !h->mask && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_layer_f32_launch(p, 0, st);                    // persistent forward layer: weights in registers, LDS-DMA row stream
     if (h->precision == 0 && !h->a_trans && h->b_trans && h->N == 256 && h->K == 256 && h->M >= 4096 && splits == 1 && !h->accumulate && !h->c_trans &&

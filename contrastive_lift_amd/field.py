@@ -156,15 +156,17 @@ class TensorVMSplit(nn.Module):
                 out.append((f"{pre}_plane.{i}", getattr(self, f"{pre}_plane"), i, "grid", grp))
             for i in range(3):
                 out.append((f"{pre}_line.{i}", getattr(self, f"{pre}_line"), i, "grid", grp))
-        out.append(("appearance_basis_mat.weight", self.appearance_basis_mat, "weight", "matrix", "net_main"))
+        out.append(("appearance_basis_mat.weight", self.appearance_basis_mat, "weight", "matrix", "net_app"))
 
         def seq(prefix, s, grp):
             for j, m in enumerate(s):
                 if isinstance(m, nn.Linear):
                     out.append((f"{prefix}.{j}.weight", m, "weight", "matrix", grp))
                     out.append((f"{prefix}.{j}.bias", m, "bias", "vector", grp))
-        seq("render_appearance_mlp.mlp", self.render_appearance_mlp.mlp, "net_main")
-        seq("render_semantic_mlp.mlp", self.render_semantic_mlp.mlp, "net_main")
+        seq("render_appearance_mlp.mlp", self.render_appearance_mlp.mlp, "net_app")
+        # the semantic MLP is its own optimizer range: while it has no gradient source (epoch < late_semantic_optimization)
+        # the reference's Adam skips it (grad is None), so its step -- and its step COUNT -- must be skippable too
+        seq("render_semantic_mlp.mlp", self.render_semantic_mlp.mlp, "net_sem")
         if self.render_instance_mlp is not None:
             seq("render_instance_mlp.mlp", self.render_instance_mlp.mlp, "inst_fast")
             if self.slow_fast_mode:

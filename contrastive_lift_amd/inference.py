@@ -49,8 +49,14 @@ def render_rays_sharded(model, renderer, rays, chunk, white_bg=False, render_fn=
     cap = max(b[r + 1] - b[r] for r in range(world))                      # equal-size slots: tiles differ by <= 1 ray
     slot = torch.zeros((cap, packed.shape[1]), dtype=packed.dtype, device=packed.device)
     slot[:packed.shape[0]] = packed
-    slots = [torch.empty_like(slot) for _ in range(world)]
-    dist.all_gather(slots, slot)
+    if dist.get_backend() != "nccl":           # CPU-side backends (gloo in the tests) gather host copies
+        host = slot.cpu()
+        slots = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(slots, host)
+        slots = [s_.to(slot.device) for s_ in slots]
+    else:
+        slots = [torch.empty_like(slot) for _ in range(world)]
+        dist.all_gather(slots, slot)
     full = torch.cat([slots[r][:b[r + 1] - b[r]] for r in range(world)], 0)
     outs, c = [], 0
     for x, w in zip(mine, widths):

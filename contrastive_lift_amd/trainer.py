@@ -35,22 +35,38 @@ def default_config(**over):
 
 class ArenaAdam:
     """torch.optim.Adam semantics (trainer/__init__.py:134-135) over contiguous arena ranges: one clift_adam launch
-    per (lr, weight_decay) range.  ``ranges`` = [(start, end, lr)]."""
+    per (lr, weight_decay) range.  ``ranges`` = [(name, start, end, lr)].
+
+    torch's Adam skips a parameter whose ``.grad`` is None (the reference zeroes with ``set_to_none=True``, T:152,211) and keeps
+    a step count PER PARAMETER, so a head that has no gradient source yet (the semantic MLP while epoch <
+    late_semantic_optimization) is neither decayed nor moved and starts its bias correction at t = 1 when its loss term
+    switches on.  Here every range has its own step count and ``step(skip=...)`` leaves the named ranges untouched."""
 
     def __init__(self, model, ranges, betas, weight_decay, eps=1e-8):
-        self.model, self.ranges, self.betas, self.wd, self.eps = model, ranges, betas, weight_decay, eps
+        self.model, self.betas, self.wd, self.eps = model, betas, weight_decay, eps
+        self.ranges = [tuple(r) for r in ranges]
         self.m = torch.zeros_like(model.param_flat)
         self.v = torch.zeros_like(model.param_flat)
-        self.t = 0
+        self.t = {r[0]: 0 for r in self.ranges}
         self.lr_scale = 1.0
 
-    def step(self):
-        self.t += 1
+    def step(self, skip=()):
         p, g = self.model.param_flat, self.model.grad_flat
         st = _lib.stream()
-        for a, b, lr in self.ranges:
+        for name, a, b, lr in self.ranges:
+            if name in skip or b <= a:
+                continue
+            self.t[name] += 1
             _lib.call("clift_adam", _lib.ptr(p[a:b]), _lib.ptr(g[a:b]), _lib.ptr(self.m[a:b]), _lib.ptr(self.v[a:b]), b - a,
-                      float(lr * self.lr_scale), self.betas[0], self.betas[1], self.eps, float(self.wd), self.t, st)
+                      float(lr * self.lr_scale), self.betas[0], self.betas[1], self.eps, float(self.wd), self.t[name], st)
+
+    def state_dict(self):
+        return {"m": self.m.detach().clone(), "v": self.v.detach().clone(), "t": dict(self.t), "lr_scale": self.lr_scale}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"].to(self.m.device)); self.v.copy_(sd["v"].to(self.v.device))
+        self.t = {k: int(sd["t"].get(k, 0)) for k in self.t}
+        self.lr_scale = float(sd.get("lr_scale", 1.0))
 
 
 class HotPathTrainer:
@@ -84,12 +100,15 @@ class HotPathTrainer:
     def setup_optimizers(self):
         m, c = self.model, self.config
         a0, a1 = m.arena.range_of("grid_density", "grid_app")
-        b0, b1 = m.arena.range_of("net_main")
-        self.opt_main = ArenaAdam(m, [(a0, a1, c.lr * 20), (b0, b1, c.lr)], (0.9, 0.99), c.weight_decay)
-        self.main_range = m.arena.range_of("grid_density", "grid_app", "net_main")
-        groups = ["inst_fast"] + (["inst_slow"] if (m.slow_fast_mode and not c.use_DINO_style) else [])
-        i0, i1 = m.arena.range_of(*groups)
-        self.opt_inst = ArenaAdam(m, [(i0, i1, c.lr)], (0.9, 0.999), c.weight_decay)
+        b0, b1 = m.arena.range_of("net_app")
+        s0, s1 = m.arena.range_of("net_sem")
+        self.opt_main = ArenaAdam(m, [("grids", a0, a1, c.lr * 20), ("net_app", b0, b1, c.lr), ("net_sem", s0, s1, c.lr)],
+                                  (0.9, 0.99), c.weight_decay)
+        self.main_range = m.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")
+        # The slow MLP is listed in the reference's instance optimizer when not DINO-style (F:241-244), but its output is detached
+        # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
+        i0, i1 = m.arena.range_of("inst_fast")
+        self.opt_inst = ArenaAdam(m, [("inst_fast", i0, i1, c.lr)], (0.9, 0.999), c.weight_decay)
         self.inst_range = (i0, i1)
 
     def on_train_epoch_start(self):
@@ -148,7 +167,7 @@ class HotPathTrainer:
         tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         self.losses[2] = tv
         self._allreduce(self.main_range)
-        self.opt_main.step()
+        self.opt_main.step(skip=() if sem_on else ("net_sem",))      # no semantic term yet: the head's grad is None in the reference
         self.last_outputs = (rgb, sem)
         return ctxs
 
