@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -84,6 +84,8 @@ _SIGNATURES = {
     "clift_tv_fwd_bwd": ([_P, _I, _I, _I, _F, _P, _P, _P], C.c_int),
     "clift_tv_fwd_bwd_multi": ([_P, _P, _P], C.c_int),
     "clift_pixel_losses": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
+    "clift_pixel_losses_sce": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P], C.c_int),
+    "clift_semantic_loss_rows": ([_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P], C.c_int),
     "clift_contrastive": ([_P, _P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
     "clift_slow_fast": ([_P, _P, _P, _I, _I, _P, _P, _P, _P], C.c_int),
     "clift_nearest_centroid": ([_P, _I, _I, _P, _I, _P, _L, _P, _P], C.c_int),

@@ -20,5 +20,5 @@ int clift_check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int clift_version(void) { return 5; }
+extern "C" int clift_version(void) { return 6; }
 extern "C" const char* clift_last_error(void) { return g_err; }

@@ -124,11 +124,57 @@ extern "C" int clift_tv_fwd_bwd(const float* plane, int H, int W, int C, float w
 }
 
 // ============================================================================ pixel losses (trainer T:160,177-178)
+// Per-row semantic loss and its gradient.  sce == 0: CrossEntropyLoss(weight=cw, reduction='none') with soft targets (T:75,177):
+//   l = -sum_c cw_c p_c log_softmax(x)_c.  sce != 0: SCELoss (model/loss/loss.py:36-59): l = alpha * CE + beta * RCE with
+//   RCE = -sum_c clamp(softmax(x . cw), 1e-8, 1)_c * log(clamp(p_c, 1e-8, 1)) * cw_c   (the prediction is re-softmaxed over the
+//   class-weighted logits, L:50-52).  gx (nullable) receives k * d l / d x.
+__device__ __forceinline__ float semantic_row_loss(const float* __restrict__ x, const float* __restrict__ p, const float* __restrict__ cw, int C,
+                                                   int sce, float alpha, float beta, float k, float* __restrict__ gx) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float lse = mx + logf(se);
+    float ce = 0.f, pw = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float wc = cw ? cw[c] : 1.f;
+        ce -= wc * p[c] * (x[c] - lse);
+        pw += wc * p[c];
+    }
+    if (!sce) {
+        if (gx)
+            for (int c = 0; c < C; ++c) gx[c] = k * (expf(x[c] - lse) * pw - (cw ? cw[c] : 1.f) * p[c]);
+        return ce;
+    }
+    // reverse cross entropy over q = softmax(cw . x)
+    float my = -INFINITY;
+    for (int c = 0; c < C; ++c) my = fmaxf(my, (cw ? cw[c] : 1.f) * x[c]);
+    float sy = 0.f;
+    for (int c = 0; c < C; ++c) sy += expf((cw ? cw[c] : 1.f) * x[c] - my);
+    float rce = 0.f, aq = 0.f;          // aq = sum_c a_c q_c with a_c = d rce / d q_c (zero where the clamp is active)
+    for (int c = 0; c < C; ++c) {
+        const float wc = cw ? cw[c] : 1.f;
+        const float q = expf(wc * x[c] - my) / sy;
+        const float L = logf(fminf(fmaxf(p[c], 1e-8f), 1.0f));
+        rce -= fminf(fmaxf(q, 1e-8f), 1.0f) * L * wc;
+        if (q >= 1e-8f && q <= 1.0f) aq += (-L * wc) * q;
+    }
+    if (gx)
+        for (int c = 0; c < C; ++c) {
+            const float wc = cw ? cw[c] : 1.f;
+            const float q = expf(wc * x[c] - my) / sy;
+            const float L = logf(fminf(fmaxf(p[c], 1e-8f), 1.0f));
+            const float a = (q >= 1e-8f && q <= 1.0f) ? -L * wc : 0.f;
+            gx[c] = k * (alpha * (expf(x[c] - lse) * pw - wc * p[c]) + beta * wc * q * (a - aq));
+        }
+    return alpha * ce + beta * rce;
+}
+
 __global__ __launch_bounds__(256) void k_pixel_losses(const float* __restrict__ rgb, const float* __restrict__ gt, const float* __restrict__ sem,
                                                        const float* __restrict__ probs, const float* __restrict__ conf,
                                                        const float* __restrict__ cw, const float* __restrict__ maskf, int N, int C,
-                                                       float w_rgb, float w_sem, float* __restrict__ out2, float* __restrict__ g_rgb,
-                                                       float* __restrict__ g_sem) {
+                                                       float w_rgb, float w_sem, int sce, float alpha, float beta,
+                                                       float* __restrict__ out2, float* __restrict__ g_rgb, float* __restrict__ g_sem) {
     __shared__ float sh[4];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float l_rgb = 0.f, l_sem = 0.f;
@@ -142,26 +188,9 @@ __global__ __launch_bounds__(256) void k_pixel_losses(const float* __restrict__ 
             }
         }
         if (sem && probs) {
-            const float* x = sem + (size_t)r * C;
-            const float* p = probs + (size_t)r * C;
             const float cf = (conf ? conf[r] : 1.f) * mk;
-            float mx = -INFINITY;
-            for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
-            float se = 0.f;
-            for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
-            const float lse = mx + logf(se);
-            float li = 0.f, pw = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float wc = cw ? cw[c] : 1.f;
-                li -= wc * p[c] * (x[c] - lse);
-                pw += wc * p[c];
-            }
-            l_sem = cf * li;
-            if (g_sem)
-                for (int c = 0; c < C; ++c) {
-                    const float wc = cw ? cw[c] : 1.f;
-                    g_sem[(size_t)r * C + c] = w_sem * cf * (expf(x[c] - lse) * pw - wc * p[c]) / (float)N;
-                }
+            l_sem = cf * semantic_row_loss(sem + (size_t)r * C, probs + (size_t)r * C, cw, C, sce, alpha, beta, w_sem * cf / (float)N,
+                                           g_sem ? g_sem + (size_t)r * C : nullptr);
         }
     }
     const float a = block_sum_256(l_rgb, sh);
@@ -176,8 +205,35 @@ extern "C" int clift_pixel_losses(const float* rgb, const float* rgb_gt, const f
                                   const float* class_w, const float* maskf, int N, int C, float w_rgb, float w_sem, float* out2,
                                   float* g_rgb, float* g_sem, clift_stream_t s) {
     if (N <= 0) return 0;
-    k_pixel_losses<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(rgb, rgb_gt, sem, probs, conf, class_w, maskf, N, C, w_rgb, w_sem, out2, g_rgb, g_sem);
+    k_pixel_losses<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(rgb, rgb_gt, sem, probs, conf, class_w, maskf, N, C, w_rgb, w_sem, 0, 1.f, 0.f, out2, g_rgb, g_sem);
     return clift_check_launch("clift_pixel_losses");
+}
+
+extern "C" int clift_pixel_losses_sce(const float* rgb, const float* rgb_gt, const float* sem, const float* probs, const float* conf,
+                                      const float* class_w, const float* maskf, int N, int C, float w_rgb, float w_sem, float alpha,
+                                      float beta, float* out2, float* g_rgb, float* g_sem, clift_stream_t s) {
+    if (N <= 0) return 0;
+    k_pixel_losses<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(rgb, rgb_gt, sem, probs, conf, class_w, maskf, N, C, w_rgb, w_sem, 1, alpha, beta, out2, g_rgb, g_sem);
+    return clift_check_launch("clift_pixel_losses_sce");
+}
+
+// Per-row form of the semantic losses (the loss callables of the reference return one value per pixel, reduction='none'):
+// loss_rows (N), grad_rows (N, C; nullable) = d loss_rows[i] / d pred[i, :].
+__global__ __launch_bounds__(256) void k_semantic_rows(const float* __restrict__ pred, const float* __restrict__ probs, const float* __restrict__ cw,
+                                                        int N, int C, int sce, float alpha, float beta, float* __restrict__ loss_rows,
+                                                        float* __restrict__ grad_rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    loss_rows[r] = semantic_row_loss(pred + (size_t)r * C, probs + (size_t)r * C, cw, C, sce, alpha, beta, 1.f,
+                                     grad_rows ? grad_rows + (size_t)r * C : nullptr);
+}
+
+extern "C" int clift_semantic_loss_rows(const float* pred, const float* probs, const float* class_w, int N, int C, int sce, float alpha,
+                                        float beta, float* loss_rows, float* grad_rows, clift_stream_t s) {
+    CLIFT_REQUIRE(C >= 1, "clift_semantic_loss_rows: C must be positive");
+    if (N <= 0) return 0;
+    k_semantic_rows<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(pred, probs, class_w, N, C, sce, alpha, beta, loss_rows, grad_rows);
+    return clift_check_launch("clift_semantic_loss_rows");
 }
 
 // ============================================================================ segment consistency (T:185-197)

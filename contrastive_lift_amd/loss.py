@@ -56,6 +56,64 @@ def slow_fast_loss(instance_features, labels_gt, confidences, return_grad=False)
     return _Scaled.apply(instance_features, loss[0], grad)
 
 
+def get_semantic_weights(reweight_classes, fg_classes, num_semantic_classes):
+    """loss.py:29-33: per-class weights of the semantic losses -- ones, foreground ("thing") classes doubled when
+    ``reweight_classes`` (config reweight_fg).  The trainer then overwrites entry 0 with config.weight_class_0 (T:69-70)."""
+    weights = torch.ones([num_semantic_classes]).float()
+    if reweight_classes:
+        weights[fg_classes] = 2
+    return weights
+
+
+class _SemanticRows(torch.autograd.Function):
+    """Per-pixel semantic loss (reduction='none') with the gradient produced by the same kernel launch."""
+
+    @staticmethod
+    def forward(ctx, pred, target, class_weights, sce, alpha, beta):
+        x = _lib.f32(pred, "pred").contiguous()
+        p = _lib.f32(target.to(x.device), "labels_probabilities").contiguous()
+        if p.shape != x.shape:
+            raise ValueError(f"soft targets must have the prediction's shape {tuple(x.shape)}, got {tuple(p.shape)}")
+        n, c = x.shape
+        cw = None if class_weights is None else _lib.f32(torch.as_tensor(class_weights).to(x.device), "class_weights").contiguous()
+        rows = torch.empty((n,), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        _lib.call("clift_semantic_loss_rows", _lib.ptr(x), _lib.ptr(p), _lib.ptr(cw), n, c, int(sce), float(alpha), float(beta),
+                  _lib.ptr(rows), _lib.ptr(grad), _lib.stream())
+        ctx.save_for_backward(grad)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g[:, None] * grad, None, None, None, None, None
+
+
+class SCELoss(nn.Module):
+    """loss.py:36-59: symmetric cross entropy on soft targets, one value per pixel:
+    alpha * CrossEntropyLoss(weight, reduction='none')(pred, p) + beta * RCE, where the reverse term re-softmaxes the
+    class-weighted logits: RCE = -sum_c clamp(softmax(pred * w), 1e-8, 1)_c * log(clamp(p_c, 1e-8, 1)) * w_c."""
+
+    def __init__(self, alpha, beta, class_weights):
+        super().__init__()
+        self.alpha, self.beta, self.class_weights = alpha, beta, class_weights
+
+    def forward(self, pred, labels_probabilities):
+        return _SemanticRows.apply(pred, labels_probabilities, self.class_weights, 1, self.alpha, self.beta)
+
+
+class SoftTargetCrossEntropy(nn.Module):
+    """torch.nn.CrossEntropyLoss(reduction='none', weight=w) on probability targets (the reference's ``loss_semantics`` when
+    use_symmetric_ce is off, T:75), through the same kernel."""
+
+    def __init__(self, class_weights=None):
+        super().__init__()
+        self.class_weights = class_weights
+
+    def forward(self, pred, labels_probabilities):
+        return _SemanticRows.apply(pred, labels_probabilities, self.class_weights, 0, 1.0, 0.0)
+
+
 @torch.no_grad()
 def ema_update(slownet, fastnet, momentum):
     """trainer T:325-329: slow <- momentum*slow + (1-momentum)*fast, parameter by parameter."""

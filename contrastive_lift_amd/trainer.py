@@ -27,7 +27,7 @@ def default_config(**over):
              semantic_weight_mode="softmax", stop_semantic_grad=True, probabilistic_ce_mode="TTAConf", weight_class_0=0.0,
              decay_step=[9, 10], decay_gamma=0.5, temperature=100.0,
              lambda_segment=1.2, segment_grouping_mode="argmax_conf", segment_optimization_epoch=6, batch_size_segments=32,
-             max_rays_segments=1024,
+             max_rays_segments=1024, use_symmetric_ce=False, ce_alpha=0.85, ce_beta=0.15, reweight_fg=False,
              mlp_dtype="fp32")     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
     c.update(over)
     return types.SimpleNamespace(**c)
@@ -75,7 +75,7 @@ class HotPathTrainer:
     def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
         # config variants of the reference that this trainer does not implement fail loudly instead of being ignored
-        unsupported = [(k, v) for k, v in (("probabilistic_ce_mode", "TTAConf"), ("use_symmetric_ce", False), ("optimize_instance_only", False),
+        unsupported = [(k, v) for k, v in (("probabilistic_ce_mode", "TTAConf"), ("optimize_instance_only", False),
                                             ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
                                             ("use_proj", False), ("use_feature_regularization", False))
                        if getattr(config, k, v) != v]
@@ -154,15 +154,24 @@ class HotPathTrainer:
         mask = batch.get("mask")
         maskf = mask.to(torch.float32) if mask is not None else None        # T:156-158 (masked pixels contribute nothing)
         self.losses.zero_()
-        _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
-                  _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
-                  _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
+        if getattr(c, "use_symmetric_ce", False):       # T:74-77: SCELoss(ce_alpha, ce_beta, weights) replaces the cross entropy
+            _lib.call("clift_pixel_losses_sce", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
+                      _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
+                      float(c.ce_alpha), float(c.ce_beta), _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
+        else:
+            _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
+                      _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
+                      _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
         g_dist = torch.full((1,), w_rgb * self.current_lambda_dist_reg / len(ctxs), dtype=torch.float32, device=self.device)
         gv = m.named_grad_views()
         for k, ctx in enumerate(ctxs):
             s = slice(k * chunk, k * chunk + ctx.N)
             engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True)
         if segments is not None and sem_on and float(getattr(c, "lambda_segment", 0.0)) != 0.0:
+            if getattr(c, "use_symmetric_ce", False):
+                # the reference calls loss_semantics(features, CLASS INDICES) here (T:194); SCELoss takes log(labels) of them
+                # (loss.py:53) -- that combination does not run in the reference either
+                raise NotImplementedError("segment-consistency term with use_symmetric_ce: SCELoss is undefined on class-index targets")
             self._segment_term(segments, segment_jitter, gv, w_sem * float(c.lambda_segment))
         tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         self.losses[2] = tv

@@ -228,6 +228,18 @@ int clift_pixel_losses(const float* rgb, const float* rgb_gt, const float* sem, 
                        const float* conf, const float* class_w, const float* maskf, int N, int C, float w_rgb,
                        float w_sem, float* out2, float* g_rgb, float* g_sem, clift_stream_t s);
 
+/* The same with SCELoss in place of the cross entropy (config use_symmetric_ce, trainer T:74-77; model/loss/loss.py:36-59):
+ * per pixel alpha * CE + beta * RCE, RCE = -sum_c clamp(softmax(sem . cw), 1e-8, 1)_c log(clamp(p_c, 1e-8, 1)) cw_c. */
+int clift_pixel_losses_sce(const float* rgb, const float* rgb_gt, const float* sem, const float* probs,
+                           const float* conf, const float* class_w, const float* maskf, int N, int C, float w_rgb,
+                           float w_sem, float alpha, float beta, float* out2, float* g_rgb, float* g_sem,
+                           clift_stream_t s);
+/* Per-pixel (reduction='none') form of the two semantic losses, as the reference's loss callables return them
+ * (CrossEntropyLoss(weight, reduction='none') with soft targets: sce = 0; SCELoss: sce = 1): loss_rows (N),
+ * grad_rows (N, C; nullable) = d loss_rows[i] / d pred[i, :]. */
+int clift_semantic_loss_rows(const float* pred, const float* probs, const float* class_w, int N, int C, int sce,
+                             float alpha, float beta, float* loss_rows, float* grad_rows, clift_stream_t s);
+
 /* ---- segment-consistency term of training_step (trainer/train_panopli_tensorf.py:185-197): feats (B, ld) rendered semantic
  * features of the rays of G 2D segments, group (B) segment index of each ray.  target class of a segment = argmax of the mean
  * feature row (torch_scatter.scatter_mean); loss[0] += mean_i( class_w[t_i] conf_i CE(feats_i, t_i) ); grad (B, ldg), nullable,

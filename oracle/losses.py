@@ -82,6 +82,24 @@ def semantic_ce(log_probs, target_probs, conf, class_weight):
     return (F.cross_entropy(log_probs, target_probs, weight=class_weight, reduction="none") * conf).mean()
 
 
+def semantic_weights(reweight_classes, fg_classes, num_semantic_classes):
+    """model/loss/loss.py:29-33."""
+    w = torch.ones(num_semantic_classes)
+    if reweight_classes:
+        w[torch.as_tensor(fg_classes, dtype=torch.long)] = 2.0
+    return w
+
+
+def sce_rows(pred, target_probs, class_weight, alpha, beta):
+    """model/loss/loss.py:45-59 (SCELoss.forward): alpha * weighted soft-target CE + beta * reverse CE, where the reverse term uses
+    softmax of the class-weighted predictions clamped to [1e-8, 1] and log of the clamped targets, again class-weighted."""
+    ce = F.cross_entropy(pred, target_probs, weight=class_weight, reduction="none")
+    w = class_weight[None, :]
+    q = torch.softmax(pred * w, dim=1).clamp(min=1e-8, max=1.0)
+    rce = -(q * torch.log(target_probs.clamp(min=1e-8, max=1.0)) * w).sum(1)
+    return alpha * ce + beta * rce
+
+
 def segment_consistency(seg_features, group, conf, class_weight, n_groups):
     """trainer/train_panopli_tensorf.py:189-194: the per-segment mean of the rendered semantic features (torch_scatter.scatter_mean
     restated: sum / max(count, 1)) picks ONE class per 2D segment (argmax); every ray of the segment is then pulled towards it:

@@ -20,11 +20,12 @@ class CpuTrainer:
     def __init__(self, P, cfg, lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
                  lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True,
                  instance_loss_mode="slow_fast", temperature=100.0, use_delta=False, lambda_segment=1.2,
-                 late_semantic_optimization=0):
+                 late_semantic_optimization=0, sce=None):
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
         self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
         self.inst_mode, self.temperature, self.use_delta = instance_loss_mode, temperature, use_delta
         self.l_seg = lambda_segment
+        self.sce = sce                                             # (ce_alpha, ce_beta) when config.use_symmetric_ce (T:74-77)
         self.sem_on = epoch >= late_semantic_optimization          # T:175,198: no semantic term before that epoch
         self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
         self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
@@ -60,7 +61,12 @@ class CpuTrainer:
         dreg = torch.stack([o[5] for o in outs]).mean()
         l_rgb = torch.nn.functional.mse_loss(rgb, rgbs)
         l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva)
-        l_sem = olosses.semantic_ce(sem, probs, conf, self.cw) if self.sem_on else torch.zeros(())
+        if not self.sem_on:
+            l_sem = torch.zeros(())
+        elif self.sce is not None:
+            l_sem = (olosses.sce_rows(sem, probs, self.cw, *self.sce) * conf).mean()
+        else:
+            l_sem = olosses.semantic_ce(sem, probs, conf, self.cw)
         loss = self.l_rgb * (l_rgb + l_tv + dreg * self.l_dist)
         if self.sem_on:                           # before it the semantic MLP's .grad stays None and Adam skips it (T:198)
             loss = loss + self.l_sem * l_sem
