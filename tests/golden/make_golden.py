@@ -447,7 +447,7 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
-def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False):
+def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -456,7 +456,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     import types as _t
     import trainer.train_panopli_tensorf as T
     import model.renderer.panopli_tensoRF_renderer as RR
-    from model.loss.loss import TVLoss
+    from model.loss.loss import TVLoss, SCELoss
     res, C, E = (9, 13, 17), 4, 3
     aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
     P, pool, rng = _scene(121, res, C, E, aabb, 200)
@@ -506,7 +506,15 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     sh.loss = torch.nn.MSELoss(reduction="mean")
     sh.loss_feat = torch.nn.L1Loss(reduction="mean")
     sh.tv_regularizer = TVLoss()
-    sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
+    if sce is not None:                          # config.use_symmetric_ce (T:74-77); weights as T:69-70 with reweight_fg on classes 2, 3
+        from model.loss.loss import get_semantic_weights
+        cw = get_semantic_weights(True, [2, 3], C)
+        cw[0] = 0.0
+        with __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")
+            sh.loss_semantics = SCELoss(sce[0], sce[1], cw)
+    else:
+        sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
     sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = mode, True, 100.0, use_delta
     sh.device = torch.device("cpu")
     sh.current_epoch = epoch
@@ -518,7 +526,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
                for g in o.param_groups] for o in sh._opts]
 
     out = dict(res=np.array(res), C=C, E=E, seed=121, shift=-3.0, aabb=aabb, B=B, Bi=Bi, steps=steps, epoch=epoch, chunk=cfg.chunk,
-               mode=np.array(mode), use_delta=int(use_delta),
+               mode=np.array(mode), use_delta=int(use_delta), sce=np.array(sce if sce is not None else [0.0, 0.0], np.float64),
                class_weights=cw, lambda_dist=np.float64(sh.current_lambda_dist_reg),
                opt_groups=np.array([[g[0], g[1], g[2][0], g[2][1], g[3]] for o in groups for g in o], np.float64),
                opt_group_counts=np.array([len(o) for o in groups]))
@@ -826,6 +834,39 @@ def g17_meanshift_clustering():
     npz("g17_meanshift_clustering", **out)
 
 
+def g18_sce():
+    """SCELoss (model/loss/loss.py:36-59) and get_semantic_weights (:29-33): per-pixel values and the gradient of the
+    confidence-weighted mean (how training_step reduces it, T:177-178), incl. exact-zero / one-hot targets (the 1e-8 clamps) and
+    a zero class weight (T:70)."""
+    import warnings
+    from model.loss.loss import SCELoss, get_semantic_weights
+    rng = np.random.default_rng(181)
+    out = {}
+    out["w.plain"] = get_semantic_weights(False, [3, 5], 7)
+    out["w.fg"] = get_semantic_weights(True, [3, 5], 7)
+    out["w.fg_idx"] = np.array([3, 5])
+    for tag, N, C, alpha, beta, onehot in (("a", 64, 7, 0.85, 0.15, False), ("b", 33, 22, 0.85, 0.15, True), ("c", 17, 2, 1.0, 1.0, False),
+                                           ("d", 40, 5, 0.3, 2.0, True)):
+        w = get_semantic_weights(tag in "ad", [1, C - 1], C)
+        w[0] = 0.0
+        pred = torch.from_numpy((rng.standard_normal((N, C)) * 2.5).astype(np.float32))
+        if tag == "b":
+            pred = torch.log_softmax(pred, -1)              # the trainer feeds the renderer's log-probabilities
+        pred.requires_grad_(True)
+        p = torch.softmax(torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32) * 3), -1)
+        if onehot:
+            hot = torch.nn.functional.one_hot(torch.from_numpy(rng.integers(0, C, N)), C).float()
+            p = torch.where(torch.from_numpy(rng.uniform(0, 1, (N, 1)) < 0.5), hot, p)
+        conf = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rows = SCELoss(alpha, beta, w)(pred, p)
+        g = torch.autograd.grad((rows * conf).mean(), pred)[0]
+        out.update({f"{tag}.pred": pred, f"{tag}.p": p, f"{tag}.conf": conf, f"{tag}.w": w, f"{tag}.ab": np.array([alpha, beta]),
+                    f"{tag}.rows": rows, f"{tag}.grad": g})
+    npz("g18_sce", **out)
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -850,6 +891,8 @@ def main():
     g15_panopli_dataset()
     g16_scene_evaluators()
     g17_meanshift_clustering()
+    g18_sce()
+    g12_training_steps(fname="g12e_training_steps_sce", steps=2, sce=(0.85, 0.15))
 
 
 if __name__ == "__main__":

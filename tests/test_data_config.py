@@ -197,6 +197,7 @@ def test_trainer_rejects_unbuilt_config_variants():
                          slow_fast_mode=True, device="cpu")
     r = cl.TensoRFRenderer(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), [6, 7, 8], semantic_weight_mode="softmax")
     HotPathTrainer(m, r, default_config())                                   # the shipped settings construct fine
-    for k, v in (("probabilistic_ce_mode", "NoTTAConf"), ("use_symmetric_ce", True), ("optimize_instance_only", True)):
+    HotPathTrainer(m, r, default_config(use_symmetric_ce=True))             # SCELoss is built (round 2)
+    for k, v in (("probabilistic_ce_mode", "NoTTAConf"), ("optimize_instance_only", True)):
         with pytest.raises(NotImplementedError):
             HotPathTrainer(m, r, default_config(**{k: v}))

@@ -947,7 +947,8 @@ def test_psnr_parity_over_a_training_trajectory():
     print(f"PSNR after {steps} steps: oracle {p_cpu:.3f} dB, HIP {p_gpu:.3f} dB; worst |delta| along the trajectory {worst:.4f} dB")
 
 
-@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments"])
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
+                                     "g12e_training_steps_sce"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
@@ -966,6 +967,8 @@ def test_g12_reference_training_steps_on_gpu(fixture):
     r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
     cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
                          use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False, max_instances=E)
+    if "sce" in g and float(g["sce"][1]) != 0.0:          # fourth fixture: config.use_symmetric_ce (SCELoss, T:74-77)
+        cfg.use_symmetric_ce, cfg.ce_alpha, cfg.ce_beta = True, float(g["sce"][0]), float(g["sce"][1])
     tr = HotPathTrainer(m, r, cfg, class_weights=T(g["class_weights"]), current_epoch=int(g["epoch"]))
     rel_close(tr.current_lambda_dist_reg, g["lambda_dist"], 1e-6, what="dist-reg ramp")
     d = lambda a: (torch.from_numpy(a) if isinstance(a, np.ndarray) else a).to(DEV)

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import grad_close, rel_close
+from conftest import grad_close, rel_close, load_golden, T
 from test_gpu_parity import _import, build_model, scene, _run_forward_backward
 
 pytestmark = pytest.mark.gpu
@@ -304,3 +304,28 @@ def test_march_dist_loss_matches_pairwise_definition(monkeypatch):
     for k in [f"density_plane.{i}" for i in range(3)] + [f"density_line.{i}" for i in range(3)]:
         assert float(Pg[k].grad.abs().max()) > 0
         grad_close(grads[k].detach().cpu(), Pg[k].grad, what=f"dist-reg grad {k}", rtol=2e-3, scale_atol=1e-4, outlier_frac=1e-3, outlier_cap=1e-3)
+
+
+# ============================================================================ a19: SCELoss / get_semantic_weights callables
+def test_sce_loss_callable_golden_g18():
+    """cl.SCELoss(alpha, beta, w)(pred, soft targets) -> per-pixel loss, and its gradient, against the reference's own SCELoss
+    (golden G18: zero class weight, one-hot targets hitting the 1e-8 clamps, log-probability inputs); get_semantic_weights; and the
+    plain soft-target cross entropy (the reference's default loss_semantics) against torch on the device."""
+    import contrastive_lift_amd as cl
+    g = load_golden("g18_sce")
+    assert torch.equal(cl.get_semantic_weights(False, list(g["w.fg_idx"]), 7), T(g["w.plain"]))
+    assert torch.equal(cl.get_semantic_weights(True, list(g["w.fg_idx"]), 7), T(g["w.fg"]))
+    for tag in "abcd":
+        pred = T(g[f"{tag}.pred"]).to(DEV).requires_grad_(True)
+        a, b = (float(x) for x in g[f"{tag}.ab"])
+        w = T(g[f"{tag}.w"])
+        rows = cl.SCELoss(a, b, w)(pred, T(g[f"{tag}.p"]).to(DEV))
+        rel_close(rows, g[f"{tag}.rows"], 1e-4, atol=1e-5, what=f"SCELoss rows {tag}")
+        gr = torch.autograd.grad((rows * T(g[f"{tag}.conf"]).to(DEV)).mean(), pred)[0]
+        rel_close(gr, g[f"{tag}.grad"], 1e-3, atol=1e-7, what=f"SCELoss grad {tag}")
+        pred2 = T(g[f"{tag}.pred"]).to(DEV).requires_grad_(True)
+        ce = cl.SoftTargetCrossEntropy(w)(pred2, T(g[f"{tag}.p"]).to(DEV))
+        pr = T(g[f"{tag}.pred"]).requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(pr, T(g[f"{tag}.p"]), weight=w, reduction="none")
+        rel_close(ce, ref.detach(), 1e-4, atol=1e-5, what=f"soft-target CE rows {tag}")
+        rel_close(torch.autograd.grad(ce.sum(), pred2)[0], torch.autograd.grad(ref.sum(), pr)[0], 1e-3, atol=1e-6, what=f"soft-target CE grad {tag}")

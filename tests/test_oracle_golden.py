@@ -193,7 +193,8 @@ def test_g11_metrics_vs_reference():
         panoptic_quality(T(g["pq0.preds"]), T(g["pq0.target"]), {1, 2}, {0, 3}, allow_unknown_preds_category=False)
 
 
-@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments"])
+@pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
+                                     "g12e_training_steps_sce"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -208,7 +209,8 @@ def test_g12_three_reference_training_steps(fixture):
     P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=(mode == "slow_fast")), res, 2.5, 0.45)
     cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
     tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]),
-                    instance_loss_mode=mode, use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False)
+                    instance_loss_mode=mode, use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False,
+                    sce=(tuple(float(x) for x in g["sce"]) if "sce" in g and float(g["sce"][1]) != 0.0 else None))   # 4th fixture: SCELoss
     rel_close(tr.l_dist, g["lambda_dist"], 1e-6, what="dist-reg ramp")
     # optimizer layout of the reference (T:98-103): 7 main groups (4 grid groups at 20 lr, 3 net groups at lr) + 1 instance group
     og = g["opt_groups"]
@@ -249,3 +251,18 @@ def test_g13_postprocess_host_parts():
         got = create_instances_from_semantics(T(g[f"inst{j}"]), T(g[f"sem{j}"]), things)
         assert torch.equal(got, T(g[f"thing{j}"]))
     rel_close(distance_to_depth(T(g["K"]), T(g["dist"])), g["depth"], 1e-6, what="distance_to_depth")
+
+
+def test_g18_sce_loss_and_semantic_weights():
+    """oracle.losses.sce_rows / semantic_weights against the reference's SCELoss / get_semantic_weights (loss.py:29-59)."""
+    from oracle import losses as olosses
+    g = load_golden("g18_sce")
+    assert torch.equal(olosses.semantic_weights(False, g["w.fg_idx"], 7), T(g["w.plain"]))
+    assert torch.equal(olosses.semantic_weights(True, g["w.fg_idx"], 7), T(g["w.fg"]))
+    for tag in "abcd":
+        pred = T(g[f"{tag}.pred"]).requires_grad_(True)
+        a, b = (float(x) for x in g[f"{tag}.ab"])
+        rows = olosses.sce_rows(pred, T(g[f"{tag}.p"]), T(g[f"{tag}.w"]), a, b)
+        rel_close(rows, g[f"{tag}.rows"], 1e-5, atol=1e-6, what=f"sce rows {tag}")
+        gr = torch.autograd.grad((rows * T(g[f"{tag}.conf"])).mean(), pred)[0]
+        rel_close(gr, g[f"{tag}.grad"], 1e-4, atol=1e-8, what=f"sce grad {tag}")

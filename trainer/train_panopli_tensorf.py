@@ -77,10 +77,8 @@ def main(argv):
                              pe_sem=cfg.pe_sem, pe_ins=cfg.pe_ins, slow_fast_mode=slow_fast, use_proj=cfg.use_proj, device=dev)
     renderer = cl.TensoRFRenderer(scene.scene_bounds, [g, g, g], semantic_weight_mode=cfg.semantic_weight_mode,
                                   stop_semantic_grad=cfg.stop_semantic_grad).to(dev)
-    cw = torch.ones(total_classes)                                         # loss.py:29-33 get_semantic_weights + T:70
-    if getattr(cfg, "reweight_fg", False):
-        cw[list(scene.segmentation_data.fg_classes)] = 2
-    cw[0] = cfg.weight_class_0
+    cw = cl.get_semantic_weights(getattr(cfg, "reweight_fg", False), list(scene.segmentation_data.fg_classes), total_classes)   # T:69
+    cw[0] = cfg.weight_class_0                                             # T:70
     tr = HotPathTrainer(model, renderer, cfg, class_weights=cw, current_epoch=0)
     run_dir = Path("runs") / cfg.experiment
     if rank == 0:
