@@ -81,6 +81,82 @@ extern "C" int clift_density_points(const clift_vm_t* h_dens, const float* xn, i
     return clift_check_launch("clift_density_points");
 }
 
+// ============================================================================ alpha-mask bounding box (renderer.py:669-761)
+// The epoch-boundary shrink asks: which voxels of the (g0, g1, g2) lattice of the current box have alpha >= threshold after a 3^3
+// max-pool, and what is their index bounding box?  Pass 1 evaluates alpha on the lattice (point p_a = lo_a (1 - s) + hi_a s with
+// s = the caller's linspace value of that axis, normalised like renderer.py:633, density + softplus like tensoRF.py:114-125,
+// alpha = 1 - exp(-sigma step), R:752-754) -- 4 lanes per voxel as in k_density_points, fully coalesced.  Pass 2 pools, thresholds
+// and reduces to six integers (min / max lattice index per axis) with wave reductions and one atomic pair per wave and axis.
+__global__ __launch_bounds__(256) void k_alpha_lattice(VmP t, float3 lo, float3 hi, float3 inv_ext2, const float* __restrict__ s0,
+                                                        const float* __restrict__ s1, const float* __restrict__ s2, int g0, int g1, int g2,
+                                                        float shift, float step, float* __restrict__ alpha) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long v = gid >> 2, total = (long)g0 * g1 * g2;
+    const int q = (int)(gid & 3);
+    if (v >= total) return;
+    const int i2 = (int)(v % g2), i1 = (int)((v / g2) % g1), i0 = (int)(v / ((long)g1 * g2));
+    const float a = s0[i0], b = s1[i1], c = s2[i2];
+    const float p[3] = {lo.x * (1.f - a) + hi.x * a, lo.y * (1.f - b) + hi.y * b, lo.z * (1.f - c) + hi.z * c};
+    const float xn[3] = {(p[0] - lo.x) * inv_ext2.x - 1.f, (p[1] - lo.y) * inv_ext2.y - 1.f, (p[2] - lo.z) * inv_ext2.z - 1.f};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const VmTaps tp = vm_taps(t, i, xn);
+        for (int c4 = q * 4; c4 < t.comps; c4 += 16) acc += f4_hsum(f4_mul(vm_plane4(t, i, tp, c4), vm_line4(t, i, tp, c4)));
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (q == 0) {
+        const float x = acc + shift;
+        const float sigma = (x > 20.f) ? x : log1pf(expf(x));
+        alpha[v] = 1.f - expf(-sigma * step);
+    }
+}
+
+__global__ void k_box_init(int* box6) {
+    if (threadIdx.x < 3) box6[threadIdx.x] = 0x7fffffff;
+    else if (threadIdx.x < 6) box6[threadIdx.x] = -1;
+    else if (threadIdx.x == 6) box6[6] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_alpha_pool_box(const float* __restrict__ alpha, int g0, int g1, int g2, float thr, int* __restrict__ box6) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x, total = (long)g0 * g1 * g2;
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1}, cnt = 0;
+    if (v < total) {
+        const int i2 = (int)(v % g2), i1 = (int)((v / g2) % g1), i0 = (int)(v / ((long)g1 * g2));
+        float best = 0.f;                                       // values are clamped to [0, 1] first (R:672), so 0 is the pool's floor
+        for (int d0 = max(i0 - 1, 0); d0 <= min(i0 + 1, g0 - 1); ++d0)
+            for (int d1 = max(i1 - 1, 0); d1 <= min(i1 + 1, g1 - 1); ++d1)
+                for (int d2 = max(i2 - 1, 0); d2 <= min(i2 + 1, g2 - 1); ++d2)
+                    best = fmaxf(best, fminf(fmaxf(alpha[((long)d0 * g1 + d1) * g2 + d2], 0.f), 1.f));
+        if (best >= thr) { mn[0] = mx[0] = i0; mn[1] = mx[1] = i1; mn[2] = mx[2] = i2; cnt = 1; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int d = 32; d > 0; d >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], d)); mx[a] = max(mx[a], __shfl_xor(mx[a], d)); }
+    cnt = wave_sum_i(cnt);
+    if (lane_id() == 0 && cnt > 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(box6 + a, mn[a]); atomicMax(box6 + 3 + a, mx[a]); }
+        atomicAdd(box6 + 6, cnt);
+    }
+}
+
+extern "C" int clift_alpha_bbox(const clift_vm_t* h_dens, const float* h_lo3, const float* h_hi3, const float* h_inv_ext2, const float* s0,
+                                const float* s1, const float* s2, int g0, int g1, int g2, float shift, float step, float threshold,
+                                float* alpha_work, int* box7, clift_stream_t s) {
+    CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_alpha_bbox: comps must be a multiple of 4");
+    CLIFT_REQUIRE(g0 >= 1 && g1 >= 1 && g2 >= 1, "clift_alpha_bbox: lattice dimensions must be positive");
+    const long total = (long)g0 * g1 * g2;
+    hipStream_t st = as_stream(s);
+    k_box_init<<<1, 64, 0, st>>>(box7);
+    k_alpha_lattice<<<cdiv(total * 4, 256), 256, 0, st>>>(to_dev(h_dens), make_float3(h_lo3[0], h_lo3[1], h_lo3[2]), make_float3(h_hi3[0], h_hi3[1], h_hi3[2]),
+                                                           make_float3(h_inv_ext2[0], h_inv_ext2[1], h_inv_ext2[2]), s0, s1, s2, g0, g1, g2, shift, step,
+                                                           alpha_work);
+    k_alpha_pool_box<<<cdiv(total, 256), 256, 0, st>>>(alpha_work, g0, g1, g2, threshold, box7);
+    return clift_check_launch("clift_alpha_bbox");
+}
+
 // ============================================================================ density backward
 // Persistent blocks; `comps` lanes form a GROUP with ONE CHANNEL PER LANE (comps = 4..64, power of two; 16 in the
 // reference configs => 4 groups per wave), so every atomic instruction covers whole 64-byte texels.

@@ -193,37 +193,59 @@ class TensoRFRenderer(nn.Module):
         return alpha, dense_xyz
 
     @torch.no_grad()
+    def occupied_index_box(self, tensorf):
+        """Index bounding box of the lattice voxels whose 3^3-max-pooled alpha reaches ``alpha_mask_threshold`` (the first half of
+        renderer.py:669-680), computed by ONE library call (clift_alpha_bbox: lattice alpha, pool, threshold, min/max reduction
+        on the device).  Returns (lo_idx, hi_idx, n_voxels) as Python ints per axis, or None when no voxel qualifies."""
+        import ctypes as C
+        from . import _lib
+        dev = self.bbox_aabb.device
+        g = [int(x) for x in self.grid_dim.tolist()]
+        ticks = [torch.linspace(0, 1, n).to(dev) for n in g]                 # lattice parameters per axis, as R:718-722
+        views = tensorf.named_views()
+        vd = engine.vm_struct(views, "density", engine.grid_res(views))
+        lo, hi = self.bbox_aabb_host
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        alpha = torch.empty(g[0] * g[1] * g[2], dtype=torch.float32, device=dev)
+        box = torch.empty(7, dtype=torch.int32, device=dev)
+        _lib.call("clift_alpha_bbox", C.byref(vd), f3(lo), f3(hi), f3(self.inv_box_extent_host), _lib.ptr(ticks[0]), _lib.ptr(ticks[1]),
+                  _lib.ptr(ticks[2]), g[0], g[1], g[2], float(tensorf.splus_density_shift), float(self.step_size_host),
+                  float(self.alpha_mask_threshold), _lib.ptr(alpha), _lib.ptr(box), _lib.stream())
+        box = box.tolist()
+        if box[6] == 0:
+            return None
+        return box[0:3], box[3:6], box[6], ticks
+
+    @torch.no_grad()
     def update_bbox_aabb_and_shrink(self, tensorf, fractional_lenience=1.0):
-        """renderer.py:668-715: dense alpha -> 3^3 max-pool -> threshold -> tight box -> crop the grids."""
-        import torch.nn.functional as F
-        alpha, dense_xyz = self.get_dense_alpha(tensorf)
-        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
-        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(self.grid_dim.tolist()[::-1])
-        alpha = (alpha >= self.alpha_mask_threshold).to(torch.float32)
-        valid_xyz = dense_xyz[alpha > 0.5]
-        if valid_xyz.shape[0] == 0:
+        """renderer.py:668-715.  The device finds the occupied index box; what is left for the host is three-vector arithmetic:
+        lattice coordinates of the two corners, the lenience scaling about the centre, clipping to the current (and the parent's)
+        box, and rounding the new corners to voxel indices for the crop."""
+        found = self.occupied_index_box(tensorf)
+        if found is None:
             return False
-        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
-        extent = xyz_max - xyz_min
-        position = (xyz_min + xyz_max) / 2
-        xyz_min = torch.maximum(self.bbox_aabb[0], position - (extent * fractional_lenience) / 2)
-        xyz_max = torch.minimum(self.bbox_aabb[1], position + (extent * fractional_lenience) / 2)
+        lo_idx, hi_idx, _, ticks = found
+        box_lo, box_hi = self.bbox_aabb[0], self.bbox_aabb[1]
+
+        def lattice(idx):                 # coordinates of a lattice node: the same two-product blend that built the lattice (R:723)
+            t = torch.stack([ticks[a][idx[a]] for a in range(3)])
+            return box_lo * (1 - t) + box_hi * t
+        corner_lo, corner_hi = lattice(lo_idx), lattice(hi_idx)       # monotone per axis: min / max coordinate = node at min / max index
+        centre, half = (corner_lo + corner_hi) / 2, ((corner_hi - corner_lo) * fractional_lenience) / 2
+        new_lo, new_hi = torch.maximum(box_lo, centre - half), torch.minimum(box_hi, centre + half)
         if self.parent_renderer_ref is not None:
-            xyz_min = torch.maximum(self.parent_renderer_ref.bbox_aabb[0], xyz_min)
-            xyz_max = torch.minimum(self.parent_renderer_ref.bbox_aabb[1], xyz_max)
-        new_bbox = torch.stack((xyz_min, xyz_max))
-        t_l = (xyz_min - self.bbox_aabb[0]) / self.units
-        b_r = (xyz_max - self.bbox_aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.grid_dim]).amin(0)
-        new_size = b_r - t_l
-        if bool((new_size > 0).all()):
-            tensorf.shrink(t_l.tolist(), b_r.tolist())
-            self.bbox_aabb.data = new_bbox
-            self.update_step_size(tuple(int(x) for x in new_size.tolist()))
-            return True
-        return False
+            new_lo = torch.maximum(self.parent_renderer_ref.bbox_aabb[0], new_lo)
+            new_hi = torch.minimum(self.parent_renderer_ref.bbox_aabb[1], new_hi)
+        # voxel range to keep: first = round(offset / unit), one past last = min(round(offset / unit) + 1, grid size)
+        first = torch.round((new_lo - box_lo) / self.units).long()
+        end = torch.minimum(torch.round((new_hi - box_lo) / self.units).long() + 1, self.grid_dim)
+        kept = end - first
+        if not bool((kept > 0).all()):
+            return False
+        tensorf.shrink(first.tolist(), end.tolist())
+        self.bbox_aabb.data = torch.stack((new_lo, new_hi))
+        self.update_step_size(tuple(int(x) for x in kept.tolist()))
+        return True
 
     @staticmethod
     def raw_to_alpha(sigma, dist):

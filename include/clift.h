@@ -83,6 +83,15 @@ int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const 
  * coordinates; out (n). */
 int clift_density_points(const clift_vm_t* h_dens, const float* xn, int ldx, long n, float shift, int activation,
                          float* out, clift_stream_t s);
+/* Alpha-mask bounding box of the epoch-boundary shrink (renderer.py:669-680,717-729,752-754): alpha = 1 - exp(-softplus(density +
+ * shift) * step) on the (g0,g1,g2) lattice of the box [h_lo3, h_hi3] (lattice coordinate of axis a at index i =
+ * lo_a (1 - s_a[i]) + hi_a s_a[i]; s0/s1/s2 are DEVICE arrays holding the caller's linspace(0,1,g_a)), clamp to [0,1], 3^3 max-pool
+ * (stride 1, padding 1), >= threshold.  alpha_work: g0*g1*g2 floats of scratch (left holding the un-pooled alpha, x-major);
+ * box7 (device, 7 ints) = [min index per axis (3), max index per axis (3), number of voxels above the threshold]; min = INT_MAX
+ * and max = -1 when none is. */
+int clift_alpha_bbox(const clift_vm_t* h_dens, const float* h_lo3, const float* h_hi3, const float* h_inv_ext2, const float* s0,
+                     const float* s1, const float* s2, int g0, int g1, int g2, float shift, float step, float threshold,
+                     float* alpha_work, int* box7, clift_stream_t s);
 /* Plane x line products at arbitrary points, F (n, 3*comps) (compute_appearance_feature before the basis, :127-134). */
 int clift_vm_products_points(const clift_vm_t* h_vm, const float* xn, int ldx, long n, float* F, clift_stream_t s);
 /* Appearance-MLP input assembly from explicit view directions (render_appearance_mlp(viewdirs, features), :400-408). */

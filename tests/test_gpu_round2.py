@@ -329,3 +329,27 @@ def test_sce_loss_callable_golden_g18():
         ref = torch.nn.functional.cross_entropy(pr, T(g[f"{tag}.p"]), weight=w, reduction="none")
         rel_close(ce, ref.detach(), 1e-4, atol=1e-5, what=f"soft-target CE rows {tag}")
         rel_close(torch.autograd.grad(ce.sum(), pred2)[0], torch.autograd.grad(ref.sum(), pr)[0], 1e-3, atol=1e-6, what=f"soft-target CE grad {tag}")
+
+
+# ============================================================================ 8f-1: alpha-mask bounding box on the device
+def test_alpha_bbox_kernel_vs_torch_pooling():
+    """clift_alpha_bbox (lattice alpha + 3^3 max-pool + threshold + index bounding box in one library call) against the same
+    steps done with torch ops on the dense alpha of ``get_dense_alpha`` (clift_density_points), on an anisotropic lattice and for
+    three thresholds incl. one that no voxel reaches."""
+    import torch.nn.functional as F
+    cl, op, orender, ofld, olosses, orays = _import()
+    res = (21, 34, 27)
+    P = op.add_blob(op.make_params(5, res, 2, 3), res, amplitude=2.5, sigma_g=0.3)
+    m = build_model(cl, P, res, 2, 3, -3.0)
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    for thr in (0.0075, 0.3, 2.0):
+        r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax", alpha_mask_threshold=thr).to(DEV)
+        alpha, _ = r.get_dense_alpha(m)
+        pooled = F.max_pool3d(alpha.clamp(0, 1)[None, None], kernel_size=3, padding=1, stride=1)[0, 0]
+        idx = torch.nonzero(pooled >= thr)
+        got = r.occupied_index_box(m)
+        if idx.shape[0] == 0:
+            assert got is None
+            continue
+        lo, hi, n, _ = got
+        assert lo == idx.amin(0).tolist() and hi == idx.amax(0).tolist() and n == idx.shape[0], (thr, lo, hi, n)
