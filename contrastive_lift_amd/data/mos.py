@@ -93,24 +93,40 @@ class SceneTables:
             c2n = s2n @ torch.from_numpy(np.asarray(pose)).float()
             yield f"{idx:04d}", generate_ray_table(H, W, self.intrinsics[0], c2n, near=0.01, device=self.device)
 
-    def build_train_tables(self):
-        """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers)."""
+    def build_train_tables(self, instance_images=True):
+        """All training pixels as HBM-resident tables (reference keeps them on the host and feeds 8 loader workers).
+        ``instance_images``: also cut the per-image instance ray sets from these tables (the reference builds those from a
+        SEPARATE dataset object at a fixed (128, 128) size, dataset/__init__.py:57,66 -- see ``build_instance_tables``)."""
         rays, tg = [], []
         for i in self.train_indices:
             rays.append(self.rays_for(i))
             tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items()})
         self.tables = dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]})
+        if instance_images:
+            self._cut_instance_images(self.tables)
+        return self.tables
+
+    def _cut_instance_images(self, tables):
         hw = self.image_dim[0] * self.image_dim[1]
         self.instance_images = []
         for j in range(len(self.train_indices)):
             sl = slice(j * hw, (j + 1) * hw)
-            m = self.tables["instances"][sl] != 0
+            m = tables["instances"][sl] != 0
             if bool(m.any()):
                 # many_object_scenes.py:242-258 / panopli.py:211-238: pixels with a label, confidences of room-masked pixels forced to 0
-                conf = self.tables["confidences"][sl] * self.tables["mask"][sl].to(torch.float32)
-                self.instance_images.append(dict(rays=self.tables["rays"][sl][m], instances=self.tables["instances"][sl][m],
-                                                 confidences=conf[m]))
-        return self.tables
+                conf = tables["confidences"][sl] * tables["mask"][sl].to(torch.float32)
+                self.instance_images.append(dict(rays=tables["rays"][sl][m], instances=tables["instances"][sl][m], confidences=conf[m]))
+
+    def build_instance_tables(self):
+        """Inconsistent*SingleDataset (many_object_scenes.py:209-286, panopli.py:200-238): one ray set per training frame that has
+        labelled pixels.  The reference constructs it at a FIXED (128, 128) image size whatever ``image_dim`` is
+        (dataset/__init__.py:57,66): call this on a scene constructed with image_dim=(128, 128)."""
+        rays, tg = [], []
+        for i in self.train_indices:
+            rays.append(self.rays_for(i))
+            tg.append({k: v.to(self.device) for k, v in self.load_targets(i).items() if k in ("instances", "confidences", "mask")})
+        self._cut_instance_images(dict(rays=torch.cat(rays, 0), **{k: torch.cat([t[k] for t in tg], 0) for k in tg[0]}))
+        return self.instance_images
 
     def build_segment_tables(self):
         """Segment*Dataset (many_object_scenes.py:334-395, panopli.py:372-432): for every training frame and every non-zero id

@@ -257,6 +257,33 @@ class HotPathTrainer:
         sd["loss_semantics.weight"] = self.class_weights.detach().clone()
         return sd
 
-    def save_checkpoint(self, path, global_step=0):
+    def save_checkpoint(self, path, global_step=0, epoch_complete=True):
+        """Lightning-layout checkpoint (keys the reference's consumers read: state_dict, epoch) plus what an exact resume
+        needs: both Adam states under Lightning's ``optimizer_states`` key and a ``clift`` record (was the epoch finished; epoch of
+        the last optimizer rebuild, from which the LR milestones count)."""
         torch.save({"state_dict": self.state_dict_lightning(), "epoch": self.current_epoch, "global_step": global_step,
-                    "pytorch-lightning_version": "2.0.4"}, path)
+                    "pytorch-lightning_version": "2.0.4",
+                    "optimizer_states": [self.opt_main.state_dict(), self.opt_inst.state_dict()],
+                    "clift": {"epoch_complete": bool(epoch_complete), "last_setup_epoch": int(getattr(self, "last_setup_epoch", 0)),
+                              "rng": self._rng_state()}}, path)
+
+    def _rng_state(self):
+        """Generators the step draws from: torch's CPU generator (white-background coin, R:164), the device's default generator
+        (jitter, ray subsampling) and the CLI's pixel-batch generator when it registered one (``self.pixel_generator``)."""
+        st = {"cpu": torch.get_rng_state()}
+        if self.device.type == "cuda":
+            st["cuda"] = torch.cuda.get_rng_state(self.device)
+        g = getattr(self, "pixel_generator", None)
+        if g is not None:
+            st["pixel"] = g.get_state()
+        return st
+
+    def load_rng_state(self, st):
+        if not st:
+            return
+        torch.set_rng_state(st["cpu"])
+        if "cuda" in st and self.device.type == "cuda":
+            torch.cuda.set_rng_state(st["cuda"], self.device)
+        g = getattr(self, "pixel_generator", None)
+        if g is not None and "pixel" in st:
+            g.set_state(st["pixel"])

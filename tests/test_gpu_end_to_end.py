@@ -126,3 +126,54 @@ def test_train_cli_on_panopli_layout(tmp_path, monkeypatch):
     acc = float((sem == gt)[valid].mean())
     print("PanopLi-layout held-out semantic accuracy on labelled pixels", acc, "of", int(valid.sum()))
     assert acc > 0.6, acc
+
+
+def test_resume_continues_a_run(tmp_path, monkeypatch):
+    """config.resume=<ckpt> (reference: trainer.fit(ckpt_path=...), T:461-470): weights, renderer box / grid, Adam moments and step
+    counts, epoch, global step and the generators come back from the checkpoint; the run continues in ITS directory from the next
+    epoch and does not restart.  A 2-epoch run + 1 resumed epoch lands where the uninterrupted 3-epoch run does (fp32 atomics make
+    the gradient sums order-dependent, so 'where' is PSNR within 0.5 dB and the optimizer step counts exactly)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=24, size=48, trajectory_frames=2)
+    monkeypatch.chdir(tmp_path)
+    train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli_r")
+    common = ["+experiment=contrastive_lift_MOS", f"dataset_root={scene_dir}", "image_dim=48", "min_grid_dim=24", "max_grid_dim=40",
+              "steps_per_epoch=80", "batch_size=1024", "chunk=0", "max_depth=3", "seed=5", "max_rays_instances=256",
+              "late_semantic_optimization=1", "instance_optimization_epoch=1", "save_every_n_train_steps=1000000"]
+    monkeypatch.setenv("experiment", "straight")
+    run_a = train.main(common + ["max_epoch=3"])
+    monkeypatch.setenv("experiment", "interrupted")
+    run_b = train.main(common + ["max_epoch=2"])
+    ck_b = sorted(os.listdir(os.path.join(run_b, "checkpoints")))
+    assert ck_b[-1].startswith("epoch=1-")
+    before = torch.load(os.path.join(run_b, "checkpoints", ck_b[-1]), map_location="cpu", weights_only=False)
+    assert before["clift"]["epoch_complete"] and before["global_step"] == 160 and before["optimizer_states"][0]["t"]["grids"] > 0
+    monkeypatch.delenv("experiment")
+    run_c = train.main(common + ["max_epoch=3", f"resume={os.path.join(run_b, 'checkpoints', ck_b[-1])}"])
+    assert os.path.basename(run_c) == "interrupted"                              # continues in the run's own directory
+    ck_c = sorted(os.listdir(os.path.join(run_c, "checkpoints")))
+    assert ck_c[-1].startswith("epoch=2-step=240") and set(ck_b) <= set(ck_c)     # earlier checkpoints untouched, steps continue at 160
+    a = torch.load(os.path.join(run_a, "checkpoints", sorted(os.listdir(os.path.join(run_a, "checkpoints")))[-1]), map_location="cpu", weights_only=False)
+    c = torch.load(os.path.join(run_c, "checkpoints", ck_c[-1]), map_location="cpu", weights_only=False)
+    assert a["epoch"] == c["epoch"] == 2 and a["global_step"] == c["global_step"] == 240
+    assert a["optimizer_states"][0]["t"] == c["optimizer_states"][0]["t"] and a["optimizer_states"][1]["t"] == c["optimizer_states"][1]["t"]
+    assert a["state_dict"]["renderer.grid_dim"].tolist() == c["state_dict"]["renderer.grid_dim"].tolist()
+    assert torch.allclose(a["state_dict"]["renderer.bbox_aabb"], c["state_dict"]["renderer.bbox_aabb"], atol=0.1)
+    # same fit quality on a training view
+    from contrastive_lift_amd.config import load_run_config
+    from contrastive_lift_amd.data import MOSScene
+    from contrastive_lift_amd import inference as inf
+    rp = _load(os.path.join(REPO, "inference", "render_panopli.py"), "clift_render_cli_r")
+    scene = MOSScene(scene_dir, "test", (48, 48), 3, subsample_frames=1, device="cuda")
+    ps = []
+    for run, ck in ((run_a, a), (run_c, c)):
+        cfg = load_run_config(os.path.join(run, "config.yaml"))
+        cfg.resume = os.path.join(run, "checkpoints", sorted(os.listdir(os.path.join(run, "checkpoints")))[-1])
+        cfg.image_dim = [48, 48]
+        model, renderer, _ = rp.build_from_checkpoint(cfg, scene, torch.device("cuda"))
+        i = scene.val_indices[0]
+        rgb, *_ = inf.render_rays(model, renderer, scene.rays_for(i), 4096, False)
+        ps.append(float(inf.psnr(rgb, scene.load_targets(i)["rgbs"].cuda())))
+    print("PSNR straight / resumed:", ps)
+    assert abs(ps[0] - ps[1]) < 0.5, ps

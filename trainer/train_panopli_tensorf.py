@@ -37,6 +37,36 @@ def experiment_name(config):
     return f"{datetime.datetime.now().strftime('%m%d%H%M')}_MOS_{Path(config.dataset_root).stem}_{config.experiment}"
 
 
+def resume_from(path, cfg, tr, model, renderer, dev):
+    """Continue a run from one of its checkpoints (reference: trainer.fit(ckpt_path=config.resume) + on_load_checkpoint, T:461-470).
+    Restores the grids at the checkpoint's resolution (upsample to ``renderer.grid_dim`` first, like RP:91-98 / T:463-466), every
+    weight, the renderer buffers, both Adam states (moments + per-range step counts), epoch and global step.  Returns
+    (first epoch to run, global step, whether that epoch was already in progress, epoch of the last optimizer rebuild)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["state_dict"]
+    grid = [int(x) for x in sd["renderer.grid_dim"].tolist()]
+    model.upsample_volume_grid(grid)                                      # shapes first; the values are overwritten below
+    missing, unexpected = model.load_state_dict({k[len("model."):]: v.to(dev) for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    renderer.bbox_aabb.data = sd["renderer.bbox_aabb"].to(dev)
+    renderer.update_step_size(grid)
+    epoch = int(ckpt["epoch"])
+    extra = ckpt.get("clift", {})
+    complete = bool(extra.get("epoch_complete", True))
+    first = epoch + 1 if complete else epoch
+    ups = [int(e) for e in cfg.grid_upscale_epochs]
+    done_ups = [e for e in ups if e < first or (e == first and not complete)]
+    if done_ups:
+        cfg.weight_decay = 0                                               # T:454,467
+    tr.config = cfg
+    tr.setup_optimizers()                                                  # buffers in the (possibly resized) arena layout
+    if "optimizer_states" in ckpt and len(ckpt["optimizer_states"]) == 2 and "m" in ckpt["optimizer_states"][0]:
+        if ckpt["optimizer_states"][0]["m"].numel() == tr.opt_main.m.numel():
+            tr.opt_main.load_state_dict(ckpt["optimizer_states"][0])
+            tr.opt_inst.load_state_dict(ckpt["optimizer_states"][1])
+    tr.load_rng_state(extra.get("rng"))
+    return first, int(ckpt.get("global_step", 0)), (not complete), int(extra.get("last_setup_epoch", max(done_ups) if done_ups else 0))
+
+
 def main(argv):
     config_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config")
     for a in list(argv):
@@ -61,7 +91,10 @@ def main(argv):
     cfg.instance_optimization_epoch = cfg.instance_optimization_epoch + cfg.late_semantic_optimization     # T:46
     cfg.segment_optimization_epoch = cfg.segment_optimization_epoch + cfg.late_semantic_optimization       # T:47
     scene = get_scene(cfg, "train", dev)
-    scene.build_train_tables()
+    scene.build_train_tables(instance_images=False)
+    # the per-image instance ray sets come from their own dataset object, always at (128, 128) (dataset/__init__.py:57,66)
+    inst_scene = get_scene(cfg, "train", dev, image_dim=(128, 128))
+    inst_scene.build_instance_tables()
     seg_scene = None
     if cfg.segment_grouping_mode != "none" and int(cfg.segment_optimization_epoch) < int(cfg.max_epoch):
         seg_scene = get_scene(cfg, "train", dev, image_dim=(128, 128))         # get_segment_dataset: always (128, 128) (dataset/__init__.py:70,78)
@@ -86,29 +119,44 @@ def main(argv):
         save_config(cfg, str(run_dir / "config.yaml"))
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed * 9973 + rank)                                    # every rank draws its own pixels (DistributedSampler role)
-    per_rank = max(1, int(cfg.batch_size) // world)
-    steps_per_epoch = int(cfg.get("steps_per_epoch") or max(1, scene.tables["rays"].shape[0] // int(cfg.batch_size)))
+    tr.pixel_generator = gen                                               # (its state travels in the checkpoint)
+    # Lightning DDP (trainer/__init__.py:97): every rank takes a FULL batch_size batch and the DistributedSampler divides the steps
+    # of an epoch by the world size -- the LR / EMA / epoch schedules of the configs are tuned for that
+    per_rank = int(cfg.batch_size)
+    steps_per_epoch = int(cfg.get("steps_per_epoch") or max(1, scene.tables["rays"].shape[0] // (int(cfg.batch_size) * world)))
     voxels = torch.round(torch.exp(torch.linspace(np.log(cfg.min_grid_dim ** 3), np.log(cfg.max_grid_dim ** 3),
                                                   len(cfg.grid_upscale_epochs) + 1))).long().tolist()[1:]           # T:451
-    gstep = 0
-    for epoch in range(int(cfg.max_epoch)):
+    gstep, start_epoch, resumed_mid_epoch, last_setup_epoch = 0, 0, False, 0
+    if cfg.get("resume"):
+        start_epoch, gstep, resumed_mid_epoch, last_setup_epoch = resume_from(str(cfg.resume), cfg, tr, model, renderer, dev)
+        if rank == 0:
+            print(f"resumed {cfg.resume}: continuing at epoch {start_epoch} (global step {gstep}), grid {renderer.grid_dim.tolist()}", flush=True)
+    for epoch in range(start_epoch, int(cfg.max_epoch)):
         tr.current_epoch = epoch
         tr.on_train_epoch_start()
-        if epoch in list(cfg.bbox_aabb_reset_epochs):
+        # a checkpoint written in the middle of an epoch already holds that epoch's shrunk / upsampled grids
+        maintenance = not (resumed_mid_epoch and epoch == start_epoch)
+        if maintenance and epoch in list(cfg.bbox_aabb_reset_epochs):
             renderer.update_bbox_aabb_and_shrink(model)
-            tr.setup_optimizers()
-        if epoch in list(cfg.grid_upscale_epochs):
+            tr.setup_optimizers()                                          # the arena was re-packed: moments follow the new layout
+        if maintenance and epoch in list(cfg.grid_upscale_epochs):
             target = renderer.get_target_resolution(voxels[list(cfg.grid_upscale_epochs).index(epoch)])
             cfg.weight_decay = 0
             model.upsample_volume_grid(target)
             renderer.update_step_size(target)
             tr.setup_optimizers()
-        lr_scale = float(cfg.decay_gamma) ** sum(1 for m in cfg.decay_step if epoch >= m)                           # MultiStepLR, stepped per epoch
+            last_setup_epoch = epoch                                       # T:456 setup_optimizers: fresh MultiStepLR schedulers as well
+        # MultiStepLR(milestones=decay_step) is stepped once per epoch and is RE-CREATED by setup_optimizers at every grid upscale, so
+        # its milestones count epochs since the last rebuild (with the template's decay_step [9, 10] and the last upscale at epoch 4 a
+        # 10-epoch run never decays)
+        lr_scale = float(cfg.decay_gamma) ** sum(1 for m in cfg.decay_step if epoch - last_setup_epoch >= m)
         tr.opt_main.lr_scale = tr.opt_inst.lr_scale = lr_scale
+        tr.last_setup_epoch = last_setup_epoch
+        order = torch.randperm(max(1, len(inst_scene.instance_images)), generator=torch.Generator().manual_seed(seed * 31 + epoch)).tolist()   # DataLoader(shuffle=True), T:436
         for it in range(steps_per_epoch):
             batch = {0: scene.pixel_batch(per_rank, gen)}
-            if epoch >= cfg.instance_optimization_epoch and scene.instance_images:
-                batch[1] = scene.instance_batch(int(cfg.max_rays_instances), gstep * world + rank)
+            if epoch >= cfg.instance_optimization_epoch and inst_scene.instance_images:
+                batch[1] = inst_scene.instance_batch(int(cfg.max_rays_instances), order[(it * world + rank) % len(order)])
             if seg_scene is not None and epoch >= cfg.segment_optimization_epoch:                                   # T:458-459
                 sb = seg_scene.segment_batch(int(cfg.batch_size_segments), int(cfg.max_rays_segments), gstep * world + rank)
                 if sb is not None:
@@ -116,7 +164,7 @@ def main(argv):
             tr.training_step(batch)
             gstep += 1
             if rank == 0 and gstep % int(cfg.save_every_n_train_steps) == 0:
-                tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep)
+                tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep, epoch_complete=False)
             if rank == 0 and (it % 50 == 0 or it == steps_per_epoch - 1):
                 l = tr.losses.tolist()
                 print(f"epoch {epoch} it {it}/{steps_per_epoch} loss_rgb {l[0]:.5f} (psnr {-10 * math.log10(max(l[0], 1e-12)):.2f}) "
@@ -124,7 +172,7 @@ def main(argv):
                       + (f" segment {float(tr.loss_segment[0]):.4f}" if 2 in batch else "")
                       + f" S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
         if rank == 0:
-            tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep)
+            tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep, epoch_complete=True)
             from contrastive_lift_amd.inference import render_rays
             ps = []
             for i in val.val_indices[:4]:
