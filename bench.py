@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--inference-probe", action="store_true",
                     help="also report frame-render throughput and the lean main-pass time (both change the launch mix of the dominant "
                          "kernel: keep them out of profiled runs)")
+    ap.add_argument("--global-rays", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3]: 8192 rays per step over the job): rays per GPU = global / world, "
+                         "instance rays stay per-GPU (one instance image per rank, as the reference's DDP)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and frame-render extras measured after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -65,6 +69,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    if a.global_rays:
+        a.rays = max(1, a.global_rays // world)
     import contrastive_lift_amd as cl
     from contrastive_lift_amd import engine, synthetic
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
@@ -140,7 +146,7 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        roof = roofline(rec, rec_all, a.steps, engine, a.dtype)
+        roof = roofline(rec, rec_all, a.steps, engine, a.dtype, ms_step)
     if rank == 0 and world == 1:
         # ---- per-pass split and sample statistics (outside the timed region)
         def timed(fn, n=n_batches):          # cycles through the same batches as the timed loop
@@ -158,15 +164,20 @@ def main():
         extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
                      main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                      f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
-        if a.inference_probe:       # opt-in probes: they change the launch mix of the dominant kernel, so they stay out of profiled runs
+        extra["active_samples_per_s_main_pass"] = M / t_main            # cost follows the ACTIVE samples; comparable across scenes
+        if a.inference_probe:       # opt-in probe: changes the launch mix of the dominant kernel, so it stays out of profiled runs
             t_lean = timed(lambda b: tr.main_pass(b[0], lean=True))            # main pass without the discarded instance heads
             extra["lean_main_pass_ms"] = round(t_lean * 1e3, 3)
+        if not a.no_extras and a.dtype == "fp32":
+            # BASELINE configs[2] (bf16 MLP operands) and configs[4] (frame render) on the same scene, AFTER the timed fp32 region, so
+            # that the driver-run record carries them: same step definition, 10 steps after 3 warm-up steps / one 262144-ray tile
             extra.update(inference_probe(cl, model, renderer, pool))
+            extra.update(bf16_probe(a, dev, batches, S))
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
-                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": ("strong" if a.global_rays else "weak"),
                 "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32 (fp32-faithful 6-product bf16 split on the matrix cores)"}[a.dtype],
                 "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
@@ -181,6 +192,29 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
+    """The same training_step in bf16 mode (mlp_dtype "bf16": bf16 MLP operands, bf16-stored hidden activations, fp32 accumulate;
+    everything else fp32) on a fresh copy of the scene."""
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        model, renderer, _ = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+        tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0,
+                                                            mlp_dtype="bf16"), current_epoch=4)
+        for i in range(warmup):
+            tr.training_step(batches[i % len(batches)], lean=a.lean)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(steps):
+            tr.training_step(batches[i % len(batches)], lean=a.lean)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+    finally:
+        engine.set_mlp_precision(prev)
+    return dict(bf16_ms_per_step=round(dt * 1e3, 3), bf16_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt)
 
 
 def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
@@ -204,7 +238,18 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
                 inference_samples_per_ray=S, inference_probe=f"{rays.shape[0]} rays, chunk {chunk}, fp32 outputs rgb/sem/inst/dist")
 
 
-def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
+def measured_traffic_ratio():
+    """HBM bytes of the dominant kernel from counters, as a ratio to its algorithmic bytes: profiles/r02_pmc_k_layer_f32.json holds
+    the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-byte-per-lane streaming reads on gfx950) over this very command and over the torch-free single-kernel harness."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_pmc_k_layer_f32.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
     """``rec`` = the (kind, M, N, K, start event, end event) records of every clift_gemm launch of the ``nb`` timed steps.  The
     dominant kernel by time is k_layer_f32<false> (csrc/layer_f32.hip) = the 256x256 forward layers of the semantic / fast /
     slow instance MLPs as a persistent kernel (rocprofv3 lists it under exactly that name, profiles/r01_v12_*): achieved = its
@@ -236,19 +281,29 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32"):
                 "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
                              "gflop_per_step": tot_f / 1e9 / nb,
                              "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
-    return {"bound": "mfma", "kernel": "k_layer_f32<false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; 256x256 forward MLP layers)",
-            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-            # HBM bytes per (average) launch of the dominant kernel = its algorithmic bytes: by construction every activation row is
-            # fetched exactly once (one LDS-DMA by the one block that owns it), every output row written once, and the 256 KB weight
-            # matrix is read once per block from L2.  The rocprofv3 --pmc passes of the end of the round did not complete on the pool (they
-            # timed out with the tiled kernels as well, profiles/r01_gemm_pmc_notes.txt); the tiled kernel measured 541 MB vs 543 MB algorithmic.
-            "traffic": (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0,
-            "traffic_unit": "bytes/launch, algorithmic (A read once + C written once = 8 B per output element, + 256 KB weights): exact by construction "
-                            "for the persistent kernel; PMC re-measurement pending (profiles/r01_gemm_pmc_notes.txt)",
-            "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
-            "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
-                         "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
-                         "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
+    alg_bytes = (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
+    pmc = measured_traffic_ratio()
+    out = {"bound": "mfma", "kernel": "k_layer_f32<false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; 256x256 forward MLP layers)",
+           "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+           # HBM bytes per (average) launch of the dominant kernel: algorithmic bytes of THIS run's average launch (A read once + C
+           # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on
+           # the same command (profiles/r02_pmc_k_layer_f32.json); null if that record is missing
+           "traffic": (alg_bytes * pmc["bench_ratio"]) if pmc else None,
+           "traffic_unit": "bytes/launch (average launch of this run)",
+           "traffic_algorithmic": alg_bytes,
+           "traffic_over_algorithmic": pmc["bench_ratio"] if pmc else None,
+           "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE x2, gfx950 correction of MI355X_MICROARCH.md) "
+                              "over `python bench.py --steps 3 --warmup 1`: profiles/r02_pmc_k_layer_f32.json") if pmc else None,
+           "mfma_busy_frac_counters": pmc.get("mfma_busy_frac") if pmc else None,
+           "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
+           "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
+                        "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
+                        "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
+    if ms_step:
+        # whole-step fraction of the fp32-MFMA roof: every matrix-core FLOP of a step / the step's wall time / peak
+        out["step_gflop"] = tot_f / 1e9 / nb
+        out["step_frac"] = (tot_f / nb) / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    return out
 
 
 def usable_cores():
@@ -297,7 +352,10 @@ def cpu_baseline(model, renderer, batch, a, S):
     return {"value": (a.rays + a.inst_rays) * S / med, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "sample": f"{len(ts)} full-size training_step(s) after 1 warm-up ({a.rays}+{a.inst_rays} rays x S={S}, chunk 2048, "
                       f"torch {torch.__version__} CPU, {cores} threads), median {med:.2f} s/step",
-            "s_per_step": med}
+            "s_per_step": med,
+            "port_vs_reference": "build container, 8 threads, same step: oracle port 6.28 s, imported reference trainer 5.22 s (port / reference time "
+                                 "= 1.20; tools/cpu_port_vs_reference.py, profiles/r02_cpu_port_vs_reference.json) -- the reference's own CPU "
+                                 "path is ~1.2x FASTER than this port number"}
 
 
 if __name__ == "__main__":
