@@ -16,15 +16,15 @@ def _round_up(x, m):
 class Slot:
     __slots__ = ("name", "shape", "kind", "offset", "numel", "pitch", "group")
 
-    def __init__(self, name, shape, kind, group):
+    def __init__(self, name, shape, kind, group, pitch_align=4):
         self.name, self.shape, self.kind, self.group = name, tuple(shape), kind, group
         if kind == "grid":            # (1,C,H,W) stored channels-last: [H][W][C]
             _, c, h, w = self.shape
             self.pitch = c
             self.numel = h * w * c
-        elif kind == "matrix":        # (out,in) stored row-major with in padded to a multiple of 4 floats
+        elif kind == "matrix":        # (out,in) stored row-major with in padded to a multiple of pitch_align (>= 4) floats
             o, i = self.shape
-            self.pitch = _round_up(i, 4)
+            self.pitch = _round_up(i, max(4, pitch_align))
             self.numel = o * self.pitch
         else:                         # "vector": 1-D
             self.pitch = 1

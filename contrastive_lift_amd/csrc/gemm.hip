@@ -257,6 +257,13 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->K < 160000 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
         h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_wgrad_f32_stream_launch(p, st);                // persistent 2-D weight gradient (row ranges x column slices)
+    // the 128-wide layers of the appearance MLP (forward K = 128 / 160 with bias, masked dgrad K = 128): persistent, every M (see above)
+    if (h->precision == 0 && !h->a_trans && h->N == 128 && ((h->K == 128) || (h->K == 160 && !h->b_trans)) && h->lda >= h->K && splits == 1 &&
+        !h->accumulate && !h->c_trans && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 &&
+        ((!h->b_trans && !h->mask && h->ldb >= h->K) ||
+         (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0 && h->ldb >= 128)) &&
+        getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_layer_n128_launch(p, h->b_trans, st);
     if (h->N > 128) {
         return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
     }

@@ -31,10 +31,27 @@ constexpr int LF_TILE = LF_ROWS * 64;        // float4 per tile: 32 rows x 1 KB
 template <int N>
 static __device__ __forceinline__ void wait_vmf() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// GEN (forward only): the layer's input is not read from memory but GENERATED -- it is the first layer of an xyz head,
+// A[m][c] = relu(W0[c] . x_m + b0[c]) with K = 3 (tensoRF.py:475,576), i.e. 13 VALU instructions per 16 bytes where the streamed
+// form costs a 255 MB write (k_linear_k3_fwd) plus its re-read.  A wave writes the four rows it would have DMA'd with ds_write_b128
+// into the same swizzled slots; a lane owns columns 4 lane .. +3 of every row, so its 12 weights + 4 biases stay in registers; the
+// sample positions of the block's rows are staged in LDS (2048 rows = 32 KB at a time).  h1 (nullable) receives the generated
+// activation when the head has a backward (the next layer's weight gradient and the ReLU mask need it).
+struct GenP {
+    const float* x4;      // (M, 4) normalised sample positions
+    const float* W0;      // (256, 3), row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+    float* h1;            // nullable: (M, ldh1) generated first-layer activation
+    int ldh1;
+};
+constexpr int LF_XROWS = 2048;               // positions staged per refill (64 tiles)
+
 // DGRAD = false: weights stored [n][k], bias + optional ReLU.  DGRAD = true: weights stored [k][n], fp32 ReLU mask.
-template <bool DGRAD>
-__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block) {
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * LF_TILE];        // 64 KB, the only LDS object
+template <bool DGRAD, bool GEN>
+__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block, GenP gp) {
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * LF_TILE + (GEN ? LF_XROWS : 0)];        // 64 KB (+ 32 KB of positions), the only LDS object
+    float4* const xs = lds + 2 * LF_TILE;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
@@ -61,12 +78,37 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     unsigned off8[8];         // slot of chunk 2 jj + lh of this lane's row, low four bits swizzled
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) off8[jj] = (unsigned)(((2 * jj + lh) ^ (li & 15)) * 16);
-    // One row of the DMA of tile t (this wave copies rows 4 wave .. +3 of every tile).
+    // GEN: this lane's first-layer coefficients (columns 4 lane .. +3)
+    float gw0[4], gw1[4], gw2[4], gbb[4];
+    if (GEN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wr0 = gp.W0 + (size_t)(4 * lane + e) * gp.ldw0;
+            gw0[e] = wr0[0]; gw1[e] = wr0[1]; gw2[e] = wr0[2]; gbb[e] = gp.b0[4 * lane + e];
+        }
+    }
+    // positions of rows [rbeg + first, rbeg + first + LF_XROWS) -> xs (all threads; callers bracket it with barriers)
+    auto fill_positions = [&](int first) {
+        const int n = min(LF_XROWS, rend - rbeg - first);
+        for (int e = tid; e < n; e += 512) xs[e] = *reinterpret_cast<const float4*>(gp.x4 + (size_t)(rbeg + first + e) * 4);
+    };
+    // One row of tile t (this wave provides rows 4 wave .. +3 of every tile): DMA'd from A, or generated.
     auto dma_row = [&](int t, int i) {
         const int row = wave * 4 + i;                                        // one 1 KB row per wave instruction
         const int gr = min(rbeg + t * LF_ROWS + row, rend - 1);              // rows past the range re-read its last row (never stored)
         const int c = lane ^ (row & 15);
-        __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(lds + (t & 1) * LF_TILE + row * 64), 16, 0, 0);
+        if (!GEN) {
+            __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(lds + (t & 1) * LF_TILE + row * 64), 16, 0, 0);
+        } else {
+            const float4 x = xs[(gr - rbeg) & (LF_XROWS - 1)];                // broadcast read
+            float4 o;
+            o.x = fmaxf(fmaf(gw2[0], x.z, fmaf(gw1[0], x.y, fmaf(gw0[0], x.x, gbb[0]))), 0.f);      // same order as k_linear_k3_fwd
+            o.y = fmaxf(fmaf(gw2[1], x.z, fmaf(gw1[1], x.y, fmaf(gw0[1], x.x, gbb[1]))), 0.f);
+            o.z = fmaxf(fmaf(gw2[2], x.z, fmaf(gw1[2], x.y, fmaf(gw0[2], x.x, gbb[2]))), 0.f);
+            o.w = fmaxf(fmaf(gw2[3], x.z, fmaf(gw1[3], x.y, fmaf(gw0[3], x.x, gbb[3]))), 0.f);
+            lds[(t & 1) * LF_TILE + row * 64 + c] = o;
+            if (gp.h1 && rbeg + t * LF_ROWS + row < rend) *reinterpret_cast<float4*>(gp.h1 + (size_t)gr * gp.ldh1 + 4 * lane) = o;
+        }
     };
     // The memory instructions of a tile are SPREAD through its MFMA loop instead of bunched at the tile boundary: eight waves issuing
     // 4 stores + 4 DMA rows each at the same moment cost 1.3 us of a 8.6 us tile (the MFMA pipe idles while the waves sit in the vector-memory
@@ -75,14 +117,25 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     // 12, 14 of tile t (dgrad: the mask loads of tile t go at steps 16 .. 22).
     float4 prev[4];
     int prev_m = rend;                                                       // row of `prev`; rend = nothing to store yet
+    if (GEN) { fill_positions(0); __syncthreads(); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_row(0, i);
     for (int t = 0; t < ntiles; ++t) {
-        // DMA of tile t: issued during tile t-1; younger than it: the 4 stores of tile t-2 (forward; the dgrad drained everything at the end
-        // of tile t-1 for its mask)
-        if (t >= 2) wait_vmf<4>(); else wait_vmf<0>();
-        __builtin_amdgcn_s_barrier();                                        // everyone's rows have landed; everyone is done with the other stage
-        asm volatile("" ::: "memory");
+        if (!GEN) {
+            // DMA of tile t: issued during tile t-1; younger than it: the 4 stores of tile t-2 (forward; the dgrad drained everything at the
+            // end of tile t-1 for its mask)
+            if (t >= 2) wait_vmf<4>(); else wait_vmf<0>();
+            __builtin_amdgcn_s_barrier();                                    // everyone's rows have landed; everyone is done with the other stage
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (no vmcnt wait: the output stores stay in flight)
+            __builtin_amdgcn_s_barrier();                                    // the generated rows of tile t are written; the other stage is free
+            asm volatile("" ::: "memory");
+            if (((t + 1) & (LF_XROWS / LF_ROWS - 1)) == 0 && t + 1 < ntiles) {   // tile t+1 (generated during this tile) starts the next 2048 rows
+                fill_positions((t + 1) * LF_ROWS);
+                __syncthreads();
+            }
+        }
         const int m = rbeg + t * LF_ROWS + li;
         const bool more = t + 1 < ntiles;
         f32x4 mk[4];
@@ -153,9 +206,29 @@ int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int tiles = cdiv(p.M, LF_ROWS);
     const int blocks = tiles < 256 ? tiles : 256;                    // one persistent block per CU
     const int rpb = cdiv(cdiv(p.M, blocks), LF_ROWS) * LF_ROWS;
-    if (b_trans) k_layer_f32<true><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb);
-    else k_layer_f32<false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb);
+    const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
+    if (b_trans) k_layer_f32<true, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none);
+    else k_layer_f32<false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none);
     return clift_check_launch("clift_gemm(fp32 layer)");
+}
+
+// First TWO layers of an xyz head in one launch: h2 = relu(W1 relu(W0 x + b0) + b1)   (tensoRF.py:475-478, 576-579), fp32.
+// x4 (M,4); W0 (256,3) pitch ldw0, b0 (256); W1 (256,256) pitch ldw1, b1 (256); h2 (M, ldh2); h1 (nullable, (M, ldh1)) = the first
+// layer's activation, written only when the caller needs it for a backward pass.
+extern "C" int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1, const float* b1,
+                                         int M, float* h1, int ldh1, float* h2, int ldh2, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)x4) & 15) == 0 && (((uintptr_t)W1) & 15) == 0 && (((uintptr_t)h2) & 15) == 0 && ldw1 % 4 == 0 && ldh2 % 4 == 0,
+                  "clift_xyz_head_first2_fwd: x4 / W1 / h2 must be 16-byte aligned with pitches that are multiples of 4");
+    CLIFT_REQUIRE(h1 == nullptr || ((((uintptr_t)h1) & 15) == 0 && ldh1 % 4 == 0 && ldh1 >= 256), "clift_xyz_head_first2_fwd: h1 must be 16-byte aligned, pitch >= 256");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = nullptr; p.lda = 256; p.B = W1; p.ldb = ldw1; p.C = h2; p.ldc = ldh2; p.bias = b1; p.act = 1;
+    const int tiles = cdiv(M, LF_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
+    const GenP gp = {x4, W0, ldw0, b0, h1, ldh1};
+    k_layer_f32<false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, gp);
+    return clift_check_launch("clift_xyz_head_first2_fwd");
 }
 
 // ============================================================================ weight gradient of the same layers, persistent

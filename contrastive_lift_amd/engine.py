@@ -220,17 +220,32 @@ class Branches:
 
 
 # ----------------------------------------------------------------------------- xyz MLP heads (semantic / instance)
-def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0):
+FUSE_FIRST2 = os.environ.get("CLIFT_FUSE_FIRST2", "1") != "0"     # K = 3 layer generated inside the second layer's kernel (fp32 path)
+
+
+def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
     """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
-    activation) into out[:, col_off:col_off+n_out] with row pitch ldo."""
+    activation) into out[:, col_off:col_off+n_out] with row pitch ldo.
+    ``keep_first`` = False: the caller will not run a backward through this head, so the first (K = 3) layer's activation is
+    never materialised (acts[0] is None) -- fp32 path, 256-wide heads."""
     dev = xa.device
     acts = []
     W0, b0 = layers[0]
     hdt = act_dtype()                     # bf16 mode stores the hidden activations as bf16 (half the HBM stream of these layers)
-    h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)
-    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
-    acts.append(h)
-    for W, b in layers[1:-1]:
+    rest = layers[1:-1]
+    if (FUSE_FIRST2 and MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
+            and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+        W1, b1 = layers[1]
+        h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
+        h = torch.empty((M, 256), dtype=torch.float32, device=dev)
+        call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h1), 256, ptr(h), 256, stream())
+        acts += [h1, h]
+        rest = layers[2:-1]
+    else:
+        h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)
+        call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
+        acts.append(h)
+    for W, b in rest:
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
         gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
         acts.append(hn)
@@ -246,6 +261,8 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
     dev = xa.device
     d = dpre
     n = len(layers)
+    if acts[0] is None:
+        raise _lib.CliftError("backward through an xyz head whose forward ran with keep_first=False (head not named in grad_heads)")
     keep = keep if keep is not None else []
     keep.append(d)
     for li in range(n - 1, 0, -1):
@@ -308,8 +325,10 @@ def _check_rays(rays, jitter):
     return rays, jitter
 
 
-def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True):
-    """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context."""
+def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("sem", "fast", "slow")):
+    """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context.
+    ``grad_heads``: the xyz heads a backward pass may be run through ("sem", "fast", "slow"); a head that is not named keeps no
+    first-layer activation (the training main pass never differentiates the instance heads, T:155; inference none)."""
     rays, jitter = _check_rays(rays, jitter)
     views = model.named_views()
     ctx = _density_march(model, renderer, rays, jitter)
@@ -360,7 +379,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
         def sem_chain(keep):
             sem_layers = _lin_params(None, "render_semantic_mlp.mlp", views)
             logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, logits, Ccls)
+            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, logits, Ccls, keep_first="sem" in grad_heads)
             if model.render_semantic_mlp.softmax:
                 sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
                 call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(sem_s), Ccls, stream())
@@ -379,10 +398,12 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
 
             def fast_chain(keep):
-                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
+                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0,
+                                                 keep_first="fast" in grad_heads)
 
             def slow_chain(keep):
-                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E)
+                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E,
+                                                 keep_first="slow" in grad_heads)
             br.run(2, fast_chain)
             if model.slow_fast_mode:
                 br.run(3, slow_chain)
@@ -542,9 +563,9 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes
-def feature_forward(model, renderer, rays, jitter, head):
+def feature_forward(model, renderer, rays, jitter, head, grad_heads=("sem", "fast", "slow")):
     """renderer.py:178-217 (head='instance') / :259-300 (head='semantic'): density and weights carry no gradient,
-    only the head does."""
+    only the head does.  ``grad_heads`` as in render_forward."""
     rays, jitter = _check_rays(rays, jitter)
     views = model.named_views()
     ctx = _density_march(model, renderer, rays, jitter)
@@ -565,7 +586,7 @@ def feature_forward(model, renderer, rays, jitter, head):
         if head == "semantic":
             layers = _lin_params(None, "render_semantic_mlp.mlp", views)
             logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, logits, Ccls)
+            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, logits, Ccls, keep_first="sem" in grad_heads)
             if model.render_semantic_mlp.softmax:
                 ctx.sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
                 call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(ctx.sem_s), Ccls, st)
@@ -577,10 +598,12 @@ def feature_forward(model, renderer, rays, jitter, head):
             br = Branches()
 
             def fast_chain(keep):
-                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0)
+                ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0,
+                                                 keep_first="fast" in grad_heads)
 
             def slow_chain(keep):
-                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E)
+                ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E,
+                                                 keep_first="slow" in grad_heads)
             br.run(2, fast_chain)
             if model.slow_fast_mode:
                 br.run(3, slow_chain)
@@ -652,7 +675,7 @@ def xyz_mlp_points(seq, xyz):
     xa[:, :3] = x[:, :3]
     layers = [(m.weight, m.bias) for m in seq if isinstance(m, torch.nn.Linear)]
     out = torch.empty((M, layers[-1][0].shape[0]), dtype=torch.float32, device=x.device)
-    xyz_mlp_fwd(layers, xa, M, out, out.shape[1])
+    xyz_mlp_fwd(layers, xa, M, out, out.shape[1], keep_first=False)
     return out
 
 

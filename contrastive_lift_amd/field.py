@@ -181,7 +181,9 @@ class TensorVMSplit(nn.Module):
         slots = []
         for name, owner, key, kind, grp in lay:
             p = owner[key] if isinstance(key, int) else getattr(owner, key)
-            slots.append(Slot(name, p.shape, kind, grp))
+            # the first appearance layer (150 inputs) gets a 160-float row pitch: a whole number of 8-chunk swizzle groups for the
+            # persistent 128-wide layer kernel (csrc/layer_n128.hip); pad columns stay zero
+            slots.append(Slot(name, p.shape, kind, grp, pitch_align=32 if name == "render_appearance_mlp.mlp.0.weight" else 4))
         arena = Arena(slots, device)
         pflat, gflat = arena.new_buffer(), arena.new_buffer()
         pv, gv = arena.views(pflat), arena.views(gflat)

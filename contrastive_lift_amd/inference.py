@@ -16,7 +16,7 @@ def render_rays(model, renderer, rays, chunk, white_bg=False):
     outs = [[], [], [], []]
     chunk = int(chunk) if chunk and int(chunk) > 0 else rays.shape[0]
     for i in range(0, rays.shape[0], chunk):
-        o, ctx = engine.render_forward(model, renderer, rays[i:i + chunk], None, bool(white_bg))
+        o, ctx = engine.render_forward(model, renderer, rays[i:i + chunk], None, bool(white_bg), grad_heads=())
         outs[0].append(o["rgb"]); outs[1].append(o["semantics"]); outs[2].append(o["instances"]); outs[3].append(o["depth"].clone())
         del ctx
     return tuple(torch.cat(x, 0) for x in outs)

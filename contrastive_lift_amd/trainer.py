@@ -141,7 +141,7 @@ class HotPathTrainer:
             else:
                 wb = bool(white_bg)
             o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,
-                                           want_inst=not lean)
+                                           want_inst=not lean, grad_heads=("sem",))        # T:155: the instance output is discarded
             ctxs.append(ctx)
             outs.append(o)
         rgb = outs[0]["rgb"] if len(outs) == 1 else torch.cat([o["rgb"] for o in outs], 0)
@@ -191,7 +191,7 @@ class HotPathTrainer:
             return
         if jitter is None and c.perturb != 0:
             jitter = c.perturb * torch.rand(n, device=self.device)
-        feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic")
+        feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic", grad_heads=("sem",))
         C = feats.shape[1]
         G = int(seg["n_groups"])
         group = seg["group"].to(device=self.device, dtype=torch.int32).contiguous()
@@ -216,7 +216,7 @@ class HotPathTrainer:
             rays = img["rays"]
             n = rays.shape[0]
             jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
-            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance")
+            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",))      # slow half: detached (T:268)
             if c.instance_loss_mode == "slow_fast":
                 # reference order: the features (fast and slow halves) are rendered first (T:214), THEN the EMA step of the slow
                 # net at the top of the loss (T:258-259) -- the slow features of this step come from the pre-update weights

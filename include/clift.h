@@ -180,6 +180,12 @@ int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
  * with row pitch ldw. */
 int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b, int M, int Nout, int relu,
                         float* out, int ldo, int out_bf16 /* out is bf16-stored (bf16 mode) */, clift_stream_t s);
+/* First TWO layers of an xyz head in one launch (tensoRF.py:475-478, 576-579; 256-wide hidden layers, fp32):
+ * h2 (M, ldh2) = relu(W1 relu(W0 x + b0) + b1).  The K = 3 layer is generated inside the second layer's persistent kernel
+ * instead of being written (255 MB at the bench shape) and re-read.  h1 (nullable; (M, ldh1)) receives the first layer's
+ * activation when a backward pass will need it.  Results are bit-identical to clift_linear_k3_fwd followed by clift_gemm. */
+int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
+                              const float* b1, int M, float* h1, int ldh1, float* h2, int ldh2, clift_stream_t s);
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         int dh_bf16 /* dH is bf16-stored */, clift_stream_t s);

@@ -353,3 +353,70 @@ def test_alpha_bbox_kernel_vs_torch_pooling():
             continue
         lo, hi, n, _ = got
         assert lo == idx.amin(0).tolist() and hi == idx.amax(0).tolist() and n == idx.shape[0], (thr, lo, hi, n)
+
+
+# ============================================================================ K = 3 layer generated inside the second layer's kernel
+@pytest.mark.parametrize("M", [1, 31, 33, 4097, 70001, 600000])
+def test_xyz_head_first_two_layers_fused_is_bit_identical(M):
+    """clift_xyz_head_first2_fwd (first layer generated in LDS by the persistent 256x256 kernel) against clift_linear_k3_fwd followed
+    by clift_gemm: same instruction sequence per element => bit-identical h2, and h1 when requested.  600000 rows = 2344 rows per
+    block: the staged positions are refilled (2048 rows per fill); 1 / 31 / 33: ragged tiles."""
+    import ctypes as C
+    from contrastive_lift_amd import _lib, engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(M)
+    xa = torch.zeros((M, 4)); xa[:, :3] = torch.rand((M, 3), generator=g) * 2 - 1
+    W0 = torch.randn((256, 4), generator=g) * 0.7; W0[:, 3] = 0
+    b0 = torch.randn(256, generator=g) * 0.3
+    W1 = torch.randn((256, 256), generator=g) * 0.08
+    b1 = torch.randn(256, generator=g) * 0.1
+    xa, W0, b0, W1, b1 = (t.to(DEV).contiguous() for t in (xa, W0, b0, W1, b1))
+    h1_ref = torch.empty((M, 256), device=DEV)
+    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), 4, ptr(b0), M, 256, 1, ptr(h1_ref), 256, 0, stream())
+    h2_ref = torch.empty((M, 256), device=DEV)
+    engine.gemm(M, 256, 256, h1_ref, 256, W1, 256, h2_ref, 256, bias=b1, act=1)
+    for keep in (True, False):
+        h1 = torch.full((M, 256), float("nan"), device=DEV) if keep else None
+        h2 = torch.full((M, 256), float("nan"), device=DEV)
+        call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), 4, ptr(b0), ptr(W1), 256, ptr(b1), M, ptr(h1), 256, ptr(h2), 256, stream())
+        assert torch.equal(h2, h2_ref), (M, keep, float((h2 - h2_ref).abs().max()))
+        if keep:
+            assert torch.equal(h1, h1_ref)
+
+
+# ============================================================================ persistent 128-wide layers (appearance MLP)
+@pytest.mark.parametrize("M", [1, 63, 65, 5000, 70001])
+def test_persistent_128_wide_layers(M):
+    """layer_n128.hip: forward K = 160 (first appearance layer, 150 inputs zero-padded to the 160-float pitch) and K = 128 with bias +
+    ReLU, masked dgrad K = 128 -- against fp64, every row of ragged ranges (64-row tiles: 1 / 63 / 65), rows beyond M and pad
+    columns untouched; and the same sums as the tiled kernel up to summation order."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 11)
+    for K in (160, 128):
+        A = torch.randn((M, K), generator=g)
+        W = (torch.randn((128, K), generator=g) / 12).contiguous()
+        if K == 160:
+            A[:, 150:] = 0; W[:, 150:] = 0
+        bias = torch.randn(128, generator=g)
+        ref = torch.relu(A.double() @ W.double().T + bias.double())
+        Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+        out = torch.full((M + 2, 132), -7.0, device=DEV)
+        engine.gemm(M, 128, K, Ad, K, Wd, K, out, 132, bias=bd, act=1)
+        rel_close(out[:M, :128], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what=f"persistent 128-wide forward K={K}")
+        assert bool((out[M:] == -7.0).all()) and bool((out[:, 128:] == -7.0).all())
+        os.environ["CLIFT_NO_PERSISTENT"] = "1"
+        try:
+            out3 = torch.zeros((M, 128), device=DEV)
+            engine.gemm(M, 128, K, Ad, K, Wd, K, out3, 128, bias=bd, act=1)
+        finally:
+            del os.environ["CLIFT_NO_PERSISTENT"]
+        scale = (A.abs().double() @ W.abs().double().T + bias.abs().double()).to(DEV)
+        assert float(((out[:M, :128] - out3).abs().double() / scale).max()) <= 2e-6
+    A = torch.randn((M, 128), generator=g)
+    W = (torch.randn((128, 128), generator=g) / 12).contiguous()
+    mask = torch.randn((M, 128), generator=g)
+    dX = torch.full((M + 2, 132), -7.0, device=DEV)
+    engine.gemm(M, 128, 128, A.to(DEV), 128, W.to(DEV), 128, dX, 132, b_trans=1, mask=mask.to(DEV), ldmask=128)
+    refd = (A.double() @ W.double()) * (mask.double() > 0)
+    rel_close(dX[:M, :128], refd, 2e-5, atol=2e-5 * float(refd.abs().max()), what="persistent 128-wide dgrad")
+    assert bool((dX[M:] == -7.0).all()) and bool((dX[:, 128:] == -7.0).all())
