@@ -257,6 +257,10 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->K < 160000 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
         h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_wgrad_f32_stream_launch(p, st);                // persistent 2-D weight gradient (row ranges x column slices)
+    // weight gradients of the 128-wide appearance layers (128 x 128 and 128 x 160 results): persistent row-range stream
+    if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 128 && (h->N == 128 || h->N == 160) && h->ldb >= h->N && h->lda >= 128 && h->K >= 4096 &&
+        h->accumulate && !h->c_trans && !h->bias && !h->mask && h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_wgrad_n128_stream_launch(p, st);
     // the 128-wide layers of the appearance MLP (forward K = 128 / 160 with bias, masked dgrad K = 128): persistent, every M (see above)
     if (h->precision == 0 && !h->a_trans && h->N == 128 && ((h->K == 128) || (h->K == 160 && !h->b_trans)) && h->lda >= h->K && splits == 1 &&
         !h->accumulate && !h->c_trans && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 &&

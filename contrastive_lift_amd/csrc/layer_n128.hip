@@ -153,3 +153,123 @@ int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st) {
     else { CLIFT_REQUIRE(false, "clift_gemm(fp32 128-wide layer): unsupported shape K=%d b_trans=%d", p.K, b_trans); }
     return clift_check_launch("clift_gemm(fp32 128-wide layer)");
 }
+
+// ============================================================================ weight gradient of the same layers, persistent
+// gW[n][k] += sum_m dY[m][n] X[m][k]  (+ gb[n] += sum_m dY[m][n]),  fp32: n < 128 (the layer's outputs), k < 32 KXC / 8 ... i.e. X has
+// KXC 16-byte chunks per row (32: the 128 -> 128 layer; 40: the first layer's 160-float pitch).  One persistent block per CU owns a
+// contiguous range of sample rows and streams 64-row tiles of dY and X through two LDS stages by LDS-DMA (one tile ahead); wave
+// (wn, wk) owns gW rows 32 wn .. +31 and the X column tiles {2 wk, 2 wk + 1} (KXC = 32) or {0,1,2} / {3,4} (KXC = 40), i.e. 64-96
+// MFMAs per wave between barriers; per step a lane reads one dY and one X element per tile (row-contiguous ds_read_b32, conflict-free
+// in a lane-linear image).  The block ends with ONE 128 x K partial added to gW (20 k atomics per block instead of the 64 k of a
+// split-K tile launch).  The tiled split-K launch it replaces ran at ~50 TFLOP/s on these shapes.
+template <int KXC>
+__global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_per_range) {
+    constexpr int ROWS = 64;
+    constexpr int YB = ROWS * 512, XB = ROWS * KXC * 16, STAGE = YB + XB;     // bytes
+    constexpr int NT = (KXC == 40) ? 3 : 2;                                   // accumulator tiles per wave (KXC = 40: 3 + 2 over the two wk)
+    constexpr int NDX = KXC / 8;                                              // X DMA instructions per wave per tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wn = wave & 3, wk = wave >> 2;
+    const int tile0 = (KXC == 40) ? 3 * wk : 2 * wk;                          // first X column tile of this wave
+    const int ntile = (KXC == 40 && wk == 1) ? 2 : NT;
+    const int rbeg = blockIdx.x * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + ROWS - 1) / ROWS;
+    const float* __restrict__ Y = g.A;            // dY (rows, 128), pitch lda
+    const float* __restrict__ X = g.B;            // X (rows, 4 KXC), pitch ldb
+    auto dma = [&](int t) {
+        const int r0 = rbeg + t * ROWS;
+        unsigned char* st = lds + (t & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {             // dY: 64 rows x 32 chunks, 2 rows per instruction
+            const int q = 64 * (4 * wave + i) + lane, row = q >> 5, c = q & 31, gr = min(r0 + row, rend - 1);
+            __builtin_amdgcn_global_load_lds(Y + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(st + 1024 * (4 * wave + i)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) {           // X: 64 rows x KXC chunks
+            const int q = 64 * (NDX * wave + i) + lane, row = q / KXC, c = q - row * KXC, gr = min(r0 + row, rend - 1);
+            __builtin_amdgcn_global_load_lds(X + (size_t)gr * g.ldb + c * 4, (lds_ptr_t)(st + YB + 1024 * (NDX * wave + i)), 16, 0, 0);
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    float bsum = 0.f;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const unsigned yoff = (unsigned)(lh * 512 + (32 * wn + li) * 4);                           // dY element (row lh, column 32 wn + li)
+    const unsigned xoff = (unsigned)(YB + lh * KXC * 16 + (32 * tile0 + li) * 4);              // X element (row lh, column 32 tile0 + li)
+
+    dma(0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile t has landed (issued a whole tile ago)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntiles) dma(t + 1);
+        const int valid = rend - (rbeg + t * ROWS);
+        if (valid < ROWS) {                                                  // last tile of the range: rows past its end contribute nothing
+            float* yt = reinterpret_cast<float*>(lds + (t & 1) * STAGE);
+            for (int e = valid * 128 + tid; e < ROWS * 128; e += 512) yt[e] = 0.f;
+            __syncthreads();
+        }
+        const unsigned sb = lds0 + (unsigned)((t & 1) * STAGE);
+        float fa[2][4], fb[2][NT][4];             // ping-pong groups of 4 steps
+        auto rd = [&](int grp, int set) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * grp + u;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(fa[set][u]) : "v"(sb + yoff + (unsigned)(2 * s * 512)) : "memory");
+#pragma unroll
+                for (int x = 0; x < NT; ++x)
+                    if (x < ntile) asm volatile("ds_read_b32 %0, %1" : "=v"(fb[set][x][u]) : "v"(sb + xoff + (unsigned)(2 * s * KXC * 16 + 128 * x)) : "memory");
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < ROWS / 8; ++grp) {
+            const int set = grp & 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp + 1 < ROWS / 8) rd(grp + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int x = 0; x < NT; ++x)
+                    if (x < ntile) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u], fb[set][x][u], acc[x], 0, 0, 0);
+                bsum += fa[set][u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // lane (li, lh) holds gW rows n = 32 wn + 8 q + 4 lh + e, column 32 (tile0 + x) + li of accumulator x
+#pragma unroll
+    for (int x = 0; x < NT; ++x) {
+        if (x >= ntile) continue;
+        const int col = 32 * (tile0 + x) + li;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * wn + 8 * (r >> 2) + 4 * lh + (r & 3);
+            unsafeAtomicAdd(g.C + (size_t)n * g.ldc + col, acc[x][r]);
+        }
+    }
+    if (g.colsum && wk == 0) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned u = __float_as_uint(bsum);
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (lh == 0) unsafeAtomicAdd(g.colsum + 32 * wn + li, tot);
+    }
+}
+
+// Eligibility decided by the caller (gemm.hip): wgrad form (a_trans, b_trans, accumulate) with a 128 x N result, N in {128, 160} (N <= ldb:
+// the pad columns of X exist and are zero), K (sample rows) >= 4096, 16-byte-aligned rows.
+int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st) {
+    const int rpr = cdiv(cdiv(p.K, 256), 64) * 64;
+    const dim3 grid(cdiv(p.K, rpr));
+    if (p.N > 128) k_wgrad_n128_stream<40><<<grid, 512, 0, st>>>(p, rpr);
+    else k_wgrad_n128_stream<32><<<grid, 512, 0, st>>>(p, rpr);
+    return clift_check_launch("clift_gemm(fp32 128-wide wgrad stream)");
+}

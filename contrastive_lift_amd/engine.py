@@ -252,7 +252,9 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         h = hn
     W, b = layers[-1]
     gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), out, ldo, bias=b, c_off=col_off)
-    return acts
+    # no backward through this head: nothing is retained, every hidden activation goes back to the (stream-ordered) allocator as soon
+    # as the next layer has been enqueued -- a frame render at 65536 rays per chunk holds ~9 GiB per hidden layer otherwise
+    return acts if keep_first else [None]
 
 
 def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
@@ -325,10 +327,10 @@ def _check_rays(rays, jitter):
     return rays, jitter
 
 
-def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("sem", "fast", "slow")):
+def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("app", "sem", "fast", "slow")):
     """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context.
-    ``grad_heads``: the xyz heads a backward pass may be run through ("sem", "fast", "slow"); a head that is not named keeps no
-    first-layer activation (the training main pass never differentiates the instance heads, T:155; inference none)."""
+    ``grad_heads``: the heads a backward pass may be run through ("app", "sem", "fast", "slow"); a head that is not named retains
+    no activations (the training main pass never differentiates the instance heads, T:155; inference none)."""
     rays, jitter = _check_rays(rays, jitter)
     views = model.named_views()
     ctx = _density_march(model, renderer, rays, jitter)
@@ -374,7 +376,11 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
             call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, stream())
             keep.append(pre)
-            ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2, ctx.rgb_s = feat, ldf, nf, X, ldx, H1, H2, rgb_s
+            ctx.rgb_s = rgb_s
+            if "app" in grad_heads:
+                ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2 = feat, ldf, nf, X, ldx, H1, H2
+            else:
+                ctx.F = None
 
         def sem_chain(keep):
             sem_layers = _lin_params(None, "render_semantic_mlp.mlp", views)
@@ -563,7 +569,7 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes
-def feature_forward(model, renderer, rays, jitter, head, grad_heads=("sem", "fast", "slow")):
+def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem", "fast", "slow")):
     """renderer.py:178-217 (head='instance') / :259-300 (head='semantic'): density and weights carry no gradient,
     only the head does.  ``grad_heads`` as in render_forward."""
     rays, jitter = _check_rays(rays, jitter)

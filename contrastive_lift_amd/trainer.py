@@ -141,7 +141,7 @@ class HotPathTrainer:
             else:
                 wb = bool(white_bg)
             o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,
-                                           want_inst=not lean, grad_heads=("sem",))        # T:155: the instance output is discarded
+                                           want_inst=not lean, grad_heads=("app", "sem"))        # T:155: the instance output is discarded
             ctxs.append(ctx)
             outs.append(o)
         rgb = outs[0]["rgb"] if len(outs) == 1 else torch.cat([o["rgb"] for o in outs], 0)

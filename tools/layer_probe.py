@@ -36,3 +36,8 @@ t_two = timeit(two)
 t_keep = timeit(lambda: call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), 4, ptr(b0), ptr(W1), 256, ptr(b1), M, ptr(h1), 256, ptr(h2), 256, stream()))
 t_drop = timeit(lambda: call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), 4, ptr(b0), ptr(W1), 256, ptr(b1), M, None, 256, ptr(h2), 256, stream()))
 print(f"xyz head first two layers M={M}: k3 + layer {t_two:7.1f} us   fused (h1 kept) {t_keep:7.1f} us   fused (h1 dropped) {t_drop:7.1f} us")
+for K in (128, 160):
+    dY = torch.randn(M, 128, device=dev); X = torch.randn(M, K, device=dev); gW = torch.zeros(128, K, device=dev); gb = torch.zeros(128, device=dev)
+    f = lambda: engine.wgrad(128, K, M, dY, 128, X, K, gW, gb)
+    t = timeit(f); os.environ["CLIFT_NO_PERSISTENT"] = "1"; t0 = timeit(f); del os.environ["CLIFT_NO_PERSISTENT"]
+    print(f"wgrad 128x{K} M={M}: persistent {t:7.1f} us ({2.0*M*128*K/t/1e6:6.1f} TF)   tiled {t0:7.1f} us ({2.0*M*128*K/t0/1e6:6.1f} TF)")
