@@ -103,35 +103,46 @@ def main():
     # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
-    real_gemm = engine.gemm
+    real_gemm, real_first2, real_last2 = engine.gemm, engine.first2, engine.last2
 
     def replay(select):
-        """Re-run the timed steps from the snapshot with the selected clift_gemm launches bracketed by HIP events."""
+        """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
+        engine.gemm (clift_gemm) and engine.first2 (clift_xyz_head_first2_fwd: the K = 3 layer generated inside the persistent kernel
+        of the first 256 x 256 layer -- kind "fwd_gen", FLOPs of both layers)."""
         model.param_flat.copy_(snap[0])
         tr.opt_main.load_state_dict(snap[1])
         tr.opt_inst.load_state_dict(snap[2])
         out = []
 
-        def recorded_gemm(M, N, K, *args, **kw):
-            kind = "wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd"
+        def bracket(kind, M, N, K, extra_flops, fn):
             if not select(kind, N):
-                return real_gemm(M, N, K, *args, **kw)
+                return fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            real_gemm(M, N, K, *args, **kw)
+            fn()
             e1.record()
-            out.append((kind, M, N, K, e0, e1))
-        engine.gemm = recorded_gemm
+            out.append((kind, M, N, K, e0, e1, extra_flops))
+
+        def recorded_gemm(M, N, K, *args, **kw):
+            kind = "wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd"
+            return bracket(kind, M, N, K, 0.0, lambda: real_gemm(M, N, K, *args, **kw))
+
+        def recorded_first2(M, *args):
+            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, lambda: real_first2(M, *args))
+
+        def recorded_last2(M, h, W, b, Wo, *args):        # last hidden layer + narrow output layer (clift_xyz_head_last2_fwd)
+            return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2(M, h, W, b, Wo, *args))
+        engine.gemm, engine.first2, engine.last2 = recorded_gemm, recorded_first2, recorded_last2
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
-            engine.gemm = real_gemm
+            engine.gemm, engine.first2, engine.last2 = real_gemm, real_first2, real_last2
         return out
-    # pass 1: only the dominant kernel's launches (11 per step) -- few enough events that the step stays GPU-bound, so an event
-    # pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the informational all_gemm split (the
-    # ~80 events per step make that pass host-bound, so its per-launch times are upper bounds).
+    # pass 1: only the dominant kernel's launches (k_layer_f32<false,false>: the plain 256 x 256 forward layers) -- few enough events that
+    # the step stays GPU-bound, so an event pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the
+    # informational all_gemm split (the ~80 events per step make that pass host-bound, so its per-launch times are upper bounds).
     rec = replay(lambda kind, N: kind == "fwd" and N > 128)
     rec_all = replay(lambda kind, N: True)
     if world > 1:
@@ -258,14 +269,14 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
     count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
     tot_f, tot_ms, by = 0.0, 0.0, {}
     dom_f, dom_ms, dom_n = 0.0, 0.0, 0
-    for kind, M, N, K, e0, e1 in rec:
+    for kind, M, N, K, e0, e1, xf in rec:
         ms = e0.elapsed_time(e1)
-        fl = 2.0 * M * N * K
+        fl = 2.0 * M * N * K + xf
         tot_f += fl
         tot_ms += ms
         b = by.setdefault(kind, [0.0, 0.0, 0])
         b[0] += fl; b[1] += ms; b[2] += 1
-    for kind, M, N, K, e0, e1 in rec_dom:
+    for kind, M, N, K, e0, e1, xf in rec_dom:
         dom_f += 2.0 * M * N * K; dom_ms += e0.elapsed_time(e1); dom_n += 1
     tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ach = tf(dom_f, dom_ms)
@@ -273,7 +284,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
         # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its
         # activations.  Algorithmic bytes per launch = A read + C written (M x 256 x 2 bytes each, bf16-stored) + weights (256 KB, L2).
         esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
-        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec_dom)
+        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _, _ in rec_dom)
         gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         return {"bound": "hbm", "kernel": "k_layer_bf16<false,3> (persistent streamed 256x256 forward layers: weights in registers, LDS-DMA ring, v_mfma_f32_32x32x16_bf16; bf16-stored activations)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
@@ -283,7 +294,9 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
                              "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
     alg_bytes = (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
     pmc = measured_traffic_ratio()
-    out = {"bound": "mfma", "kernel": "k_layer_f32<false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; 256x256 forward MLP layers)",
+    out = {"bound": "mfma", "kernel": "k_layer_f32<false, false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; the 256x256 forward MLP layers whose input is "
+                                      "streamed from memory -- the first 256x256 layer of each head runs as k_layer_f32<false, true>, which generates its K = 3 input, "
+                                      "and is listed under all_gemm.by_kind.fwd_gen)",
            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
            # HBM bytes per (average) launch of the dominant kernel: algorithmic bytes of THIS run's average launch (A read once + C
            # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on

@@ -47,11 +47,30 @@ struct GenP {
 };
 constexpr int LF_XROWS = 2048;               // positions staged per refill (64 tiles)
 
+// OUTV (forward only): the layer is the LAST hidden layer of a head with a narrow output (E <= 4 columns: the instance heads,
+// tensoRF.py:480-481), and the output layer out[m][c] = sum_k h[m][k] Wout[c][k] + bout[c] is applied to the tile while it is still in
+// registers instead of by a separate launch that re-reads the 1 KB-per-row activation: every lane holds 16 values of its row, so
+// 4 x 16 FMAs give its share of the E dot products (weights from LDS), a permlane swap folds the two half-waves, the eight waves'
+// shares meet in LDS and 16 lanes of the wave that owns the rows add them up (fixed order) and store.  All of it is spread through the
+// MFMA loops of the two following tiles.  store_hidden = 0: the hidden activation itself is not written (no backward through the head).
+struct OutP {
+    const float* Wout;    // (E, 256), row pitch ldwo
+    int ldwo;
+    const float* bout;    // (E), nullable
+    int E;
+    float* out;           // (M, ldo), column offset already applied
+    int ldo;
+    int store_hidden;
+};
+constexpr int LF_OUTV_F4 = 256 + 2 * 8 * 32;  // float4: Wout rows padded to 4 x 256 floats + two buffers of 8 waves x 32 rows of partial sums
+
 // DGRAD = false: weights stored [n][k], bias + optional ReLU.  DGRAD = true: weights stored [k][n], fp32 ReLU mask.
-template <bool DGRAD, bool GEN>
-__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block, GenP gp) {
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * LF_TILE + (GEN ? LF_XROWS : 0)];        // 64 KB (+ 32 KB of positions), the only LDS object
+template <bool DGRAD, bool GEN, bool OUTV>
+__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block, GenP gp, OutP op) {
+    __shared__ __attribute__((aligned(1024))) float4 lds[2 * LF_TILE + (GEN ? LF_XROWS : 0) + (OUTV ? LF_OUTV_F4 : 0)];   // the only LDS object
     float4* const xs = lds + 2 * LF_TILE;
+    float4* const wl4 = lds + 2 * LF_TILE + (GEN ? LF_XROWS : 0);            // OUTV: wl4[c * 64 + k / 4]
+    float4* const part = wl4 + 256;                                          // OUTV: part[(tile & 1) * 256 + wave * 32 + row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
@@ -75,9 +94,6 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     }
     wait_vmf<0>();
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    unsigned off8[8];         // slot of chunk 2 jj + lh of this lane's row, low four bits swizzled
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) off8[jj] = (unsigned)(((2 * jj + lh) ^ (li & 15)) * 16);
     // GEN: this lane's first-layer coefficients (columns 4 lane .. +3)
     float gw0[4], gw1[4], gw2[4], gbb[4];
     if (GEN) {
@@ -118,6 +134,60 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     float4 prev[4];
     int prev_m = rend;                                                       // row of `prev`; rend = nothing to store yet
     if (GEN) { fill_positions(0); __syncthreads(); }
+    // ---- OUTV state
+    const unsigned wl0 = (unsigned)(uintptr_t)(lds_ptr_t)wl4, part0 = (unsigned)(uintptr_t)(lds_ptr_t)part;
+    const unsigned wlane = wl0 + (unsigned)((8 * wave + lh) * 16);           // this lane's slice of a Wout row: floats 32 wave + 4 lh + 8 q ...
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};                                         // this lane's share of the E dot products of the previous tile
+    f32x4 wv[2];              // (also the eight shares of the cross-wave sum: the two uses never overlap)
+    if (OUTV) {
+        float* wl = reinterpret_cast<float*>(wl4);
+        for (int e = tid; e < 1024; e += 512) { const int c = e >> 8, k = e & 255; wl[e] = c < op.E ? op.Wout[(size_t)c * op.ldwo + k] : 0.f; }
+        __syncthreads();
+    }
+    // narrow layer, one (column group q, output c) pair per k-step, pairs p = 4 q + c = 0 .. 15: the weight fragment of pair p is read
+    // at k-step 7 + p ...
+    auto outv_issue = [&](int p_) {
+        const int q = p_ >> 2, c = p_ & 3;
+        unsigned b = wlane;                       // (opaque copy: keeps the compiler from hoisting sixteen precomputed addresses into registers)
+        asm volatile("" : "+v"(b));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wv[p_ & 1]) : "v"(b + (unsigned)((c * 64 + 2 * q) * 16)) : "memory");
+    };
+    // ... and used at k-step 8 + p (after that step's lgkmcnt(0)): 4 FMAs
+    auto outv_fma = [&](int p_) {
+        const int q = p_ >> 2, c = p_ & 3;
+        const f32x4 wq = wv[p_ & 1];
+        pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
+    };
+    // step 3 (k-step 24): fold the half-waves, park the wave's share of tile `tile` in LDS
+    auto outv_park = [&](int tile) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned u = __float_as_uint(pv[c]);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            pv[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        if (lh == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(part0 + (unsigned)(((tile & 1) * 256 + wave * 32 + li) * 16)), "v"(pv) : "memory");
+        pv = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // step 4 (k-step 26 of the tile after that, i.e. behind a barrier): lanes 0..15 of wave w fetch the eight shares of (row 4 w + lane / 4, column lane % 4) ...
+    auto outv_fetch = [&](int tile) {
+        if (lane < 16) {
+            unsigned b = part0 + (unsigned)(((tile & 1) * 256 + 4 * wave + (lane >> 2)) * 16 + (lane & 3) * 4);
+            asm volatile("" : "+v"(b));
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(wv[w8 >> 2][w8 & 3]) : "v"(b + (unsigned)(w8 * 32 * 16)) : "memory");
+        }
+    };
+    // ... step 5 (k-step 28): add them up in a fixed order, add the bias, store
+    auto outv_store = [&](int tile) {
+        if (lane < 16) {
+            const int c = lane & 3, mrow = rbeg + tile * LF_ROWS + 4 * wave + (lane >> 2);
+            const float v = ((wv[0][0] + wv[0][1]) + (wv[0][2] + wv[0][3])) + ((wv[1][0] + wv[1][1]) + (wv[1][2] + wv[1][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
+            if (c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_row(0, i);
     for (int t = 0; t < ntiles; ++t) {
@@ -144,11 +214,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         if (!DGRAD) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bw, 1.0f, acc1, 0, 0, 0);
         const unsigned rowb = lds0 + (unsigned)((t & 1) * LF_TILE * 16 + li * 1024);
-        unsigned ad[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) ad[jj] = rowb + off8[jj];
+        // slot of chunk 2 jj + lh of this lane's row, low four bits swizzled: (2 jj + lh) ^ (li & 15) = 2 jj ^ (lh ^ (li & 15)), and the row base
+        // is a multiple of 1 KB, so the address is one XOR away from a per-tile base (no table of eight addresses in registers)
+        const unsigned adk = rowb + (unsigned)((lh ^ (li & 15)) * 16);
         auto rd = [&](int j, f32x4& x0) {
-            const unsigned a = ad[j & 7];
+            const unsigned a = adk ^ (unsigned)(32 * (j & 7));
             if ((j >> 3) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(a) : "memory");
             if ((j >> 3) == 1) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(x0) : "v"(a) : "memory");
             if ((j >> 3) == 2) asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(x0) : "v"(a) : "memory");
@@ -162,9 +232,18 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0) : : "memory");
             if (j + 1 < 32) rd(j + 1, fa[(j + 1) & 1]);
             if (j < 8 && (j & 1) == 0) { if (more) dma_row(t + 1, j >> 1); }
-            if (j >= 8 && j < 16 && (j & 1) == 0) {
+            if (j >= 8 && j < 16 && (j & 1) == 0 && (!OUTV || op.store_hidden)) {
                 const int q = (j - 8) >> 1;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
+            }
+            if (OUTV && t >= 1) {                       // output layer of tile t-1 (its activation is still in `prev`)
+                if (j >= 8 && j < 24) outv_fma(j - 8);
+                if (j >= 7 && j < 23) outv_issue(j - 7);
+                if (j == 25) outv_park(t - 1);
+            }
+            if (OUTV && t >= 2) {                       // ... and the cross-wave sum of tile t-2 (parked during tile t-1, behind this tile's barrier)
+                if (j == 26) outv_fetch(t - 2);
+                if (j == 28) outv_store(t - 2);
             }
             if (DGRAD && j >= 16 && j < 24 && (j & 1) == 0) {
                 const int q = (j - 16) >> 1;
@@ -194,9 +273,26 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         }
         prev_m = m;
     }
-    if (prev_m < rend) {
+    if (prev_m < rend && (!OUTV || op.store_hidden)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
+    }
+    if (OUTV) {                                         // drain the two-tile pipeline of the output layer
+#pragma unroll
+        for (int p_ = 0; p_ < 16; ++p_) {
+            outv_issue(p_);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");
+            outv_fma(p_);
+        }
+        outv_park(ntiles - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int tile = max(ntiles - 2, 0); tile < ntiles; ++tile) {
+            outv_fetch(tile);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");
+            outv_store(tile);
+        }
     }
 }
 
@@ -207,9 +303,30 @@ int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int blocks = tiles < 256 ? tiles : 256;                    // one persistent block per CU
     const int rpb = cdiv(cdiv(p.M, blocks), LF_ROWS) * LF_ROWS;
     const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
-    if (b_trans) k_layer_f32<true, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none);
-    else k_layer_f32<false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none);
+    const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
+    if (b_trans) k_layer_f32<true, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out);
+    else k_layer_f32<false, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out);
     return clift_check_launch("clift_gemm(fp32 layer)");
+}
+
+// LAST hidden layer of an xyz head together with its narrow output layer (E <= 4: the instance heads, tensoRF.py:478-481):
+//   h = relu(W A^T + b) (written to `hidden` only if it is non-null), out[:, 0:E] = h Wout^T + bout.
+extern "C" int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                        const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(E >= 1 && E <= 4, "clift_xyz_head_last2_fwd: E must be in [1,4] (got %d)", E);
+    CLIFT_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= 256 && ldw >= 256,
+                  "clift_xyz_head_last2_fwd: A / W must be 16-byte aligned with pitches >= 256 that are multiples of 4");
+    CLIFT_REQUIRE(hidden == nullptr || ((((uintptr_t)hidden) & 15) == 0 && ldh % 4 == 0 && ldh >= 256), "clift_xyz_head_last2_fwd: hidden must be 16-byte aligned, pitch >= 256");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
+    const int tiles = cdiv(M, LF_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
+    const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
+    const OutP op = {Wout, ldwo, bout, E, out, ldo, hidden != nullptr ? 1 : 0};
+    k_layer_f32<false, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, none, op);
+    return clift_check_launch("clift_xyz_head_last2_fwd");
 }
 
 // First TWO layers of an xyz head in one launch: h2 = relu(W1 relu(W0 x + b0) + b1)   (tensoRF.py:475-478, 576-579), fp32.
@@ -227,7 +344,8 @@ extern "C" int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int l
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
     const GenP gp = {x4, W0, ldw0, b0, h1, ldh1};
-    k_layer_f32<false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, gp);
+    const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
+    k_layer_f32<false, true, false><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, gp, no_out);
     return clift_check_launch("clift_xyz_head_first2_fwd");
 }
 

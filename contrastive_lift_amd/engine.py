@@ -223,6 +223,21 @@ class Branches:
 FUSE_FIRST2 = os.environ.get("CLIFT_FUSE_FIRST2", "1") != "0"     # K = 3 layer generated inside the second layer's kernel (fp32 path)
 
 
+FUSE_LAST2 = os.environ.get("CLIFT_FUSE_LAST2", "1") != "0"       # narrow (E <= 4) output layer applied inside the last hidden layer's kernel
+
+
+def last2(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
+    """One clift_xyz_head_last2_fwd launch: hidden = relu(h W^T + b) (written if not None), out[:, col_off:col_off+E] = hidden Wo^T + bo."""
+    call("clift_xyz_head_last2_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), ptr(Wo), _pitch(Wo), ptr(bo), Wo.shape[0], M, ptr(hidden), 256,
+         C.c_void_p(out.data_ptr() + 4 * col_off), ldo, stream())
+
+
+def first2(M, xa, W0, b0, W1, b1, h1, h2):
+    """One clift_xyz_head_first2_fwd launch: h2 = relu(W1 relu(W0 x + b0) + b1); h1 (or None) receives the first layer's activation.
+    (A module-level function so that bench.py can bracket these launches with events like it does engine.gemm.)"""
+    call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h1), 256, ptr(h2), 256, stream())
+
+
 def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
     """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
     activation) into out[:, col_off:col_off+n_out] with row pitch ldo.
@@ -238,19 +253,28 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         W1, b1 = layers[1]
         h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
-        call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h1), 256, ptr(h), 256, stream())
+        first2(M, xa, W0, b0, W1, b1, h1, h)
         acts += [h1, h]
         rest = layers[2:-1]
     else:
         h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)
         call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
         acts.append(h)
-    for W, b in rest:
+    Wo, bo = layers[-1]
+    fuse_out = (FUSE_LAST2 and MLP_PRECISION == 0 and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
+                and h.dtype == torch.float32 and out.dtype == torch.float32 and os.environ.get("CLIFT_NO_PERSISTENT") is None)
+    for li_, (W, b) in enumerate(rest):
+        if fuse_out and li_ == len(rest) - 1:
+            # last hidden layer + the narrow output layer in one launch; the hidden activation is written only for a backward
+            hn = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
+            last2(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
+            acts.append(hn)
+            return acts if keep_first else [None]
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
         gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
         acts.append(hn)
         h = hn
-    W, b = layers[-1]
+    W, b = Wo, bo
     gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), out, ldo, bias=b, c_off=col_off)
     # no backward through this head: nothing is retained, every hidden activation goes back to the (stream-ordered) allocator as soon
     # as the next layer has been enqueued -- a frame render at 65536 rays per chunk holds ~9 GiB per hidden layer otherwise

@@ -186,6 +186,13 @@ int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b
  * activation when a backward pass will need it.  Results are bit-identical to clift_linear_k3_fwd followed by clift_gemm. */
 int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
                               const float* b1, int M, float* h1, int ldh1, float* h2, int ldh2, clift_stream_t s);
+/* LAST hidden layer of an xyz head together with its narrow output layer (E <= 4 outputs: the instance heads,
+ * tensoRF.py:478-481): h = relu(A W^T + b), out[:, 0:E] = h Wout^T + bout, in one launch -- the output layer is applied to the
+ * tile while it is in registers instead of re-reading the 1 KB-per-row activation.  `hidden` (nullable, (M, ldh)) receives h when
+ * a backward pass will need it.  The E sums are formed in a fixed order (deterministic); they differ from clift_gemm's by
+ * summation order only. */
+int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                             const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s);
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         int dh_bf16 /* dH is bf16-stored */, clift_stream_t s);
