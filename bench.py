@@ -103,7 +103,7 @@ def main():
     # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
-    real_gemm, real_first2, real_last2 = engine.gemm, engine.first2, engine.last2
+    real_gemm, real_first2, real_last2, real_app_last2 = engine.gemm, engine.first2, engine.last2, engine.app_last2
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -132,13 +132,15 @@ def main():
 
         def recorded_last2(M, h, W, b, Wo, *args):        # last hidden layer + narrow output layer (clift_xyz_head_last2_fwd)
             return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2(M, h, W, b, Wo, *args))
-        engine.gemm, engine.first2, engine.last2 = recorded_gemm, recorded_first2, recorded_last2
+        def recorded_app_last2(M, H1, W2, b2, W3, *args):  # appearance: last hidden layer + output layer + sigmoid (clift_app_head_last2_fwd)
+            return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], lambda: real_app_last2(M, H1, W2, b2, W3, *args))
+        engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
-            engine.gemm, engine.first2, engine.last2 = real_gemm, real_first2, real_last2
+            engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32<false,false>: the plain 256 x 256 forward layers) -- few enough events that
     # the step stays GPU-bound, so an event pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the

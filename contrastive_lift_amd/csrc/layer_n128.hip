@@ -20,13 +20,35 @@ constexpr int LN_ROWS = 64;                  // rows per streamed tile (two 32-r
 template <int N>
 static __device__ __forceinline__ void wait_vmn() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KC, bool DGRAD>
-__global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_block) {
+// OUTV (forward, KC = 32): the layer is the last hidden layer of the appearance MLP and the 3-wide output layer + sigmoid
+// (tensoRF.py:395-397,410) is applied to the tile while it is in registers: every lane holds 16 values of its row, 4 x 16 FMAs give its
+// share of the E <= 4 dot products (weights from LDS), a permlane swap folds the half-waves, the four column-waves' shares meet in LDS and
+// 32 lanes of the wave that owns the rows add them in a fixed order, add the bias, apply the sigmoid and store -- spread through the MFMA
+// loops of the two following tiles.  Replaces a launch that re-read the 512 B-per-row activation plus the row-activation launch.
+struct OutN {
+    const float* Wout;    // (E, 128), row pitch ldwo
+    int ldwo;
+    const float* bout;    // (E), nullable
+    int E;
+    float* pre;           // nullable: (M, ldp) pre-activation outputs
+    int ldp;
+    float* out;           // (M, ldo) = sigmoid(pre) when `sigmoid`, else pre
+    int ldo;
+    int sigmoid;
+    int store_hidden;
+};
+constexpr int LN_OUTV_F4 = 128 + 2 * 8 * 32;  // float4: Wout rows padded to 4 x 128 floats + two buffers of 8 waves x 32 rows of shares
+
+template <int KC, bool DGRAD, bool OUTV>
+__global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_block, OutN op) {
     constexpr int NJ = KC / 2;               // contraction steps of 8 k
     constexpr int TILE = LN_ROWS * KC;       // float4 per stage
     constexpr int NDMA = KC / 8;             // LDS-DMA instructions per wave per tile (64 chunks each)
     static_assert(KC % 8 == 0 && NJ >= 16, "K must be a multiple of 32 floats, at least 128");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * TILE];
+    static_assert(!OUTV || (KC == 32 && !DGRAD), "the fused output layer exists for the 128 -> 128 forward layer only");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * TILE + (OUTV ? LN_OUTV_F4 : 0)];
+    float4* const wl4 = lds + 2 * TILE;      // OUTV: wl4[c * 32 + k / 4]
+    float4* const part = wl4 + 128;          // OUTV: part[(tile & 1) * 256 + wave * 32 + row of the wave's half]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wc = wave & 3, wr = wave >> 2;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
@@ -65,6 +87,67 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     };
     float4 prev[4];
     int prev_m = rend;
+    // ---- OUTV state and steps
+    const unsigned wl0 = (unsigned)(uintptr_t)(lds_ptr_t)wl4, part0 = (unsigned)(uintptr_t)(lds_ptr_t)part;
+    const unsigned wlane = wl0 + (unsigned)((8 * wc + lh) * 16);             // this lane's slice of a Wout row: floats 32 wc + 4 lh + 8 q ...
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wv[2][2];
+    if (OUTV) {
+        float* wl = reinterpret_cast<float*>(wl4);
+        for (int e = tid; e < 512; e += 512) { const int c = e >> 7, k = e & 127; wl[e] = c < op.E ? op.Wout[(size_t)c * op.ldwo + k] : 0.f; }
+        __syncthreads();
+    }
+    // pairs p = 4 q + c (column group q, output c), two per k-step: fragments of pairs 2 s, 2 s + 1 are read at k-step s - 1 ...
+    auto outv_issue = [&](int s_) {
+        unsigned b = wlane;
+        asm volatile("" : "+v"(b));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p_ = 2 * s_ + u, q = p_ >> 2, c = p_ & 3;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wv[s_ & 1][u]) : "v"(b + (unsigned)((c * 32 + 2 * q) * 16)) : "memory");
+        }
+    };
+    // ... and used at k-step s (after its lgkmcnt(0))
+    auto outv_fma = [&](int s_) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p_ = 2 * s_ + u, q = p_ >> 2, c = p_ & 3;
+            const f32x4 wq = wv[s_ & 1][u];
+            pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
+        }
+    };
+    auto outv_park = [&](int tile) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned u = __float_as_uint(pv[c]);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            pv[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        if (lh == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(part0 + (unsigned)(((tile & 1) * 256 + wave * 32 + li) * 16)), "v"(pv) : "memory");
+        pv = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // lanes 0..31 of wave w own (row 8 w + lane / 4 of the tile, output lane % 4): the four column-waves' shares of that row
+    auto outv_fetch = [&](int tile) {
+        if (lane < 32) {
+            const int row = 8 * wave + (lane >> 2);
+            unsigned b = part0 + (unsigned)(((tile & 1) * 256 + (4 * (row >> 5)) * 32 + (row & 31)) * 16 + (lane & 3) * 4);
+            asm volatile("" : "+v"(b));
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4)
+                asm volatile("ds_read_b32 %0, %1" : "=v"(wv[0][0][w4]) : "v"(b + (unsigned)(w4 * 32 * 16)) : "memory");
+        }
+    };
+    auto outv_store = [&](int tile) {
+        if (lane < 32) {
+            const int c = lane & 3, mrow = rbeg + tile * LN_ROWS + 8 * wave + (lane >> 2);
+            const float v = ((wv[0][0][0] + wv[0][0][1]) + (wv[0][0][2] + wv[0][0][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
+            if (c < op.E && mrow < rend) {
+                if (op.pre) op.pre[(size_t)mrow * op.ldp + c] = v;
+                op.out[(size_t)mrow * op.ldo + c] = op.sigmoid ? 1.f / (1.f + expf(-v)) : v;
+            }
+        }
+    };
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) dma_piece(0, i);
     for (int t = 0; t < ntiles; ++t) {
@@ -101,9 +184,18 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
             // memory instructions of the tile, one per k-step: next tile's DMA pieces first, then the previous tile's stores, then (dgrad) this
             // tile's mask loads
             if (j < NDMA) { if (more) dma_piece(t + 1, j); }
-            if (j >= NDMA && j < NDMA + 4) {
+            if (j >= NDMA && j < NDMA + 4 && (!OUTV || op.store_hidden)) {
                 const int q = j - NDMA;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
+            }
+            if (OUTV && t >= 1) {                       // output layer of tile t-1 (its activation is still in `prev`)
+                if (j >= 1 && j < 9) outv_fma(j - 1);
+                if (j < 8) outv_issue(j);
+                if (j == 10) outv_park(t - 1);
+            }
+            if (OUTV && t >= 2) {                       // cross-wave sum of tile t-2 (parked during tile t-1, behind this tile's barrier)
+                if (j == 12) outv_fetch(t - 2);
+                if (j == 14) outv_store(t - 2);
             }
             if (DGRAD && j >= NDMA + 4 && j < NDMA + 8) {
                 const int q = j - NDMA - 4;
@@ -134,9 +226,26 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
         }
         prev_m = m;
     }
-    if (prev_m < rend) {
+    if (prev_m < rend && (!OUTV || op.store_hidden)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
+    }
+    if (OUTV) {                                         // drain the two-tile pipeline of the output layer
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            outv_issue(s_);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0][0]), "+v"(wv[0][1]), "+v"(wv[1][0]), "+v"(wv[1][1]) : : "memory");
+            outv_fma(s_);
+        }
+        outv_park(ntiles - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int tile = max(ntiles - 2, 0); tile < ntiles; ++tile) {
+            outv_fetch(tile);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0][0]) : : "memory");
+            outv_store(tile);
+        }
     }
 }
 
@@ -147,11 +256,32 @@ int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(p.M, blocks), LN_ROWS) * LN_ROWS;
     const dim3 grid(cdiv(p.M, rpb));
-    if (p.K == 160 && !b_trans) k_layer_n128<40, false><<<grid, 512, 0, st>>>(p, rpb);
-    else if (p.K == 128 && !b_trans) k_layer_n128<32, false><<<grid, 512, 0, st>>>(p, rpb);
-    else if (p.K == 128 && b_trans) k_layer_n128<32, true><<<grid, 512, 0, st>>>(p, rpb);
+    const OutN no_out = {nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1};
+    if (p.K == 160 && !b_trans) k_layer_n128<40, false, false><<<grid, 512, 0, st>>>(p, rpb, no_out);
+    else if (p.K == 128 && !b_trans) k_layer_n128<32, false, false><<<grid, 512, 0, st>>>(p, rpb, no_out);
+    else if (p.K == 128 && b_trans) k_layer_n128<32, true, false><<<grid, 512, 0, st>>>(p, rpb, no_out);
     else { CLIFT_REQUIRE(false, "clift_gemm(fp32 128-wide layer): unsupported shape K=%d b_trans=%d", p.K, b_trans); }
     return clift_check_launch("clift_gemm(fp32 128-wide layer)");
+}
+
+// Last hidden layer of the appearance MLP + its output layer + sigmoid in one launch (tensoRF.py:395-397,410):
+//   h = relu(A W^T + b) (written to `hidden` if non-null), pre = h Wout^T + bout (written if `pre` non-null), out = sigmoid(pre).
+extern "C" int clift_app_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                        const float* bout, int E, int M, float* hidden, int ldh, float* pre, int ldp, float* out, int ldo,
+                                        int sigmoid, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(E >= 1 && E <= 4, "clift_app_head_last2_fwd: E must be in [1,4] (got %d)", E);
+    CLIFT_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= 128 && ldw >= 128,
+                  "clift_app_head_last2_fwd: A / W must be 16-byte aligned with pitches >= 128 that are multiples of 4");
+    CLIFT_REQUIRE(hidden == nullptr || ((((uintptr_t)hidden) & 15) == 0 && ldh % 4 == 0 && ldh >= 128), "clift_app_head_last2_fwd: hidden must be 16-byte aligned, pitch >= 128");
+    GemmP p = {};
+    p.M = M; p.N = 128; p.K = 128; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
+    const int tiles = cdiv(M, LN_ROWS);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), LN_ROWS) * LN_ROWS;
+    const OutN op = {Wout, ldwo, bout, E, pre, ldp, out, ldo, sigmoid, hidden != nullptr ? 1 : 0};
+    k_layer_n128<32, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, op);
+    return clift_check_launch("clift_app_head_last2_fwd");
 }
 
 // ============================================================================ weight gradient of the same layers, persistent

@@ -232,6 +232,12 @@ def last2(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
          C.c_void_p(out.data_ptr() + 4 * col_off), ldo, stream())
 
 
+def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
+    """One clift_app_head_last2_fwd launch: H2 = relu(H1 W2^T + b2) (written if not None), rgb = sigmoid(H2 W3^T + b3)."""
+    call("clift_app_head_last2_fwd", ptr(H1), H1.shape[1], ptr(W2), _pitch(W2), ptr(b2), ptr(W3), _pitch(W3), ptr(b3), W3.shape[0], M,
+         ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
+
+
 def first2(M, xa, W0, b0, W1, b1, h1, h2):
     """One clift_xyz_head_first2_fwd launch: h2 = relu(W1 relu(W0 x + b0) + b1); h1 (or None) receives the first layer's activation.
     (A module-level function so that bench.py can bracket these launches with events like it does engine.gemm.)"""
@@ -393,13 +399,19 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                  ptr(X), ldx, int(hdt == torch.bfloat16), stream())
             H1 = torch.empty((M, W1.shape[0]), dtype=hdt, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
-            H2 = torch.empty((M, W2.shape[0]), dtype=hdt, device=dev)
-            gemm(M, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
-            pre = torch.empty((M, 3), dtype=torch.float32, device=dev)
-            gemm(M, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
-            call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, stream())
-            keep.append(pre)
+            if (FUSE_LAST2 and MLP_PRECISION == 0 and hdt == torch.float32 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4 and W3.shape[1] == 128
+                    and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+                # second hidden layer + output layer + sigmoid in one launch; H2 is written only for a backward
+                H2 = torch.empty((M, 128), dtype=torch.float32, device=dev) if "app" in grad_heads else None
+                app_last2(M, H1, W2, b2, W3, b3, H2, rgb_s)
+            else:
+                H2 = torch.empty((M, W2.shape[0]), dtype=hdt, device=dev)
+                gemm(M, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
+                pre = torch.empty((M, 3), dtype=torch.float32, device=dev)
+                gemm(M, 3, W3.shape[1], H2, H2.shape[1], W3, _pitch(W3), pre, 3, bias=b3)
+                call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, stream())
+                keep.append(pre)
             ctx.rgb_s = rgb_s
             if "app" in grad_heads:
                 ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2 = feat, ldf, nf, X, ldx, H1, H2

@@ -193,6 +193,12 @@ int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const 
  * summation order only. */
 int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
                              const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s);
+/* Last hidden layer of the appearance MLP + its output layer + sigmoid in one launch (tensoRF.py:395-397,410; 128-wide, fp32):
+ * h = relu(A W^T + b) (written to `hidden` if non-null), pre = h Wout^T + bout (written if `pre` non-null), out = sigmoid ?
+ * 1/(1+exp(-pre)) : pre.  E <= 4.  Deterministic; differs from clift_gemm + clift_rows_act_fwd by summation order only. */
+int clift_app_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                             const float* bout, int E, int M, float* hidden, int ldh, float* pre, int ldp, float* out, int ldo,
+                             int sigmoid, clift_stream_t s);
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         int dh_bf16 /* dH is bf16-stored */, clift_stream_t s);

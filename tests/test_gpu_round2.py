@@ -476,3 +476,30 @@ def test_xyz_head_last_two_layers_fused(M, E):
         got = out[:M, 1:1 + E].double().cpu()
         assert float(((got - ref).abs() / scale).max()) <= 2e-6, (M, E, keep)
         assert bool((out[M:] == -7.0).all()) and bool((out[:, 0] == -7.0).all()) and bool((out[:, 1 + E:] == -7.0).all())
+
+
+@pytest.mark.parametrize("M", [1, 63, 65, 130, 5000, 70001])
+def test_appearance_head_last_two_layers_fused(M):
+    """clift_app_head_last2_fwd (128 -> 128 + ReLU, 128 -> 3, sigmoid in one launch) against clift_gemm x 2 + clift_rows_act_fwd: the
+    hidden activation bit-identical, rgb to summation-order round-off (vs fp64), with and without writing the hidden activation."""
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(M * 3 + 1)
+    H1 = torch.relu(torch.randn((M, 128), generator=g))
+    W2 = (torch.randn((128, 128), generator=g) / 11).contiguous()
+    b2 = torch.randn(128, generator=g) * 0.2
+    W3 = (torch.randn((3, 128), generator=g) / 8).contiguous()
+    b3 = torch.randn(3, generator=g) * 0.3
+    H1d, W2d, b2d, W3d, b3d = (t.to(DEV) for t in (H1, W2, b2, W3, b3))
+    H2_ref = torch.empty((M, 128), device=DEV)
+    engine.gemm(M, 128, 128, H1d, 128, W2d, 128, H2_ref, 128, bias=b2d, act=1)
+    pre = H2_ref.double().cpu() @ W3.double().T + b3.double()
+    ref = torch.sigmoid(pre)
+    for keep in (True, False):
+        H2 = torch.full((M, 128), float("nan"), device=DEV) if keep else None
+        rgb = torch.full((M + 1, 3), -7.0, device=DEV)
+        engine.app_last2(M, H1d, W2d, b2d, W3d, b3d, H2, rgb)
+        if keep:
+            assert torch.equal(H2, H2_ref)
+        rel_close(rgb[:M], ref, 1e-5, atol=2e-6, what=f"fused appearance output M={M}")
+        assert bool((rgb[M:] == -7.0).all())
