@@ -362,8 +362,9 @@ extern "C" int clift_composite_fwd(const float* w, const int* ray_start, const i
     k_composite_sum<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(w, ray_start, act_idx, N, C, D, rgb_s, sem_s, inst_s, rgb_raw, sem_raw, inst_map);
     int rc = clift_check_launch("clift_composite_fwd(sum)");
     if (rc) return rc;
-    k_composite_finish<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(N, C, ray_out, softmax_mode, white_bg, rgb_s ? rgb_raw : nullptr, rgb_map,
-                                                                sem_s ? sem_raw : nullptr, sem_map);
+    // (a chunk without a single active sample passes NULL heads: its sums are the caller's zeros and are finished all the same --
+    // white background, clamp, log-normalisation of an all-zero semantic sum, renderer.py:160-167)
+    k_composite_finish<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(N, C, ray_out, softmax_mode, white_bg, rgb_raw, rgb_map, C > 0 ? sem_raw : nullptr, sem_map);
     return clift_check_launch("clift_composite_fwd(finish)");
 }
 

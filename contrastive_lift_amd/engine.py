@@ -471,19 +471,6 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
     return out, ctx
 
 
-def _finish_empty(ctx, rgb_raw, rgb_map, sem_raw, sem_map):
-    """Compositing of a chunk with zero active samples, done with the same finishing kernel semantics."""
-    if rgb_map is not None:
-        add = (1.0 - ctx.ray_out[:, 0:1]) if ctx.white_bg else 0.0
-        rgb_raw.copy_(rgb_raw + add)
-        rgb_map.copy_(rgb_raw.clamp(0, 1))
-    if sem_map is not None:
-        if ctx.softmax_mode:
-            sem_map.copy_(torch.log(sem_raw / (sem_raw.sum(-1, keepdim=True) + 1e-8) + 1e-8))
-        else:
-            sem_map.copy_(sem_raw)
-
-
 # ----------------------------------------------------------------------------- backward
 def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_dist=None, density_grad=True,
                     slow_grad=False):
@@ -655,8 +642,6 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
     inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D else None
     call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls, D, None, ptr(ctx.sem_s), ptr(ctx.inst_s),
          ptr(ctx.ray_out), ctx.softmax_mode, 0, None, None, ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
-    if M == 0 and sem_map is not None:
-        _finish_empty(ctx, None, None, sem_raw, sem_map)
     ctx.sem_raw = sem_raw
     ctx.want = (False, head == "semantic", head == "instance")
     if head == "instance":
