@@ -463,7 +463,6 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
         call("clift_composite_fwd", None, ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D,
              None, None, None, ptr(ctx.ray_out), softmax_mode, ctx.white_bg,
              ptr(rgb_raw), ptr(rgb_map), ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
-        _finish_empty(ctx, rgb_raw, rgb_map, sem_raw, sem_map)
     ctx.rgb_raw, ctx.sem_raw = rgb_raw, sem_raw
     ctx.want = (want_rgb, want_sem, D > 0)
     out = dict(rgb=rgb_map, semantics=sem_map, instances=inst_map, depth=ctx.ray_out[:, 1],
