@@ -16,6 +16,7 @@
 // Used for (reference tensoRF.py): basis Linear :65, appearance MLP :393-397, instance MLPs :475-491,
 // semantic MLP :576-582 -- forward (A = activations, B = weight (out,in)), dgrad (B transposed), wgrad
 // (both transposed, reduction over the sample dimension split over blockIdx.z with atomic accumulation).
+#include <cstring>
 #include "gemm_common.h"
 
 constexpr int BK = 32;
@@ -254,9 +255,13 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         (((uintptr_t)h->mask) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_dgrad_narrow_stream_launch(p, 0, st);          // output-layer dgrad: a stream over the mask and the result
     // (up to ~150 k rows: beyond that the split-K tiled launch, whose k-loop is long by then, is as fast or faster: 304 vs 332 us at 249 k)
-    if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->K < 160000 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
-        h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
-        return clift_wgrad_f32_stream_launch(p, st);                // persistent 2-D weight gradient (row ranges x column slices)
+    if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
+        h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr) {
+        const char* mode = getenv("CLIFT_WGRAD256");                // A/B switch: "quads" | "slices" | "tiled"; default below
+        if (mode && !strcmp(mode, "quads")) return clift_wgrad_f32_quads_launch(p, st);
+        if (mode && !strcmp(mode, "slices")) return clift_wgrad_f32_stream_launch(p, st);
+        if (!mode && h->K < 160000) return clift_wgrad_f32_stream_launch(p, st);   // persistent 2-D weight gradient (row ranges x column slices)
+    }
     // weight gradients of the 128-wide appearance layers (128 x 128 and 128 x 160 results): persistent row-range stream
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 128 && (h->N == 128 || h->N == 160) && h->ldb >= h->N && h->lda >= 128 && h->K >= 4096 &&
         h->accumulate && !h->c_trans && !h->bias && !h->mask && h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)

@@ -293,7 +293,7 @@ extern "C" int clift_app_head_last2_fwd(const float* A, int lda, const float* W,
 // in a lane-linear image).  The block ends with ONE 128 x K partial added to gW (20 k atomics per block instead of the 64 k of a
 // split-K tile launch).  The tiled split-K launch it replaces ran at ~50 TFLOP/s on these shapes.
 template <int KXC>
-__global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_per_range) {
+__global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_per_range, int quads) {
     constexpr int ROWS = 64;
     constexpr int YB = ROWS * 512, XB = ROWS * KXC * 16, STAGE = YB + XB;     // bytes
     constexpr int NT = (KXC == 40) ? 3 : 2;                                   // accumulator tiles per wave (KXC = 40: 3 + 2 over the two wk)
@@ -303,11 +303,18 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     const int wn = wave & 3, wk = wave >> 2;
     const int tile0 = (KXC == 40) ? 3 * wk : 2 * wk;                          // first X column tile of this wave
     const int ntile = (KXC == 40 && wk == 1) ? 2 : NT;
-    const int rbeg = blockIdx.x * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
+    // quads == 1: the block owns a row range and the whole 128 x K result.  quads == 4 (256 x 256 results, KXC = 32): block b owns quadrant
+    // (b >> 3) & 3 of the result -- dY columns 128 (quad >> 1) .., X columns 128 (quad & 1) .. -- for row range (b & 7) + 8 (b >> 5): the four
+    // quadrant-blocks of a range have ids 8 apart, i.e. share an XCD, so dY and X are fetched from HBM once and re-read from that L2
+    const int b = blockIdx.x;
+    const int quad = quads == 4 ? (b >> 3) & 3 : 0, range = quads == 4 ? (b & 7) + 8 * (b >> 5) : b;
+    const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + ROWS - 1) / ROWS;
-    const float* __restrict__ Y = g.A;            // dY (rows, 128), pitch lda
-    const float* __restrict__ X = g.B;            // X (rows, 4 KXC), pitch ldb
+    const float* __restrict__ Y = g.A + 128 * (quad >> 1);            // dY (rows, 128 of lda)
+    const float* __restrict__ X = g.B + 128 * (quad & 1);             // X (rows, 4 KXC of ldb)
+    float* __restrict__ Cq = g.C + (size_t)(128 * (quad >> 1)) * g.ldc + 128 * (quad & 1);
+    const int ncols = quads == 4 ? 128 : g.N;
     auto dma = [&](int t) {
         const int r0 = rbeg + t * ROWS;
         unsigned char* st = lds + (t & 1) * STAGE;
@@ -378,20 +385,27 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     for (int x = 0; x < NT; ++x) {
         if (x >= ntile) continue;
         const int col = 32 * (tile0 + x) + li;
-        if (col >= g.N) continue;
+        if (col >= ncols) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = 32 * wn + 8 * (r >> 2) + 4 * lh + (r & 3);
-            unsafeAtomicAdd(g.C + (size_t)n * g.ldc + col, acc[x][r]);
+            unsafeAtomicAdd(Cq + (size_t)n * g.ldc + col, acc[x][r]);
         }
     }
-    if (g.colsum && wk == 0) {
+    if (g.colsum && wk == 0 && (quad & 1) == 0) {      // (one of the two quadrants that saw these dY columns adds the bias gradient)
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const unsigned u = __float_as_uint(bsum);
         const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (lh == 0) unsafeAtomicAdd(g.colsum + 32 * wn + li, tot);
+        if (lh == 0) unsafeAtomicAdd(g.colsum + 128 * (quad >> 1) + 32 * wn + li, tot);
     }
+}
+
+// The 256 x 256 weight gradient as four 128 x 128 quadrants of the same kernel (64 row ranges x 4 quadrant-blocks = 256 blocks).
+int clift_wgrad_f32_quads_launch(const GemmP& p, hipStream_t st) {
+    const int rpr = cdiv(cdiv(p.K, 64), 64) * 64;
+    k_wgrad_n128_stream<32><<<256, 512, 0, st>>>(p, rpr, 4);
+    return clift_check_launch("clift_gemm(fp32 wgrad quadrants)");
 }
 
 // Eligibility decided by the caller (gemm.hip): wgrad form (a_trans, b_trans, accumulate) with a 128 x N result, N in {128, 160} (N <= ldb:
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
 int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st) {
     const int rpr = cdiv(cdiv(p.K, 256), 64) * 64;
     const dim3 grid(cdiv(p.K, rpr));
-    if (p.N > 128) k_wgrad_n128_stream<40><<<grid, 512, 0, st>>>(p, rpr);
-    else k_wgrad_n128_stream<32><<<grid, 512, 0, st>>>(p, rpr);
+    if (p.N > 128) k_wgrad_n128_stream<40><<<grid, 512, 0, st>>>(p, rpr, 1);
+    else k_wgrad_n128_stream<32><<<grid, 512, 0, st>>>(p, rpr, 1);
     return clift_check_launch("clift_gemm(fp32 128-wide wgrad stream)");
 }

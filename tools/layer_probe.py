@@ -41,3 +41,16 @@ for K in (128, 160):
     f = lambda: engine.wgrad(128, K, M, dY, 128, X, K, gW, gb)
     t = timeit(f); os.environ["CLIFT_NO_PERSISTENT"] = "1"; t0 = timeit(f); del os.environ["CLIFT_NO_PERSISTENT"]
     print(f"wgrad 128x{K} M={M}: persistent {t:7.1f} us ({2.0*M*128*K/t/1e6:6.1f} TF)   tiled {t0:7.1f} us ({2.0*M*128*K/t0/1e6:6.1f} TF)")
+for Mw in sorted({M, 62000}):
+    dY = torch.randn(Mw, 256, device=dev); X = torch.relu(torch.randn(Mw, 256, device=dev)); gW = torch.zeros(256, 256, device=dev); gb = torch.zeros(256, device=dev)
+    f = lambda: engine.wgrad(256, 256, Mw, dY, 256, X, 256, gW, gb)
+    res = {}
+    for mode in ("tiled", "slices", "quads"):
+        os.environ["CLIFT_WGRAD256"] = mode
+        res[mode] = timeit(f)
+    del os.environ["CLIFT_WGRAD256"]
+    print(f"wgrad 256x256 M={Mw}: " + "   ".join(f"{k} {v:7.1f} us ({2.0*Mw*65536/v/1e6:6.1f} TF)" for k, v in res.items()))
+    # correctness of the quadrant form against the tiled one
+    os.environ["CLIFT_WGRAD256"] = "quads"; gW.zero_(); gb.zero_(); f(); a = gW.clone(); ab = gb.clone()
+    os.environ["CLIFT_WGRAD256"] = "tiled"; gW.zero_(); gb.zero_(); f(); del os.environ["CLIFT_WGRAD256"]
+    print("   quads vs tiled: max rel diff", float((a - gW).abs().max() / gW.abs().max()), "bias", float((ab - gb).abs().max() / gb.abs().max()))
