@@ -189,8 +189,10 @@ def test_full_size_backward_vs_oracle():
         got = torch.zeros_like(ref) if gr is None else gr.detach().cpu()
         # all but 0.1 % of the entries within 2e-3 relative + 1e-4 of the tensor's scale; those few (a sample whose weight sits on the
         # 1e-4 activity threshold, or a hidden unit on the ReLU kink, lands on the other side: one such sample moves the 48 channels of
-        # the texels it touches) within 1e-2 of the scale (observed 1e-3 .. 4e-3 depending on the kernels' summation order)
-        grad_close(got, ref, what=f"full-size grad {k}", rtol=2e-3, scale_atol=1e-4, outlier_frac=1e-3, outlier_cap=1e-2)
+        # the texels it touches -- hence 0.5 % for the table gradients) within 1e-2 of the scale (observed 1e-3 .. 4e-3 depending on the
+        # kernels' summation order; tools/ab_persistent.py shows the same handful of entries between two GPU kernel sets)
+        grad_close(got, ref, what=f"full-size grad {k}", rtol=2e-3, scale_atol=1e-4,
+                   outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-3), outlier_cap=1e-2)
         n += 1
     assert n >= 38
 
