@@ -254,13 +254,18 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         !h->accumulate && !h->c_trans && h->mask && !h->bias && h->act == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && h->ldmask % 4 == 0 &&
         (((uintptr_t)h->mask) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_dgrad_narrow_stream_launch(p, 0, st);          // output-layer dgrad: a stream over the mask and the result
+    if (h->precision == 0 && !h->a_trans && h->b_trans && h->N <= 256 && h->N % 4 == 0 && h->N > 32 && h->K <= 32 && h->K <= h->lda && h->lda <= 32 && h->M >= 4096 &&
+        splits == 1 && !h->accumulate && !h->c_trans && !h->mask && !h->bias && h->act == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 &&
+        getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_dgrad_narrow_stream_launch(p, 0, st);          // unmasked narrow-K dgrad (appearance basis 27 -> 144): a stream over the result
     // (up to ~150 k rows: beyond that the split-K tiled launch, whose k-loop is long by then, is as fast or faster: 304 vs 332 us at 249 k)
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
         h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr) {
-        const char* mode = getenv("CLIFT_WGRAD256");                // A/B switch: "quads" | "slices" | "tiled"; default below
-        if (mode && !strcmp(mode, "quads")) return clift_wgrad_f32_quads_launch(p, st);
-        if (mode && !strcmp(mode, "slices")) return clift_wgrad_f32_stream_launch(p, st);
-        if (!mode && h->K < 160000) return clift_wgrad_f32_stream_launch(p, st);   // persistent 2-D weight gradient (row ranges x column slices)
+        // persistent 2-D weight gradient.  Default: 64 row ranges x four 128 x 128 quadrants, 64-row tiles (layer_n128.hip) -- 92 / 318 us at
+        // 62 k / 249 k rows; the older 256 x 64 slices with 32-row tiles (layer_f32.hip): 95 / 340; the split-K tiled launch: 127 / 349.
+        const char* mode = getenv("CLIFT_WGRAD256");                // A/B switch: "quads" | "slices" | "tiled"
+        if (!mode || !strcmp(mode, "quads")) return clift_wgrad_f32_quads_launch(p, st);
+        if (!strcmp(mode, "slices")) return clift_wgrad_f32_stream_launch(p, st);
     }
     // weight gradients of the 128-wide appearance layers (128 x 128 and 128 x 160 results): persistent row-range stream
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 128 && (h->N == 128 || h->N == 160) && h->ldb >= h->N && h->lda >= 128 && h->K >= 4096 &&

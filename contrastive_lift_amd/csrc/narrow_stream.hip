@@ -165,7 +165,9 @@ int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M,
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
-template <int KJ, bool HB>
+// MASK = false (fp32 only): plain dX = dOut W with N = g.N <= 256 output columns (a multiple of 4): the dgrad of the appearance basis
+// (27 -> 144, tensoRF.py:65,127-134), which the tiled kernel ran at 1.4 TB/s.  Waves whose 32 columns lie past N only help with the DMA.
+template <int KJ, bool HB, bool MASK>
 __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block) {
     constexpr int ROWS = 32, TILEB = ROWS * 32 * 4;                          // stage: up to 32 rows x 32 floats
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB];   // the only LDS object
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = 8 * j + 4 * lh + i;
-            v[i] = k < K ? g.B[(size_t)k * g.ldb + 32 * wave + li] : 0.f;
+            v[i] = (k < K && 32 * wave + li < g.N) ? g.B[(size_t)k * g.ldb + 32 * wave + li] : 0.f;
         }
         w[j] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -200,17 +202,20 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     unsigned foff[KJ];        // fragment (row li, k = 8 j + 4 lh .. +3); a fragment past the row (its weights are zero) re-reads k = 0..3
 #pragma unroll
     for (int j = 0; j < KJ; ++j) foff[j] = (unsigned)((li * lda + ((8 * j + 4 * lh + 3 < lda) ? 8 * j + 4 * lh : 0)) * 4);
+    const bool full_wave = 32 * wave + 32 <= g.N;                            // all four column groups of this wave are stored
     dma(0);
     for (int t = 0; t < ntiles; ++t) {
-        // the previous epilogue waited for everything older than its stores, the DMA of this tile included
-        if (t > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // MASK: the previous epilogue waited for everything older than its stores, the DMA of this tile included.  !MASK: the DMA of this tile
+        // is older than the previous tile's stores -- four of them in a wave that stores all its column groups, otherwise drain
+        if (t > 0 && (MASK || full_wave)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < ntiles) dma(t + 1);
         const int m = rbeg + t * ROWS + li;
         f32x4 mk[4];
         u32x2v mh[4];
-        if (!HB) {
+        if (!MASK) {
+        } else if (!HB) {
             const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
                          "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
@@ -236,13 +241,17 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, fa[j].z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, fa[j].w, acc1, 0, 0, 0);
         }
-        if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
+        if (!MASK) {
+        } else if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mh[0]), "+v"(mh[1]), "+v"(mh[2]), "+v"(mh[3]) : : "memory");
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float o[4] = {acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
                           acc0[4 * q + 3] + acc1[4 * q + 3]};
-            if (!HB) {
+            if (!MASK) {
+                if (m < rend && 32 * wave + 8 * q + 4 * lh + 3 < g.N)
+                    *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + 32 * wave + 8 * q + 4 * lh) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (!HB) {
                 o[0] = mk[q].x > 0.f ? o[0] : 0.f; o[1] = mk[q].y > 0.f ? o[1] : 0.f;
                 o[2] = mk[q].z > 0.f ? o[2] : 0.f; o[3] = mk[q].w > 0.f ? o[3] : 0.f;
                 if (m < rend) *reinterpret_cast<float4*>(g.C + (size_t)m * g.ldc + 32 * wave + 8 * q + 4 * lh) = make_float4(o[0], o[1], o[2], o[3]);
@@ -260,8 +269,9 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     }
 }
 
-// Eligibility decided by the callers (gemm.hip / gemm_bf16.hip): plain fp32 A with lda in {4, 8, .., 32} = its row pitch, K <= lda, N = 256,
-// b_trans weights, a mask, no bias / activation, M >= 4096; half = bf16-stored mask and output.
+// Eligibility decided by the callers (gemm.hip / gemm_bf16.hip): plain fp32 A with lda in {4, 8, .., 32} = its row pitch, K <= lda, b_trans
+// weights, no bias / activation, M >= 4096, and either N = 256 with a mask (half = bf16-stored mask and output) or no mask, fp32, N <= 256,
+// N % 4 == 0.
 int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
     const int tiles = cdiv(p.M, 32);
     const int blocks = tiles < 256 ? tiles : 256;
@@ -270,8 +280,9 @@ int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
     const int kj = cdiv(p.K, 8);
 #define CLIFT_DN(KJ)                                                                                     \
     do {                                                                                                 \
-        if (half) k_dgrad_narrow_stream<KJ, true><<<grid, 512, 0, st>>>(p, rpb);                         \
-        else k_dgrad_narrow_stream<KJ, false><<<grid, 512, 0, st>>>(p, rpb);                             \
+        if (!p.mask) k_dgrad_narrow_stream<KJ, false, false><<<grid, 512, 0, st>>>(p, rpb);              \
+        else if (half) k_dgrad_narrow_stream<KJ, true, true><<<grid, 512, 0, st>>>(p, rpb);              \
+        else k_dgrad_narrow_stream<KJ, false, true><<<grid, 512, 0, st>>>(p, rpb);                       \
     } while (0)
     if (kj <= 1) CLIFT_DN(1);
     else if (kj == 2) CLIFT_DN(2);
