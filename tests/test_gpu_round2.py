@@ -505,3 +505,20 @@ def test_appearance_head_last_two_layers_fused(M):
             assert torch.equal(H2, H2_ref)
         rel_close(rgb[:M], ref, 1e-5, atol=2e-6, what=f"fused appearance output M={M}")
         assert bool((rgb[M:] == -7.0).all())
+
+
+@pytest.mark.parametrize("M", [4096, 4129, 70001])
+def test_unmasked_narrow_dgrad_stream(M):
+    """k_dgrad_narrow_stream<.., MASK = false>: dF = dfeat Wb (K = 27 in a 28-float pitch -> N = 144), the dgrad of the appearance basis,
+    against fp64; pad column of dfeat holds garbage-free zeros in the pipeline but is given non-zero values here (its weights are
+    zero past K); rows beyond M and columns beyond N untouched; and N = 256, K = 22."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M)
+    for N, K, lda in ((144, 27, 28), (256, 22, 24), (64, 3, 4)):
+        A = torch.randn((M, lda), generator=g)
+        W = (torch.randn((K, N), generator=g) / 4).contiguous()
+        out = torch.full((M + 2, N + 4), -7.0, device=DEV)
+        engine.gemm(M, N, K, A.to(DEV), lda, W.to(DEV), N, out, N + 4, b_trans=1)
+        ref = A[:, :K].double() @ W.double()
+        rel_close(out[:M, :N], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what=f"unmasked narrow dgrad N={N} K={K}")
+        assert bool((out[M:] == -7.0).all()) and bool((out[:, N:] == -7.0).all())
