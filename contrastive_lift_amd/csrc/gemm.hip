@@ -250,7 +250,7 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         h->mask && !h->bias && h->act == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0 &&
         getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_layer_f32_launch(p, 1, st);                    // persistent masked dgrad of the same layers
-    if (h->precision == 0 && !h->a_trans && h->b_trans && h->N == 256 && h->K <= 32 && h->K <= h->lda && h->lda <= 32 && h->M >= 4096 && splits == 1 &&
+    if (h->precision == 0 && !h->a_trans && h->b_trans && (h->N == 256 || h->N == 128) && h->K <= 32 && h->K <= h->lda && h->lda <= 32 && h->M >= 4096 && splits == 1 &&
         !h->accumulate && !h->c_trans && h->mask && !h->bias && h->act == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && h->ldmask % 4 == 0 &&
         (((uintptr_t)h->mask) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_dgrad_narrow_stream_launch(p, 0, st);          // output-layer dgrad: a stream over the mask and the result

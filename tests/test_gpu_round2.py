@@ -523,3 +523,18 @@ def test_unmasked_narrow_dgrad_stream(M):
         ref = A[:, :K].double() @ W.double()
         rel_close(out[:M, :N], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what=f"unmasked narrow dgrad N={N} K={K}")
         assert bool((out[M:] == -7.0).all()) and bool((out[:, N:] == -7.0).all())
+
+
+@pytest.mark.parametrize("M", [4096, 4129, 70001])
+def test_masked_narrow_dgrad_stream_128_wide(M):
+    """k_dgrad_narrow_stream with N = 128: dH2 = mask(H2) . (dpre W3), the dgrad of the appearance output layer (K = 3 in a 4-float pitch)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 1)
+    A = torch.randn((M, 4), generator=g); A[:, 3] = 0
+    W = (torch.randn((3, 128), generator=g) / 2).contiguous()
+    mask = torch.randn((M, 128), generator=g)
+    out = torch.full((M + 2, 132), -7.0, device=DEV)
+    engine.gemm(M, 128, 3, A.to(DEV), 4, W.to(DEV), 128, out, 132, b_trans=1, mask=mask.to(DEV), ldmask=128)
+    ref = (A[:, :3].double() @ W.double()) * (mask.double() > 0)
+    rel_close(out[:M, :128], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="masked narrow dgrad N=128")
+    assert bool((out[M:] == -7.0).all()) and bool((out[:, 128:] == -7.0).all())
