@@ -142,10 +142,11 @@ def main():
         finally:
             engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
         return out
-    # pass 1: only the dominant kernel's launches (k_layer_f32<false,false>: the plain 256 x 256 forward layers) -- few enough events that
-    # the step stays GPU-bound, so an event pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the
-    # informational all_gemm split (the ~80 events per step make that pass host-bound, so its per-launch times are upper bounds).
-    rec = replay(lambda kind, N: kind == "fwd" and N > 128)
+    # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
+    # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays
+    # GPU-bound, so an event pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the informational all_gemm
+    # split (the ~60 events per step make that pass host-bound, so its per-launch times are upper bounds).
+    rec = replay(lambda kind, N: kind in ("fwd", "fwd_gen", "fwd_out") and N > 128)
     rec_all = replay(lambda kind, N: True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -278,8 +279,12 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
         tot_ms += ms
         b = by.setdefault(kind, [0.0, 0.0, 0])
         b[0] += fl; b[1] += ms; b[2] += 1
+    inst = {}
     for kind, M, N, K, e0, e1, xf in rec_dom:
-        dom_f += 2.0 * M * N * K; dom_ms += e0.elapsed_time(e1); dom_n += 1
+        ms = e0.elapsed_time(e1)
+        dom_f += 2.0 * M * N * K + xf; dom_ms += ms; dom_n += 1
+        b = inst.setdefault(kind, [0.0, 0.0, 0])
+        b[0] += 2.0 * M * N * K + xf; b[1] += ms; b[2] += 1
     tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ach = tf(dom_f, dom_ms)
     if dtype == "bf16":
@@ -294,11 +299,18 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
                 "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
                              "gflop_per_step": tot_f / 1e9 / nb,
                              "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
-    alg_bytes = (dom_f / max(1, dom_n)) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
+    # algorithmic bytes of the average launch: the plain instantiation reads a 1 KB row and writes one per sample; the generating one reads
+    # 16 B and writes 1 KB (2 KB when the first layer's activation is kept); the output-fused one reads 1 KB and writes 16 B (+ 1 KB when kept).
+    # Reported for the plain instantiation, the one the counter passes measured (8 B per output element + 256 KB weights).
+    plain = inst.get("fwd", [dom_f, dom_ms, dom_n])
+    alg_bytes = (plain[0] / max(1, plain[2])) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
     pmc = measured_traffic_ratio()
-    out = {"bound": "mfma", "kernel": "k_layer_f32<false, false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel; the 256x256 forward MLP layers whose input is "
-                                      "streamed from memory -- the first 256x256 layer of each head runs as k_layer_f32<false, true>, which generates its K = 3 input, "
-                                      "and is listed under all_gemm.by_kind.fwd_gen)",
+    names = {"fwd": "k_layer_f32<false, false, false>", "fwd_gen": "k_layer_f32<false, true, false>", "fwd_out": "k_layer_f32<false, false, true>"}
+    out = {"bound": "mfma", "kernel": "k_layer_f32<false, *, *> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel: the 256x256 forward MLP layers of the xyz heads, "
+                                      "11 launches per step in three instantiations -- input streamed from memory / K = 3 input layer generated in-kernel / narrow "
+                                      "output layer applied in-kernel; rocprofv3 lists them separately: see `instantiations`)",
+           "instantiations": {names[k]: {"tflops": tf(v[0], v[1]), "frac": tf(v[0], v[1]) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": v[2] // nb,
+                                         "avg_launch_ms": v[1] / max(1, v[2])} for k, v in inst.items()},
            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
            # HBM bytes per (average) launch of the dominant kernel: algorithmic bytes of THIS run's average launch (A read once + C
            # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on

@@ -610,8 +610,10 @@ def test_forward_backward_vs_oracle_mid(mode, white):
         # (observed: one row of one 256 x 256 gradient differs by 4e-4 of its scale between the tiled and the persistent forward
         # kernel, everything else to 1e-6)
         # (table gradients: one such sample touches 2 line texels x 16 / 48 channels per plane, i.e. ~10 entries of a 2688-entry line
-        # table at once -- hence the 0.5 % allowance there)
-        grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-4, outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-3),
+        # table at once
+        # table entries at once -- hence the 0.5 % allowance there, 1 % for the 27 x 144 basis matrix right behind the tables)
+        grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-4,
+                   outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-2 if k.startswith("appearance_basis") else 1e-3),
                    outlier_cap=1e-3)
 
 
