@@ -61,6 +61,7 @@ _SIGNATURES = {
     "clift_xyz_head_first2_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_xyz_head_last2_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_app_head_last2_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P], C.c_int),
+    "clift_xyz_head_bf16_fwd": ([_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "clift_alpha_bbox": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P], C.c_int),
     "clift_vm_products_points": ([_P, _P, _I, _L, _P, _P], C.c_int),
     "clift_app_encode_points": ([_P, _I, _I, _I, _I, _P, _I, _L, _P, _I, _P], C.c_int),

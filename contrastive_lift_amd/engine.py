@@ -238,6 +238,18 @@ def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
          ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
 
 
+FUSE_HEAD_BF16 = os.environ.get("CLIFT_FUSE_HEAD_BF16", "1") != "0"   # bf16 mode: first three layers (+ narrow output layer) of an xyz head in one launch
+
+
+def head_bf16(M, xa, l0, l1, l2, lout, h1, h2, h3, out, ldo, col_off):
+    """One clift_xyz_head_bf16_fwd launch (csrc/head_bf16.hip)."""
+    (W0, b0), (W1, b1), (W2, b2) = l0, l1, l2
+    Wo, bo = lout if lout is not None else (None, None)
+    call("clift_xyz_head_bf16_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), ptr(W2), _pitch(W2), ptr(b2),
+         ptr(Wo), _pitch(Wo) if Wo is not None else 0, ptr(bo), Wo.shape[0] if Wo is not None else 0, M, ptr(h1), ptr(h2), ptr(h3),
+         C.c_void_p(out.data_ptr() + 4 * col_off) if lout is not None else None, ldo, stream())
+
+
 def first2(M, xa, W0, b0, W1, b1, h1, h2):
     """One clift_xyz_head_first2_fwd launch: h2 = relu(W1 relu(W0 x + b0) + b1); h1 (or None) receives the first layer's activation.
     (A module-level function so that bench.py can bracket these launches with events like it does engine.gemm.)"""
@@ -254,7 +266,22 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
     W0, b0 = layers[0]
     hdt = act_dtype()                     # bf16 mode stores the hidden activations as bf16 (half the HBM stream of these layers)
     rest = layers[1:-1]
-    if (FUSE_FIRST2 and MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
+    if (FUSE_HEAD_BF16 and MLP_PRECISION == 1 and hdt == torch.bfloat16 and len(layers) >= 4 and W0.shape[0] == 256
+            and tuple(layers[1][0].shape) == (256, 256) and tuple(layers[2][0].shape) == (256, 256) and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+        # bf16 mode: K = 3 layer + two hidden layers (+ the output layer when it is <= 4 wide and follows directly) in one launch with the
+        # activations resident in LDS; they are written (bf16) only for a backward pass
+        Wo, bo = layers[-1]
+        with_out = len(layers) == 4 and Wo.shape[0] <= 4 and out.dtype == torch.float32
+        mk = lambda: torch.empty((M, 256), dtype=torch.bfloat16, device=dev)
+        h1, h2 = (mk(), mk()) if keep_first else (None, None)
+        h3 = mk() if (keep_first or not with_out) else None
+        head_bf16(M, xa, layers[0], layers[1], layers[2], (Wo, bo) if with_out else None, h1, h2, h3, out, ldo, col_off)
+        acts += [h1, h2, h3]
+        if with_out:
+            return acts if keep_first else [None]
+        h = h3
+        rest = layers[3:-1]
+    elif (FUSE_FIRST2 and MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
             and os.environ.get("CLIFT_NO_PERSISTENT") is None):
         W1, b1 = layers[1]
         h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None

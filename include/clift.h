@@ -199,6 +199,15 @@ int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, c
 int clift_app_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
                              const float* bout, int E, int M, float* hidden, int ldh, float* pre, int ldp, float* out, int ldo,
                              int sigmoid, clift_stream_t s);
+/* bf16 mode: the first three layers of an xyz head (K = 3 layer + two 256 x 256 hidden layers, tensoRF.py:475-479, 576-579) and,
+ * for E in [1,4], its E-wide output layer, in ONE launch with the activations resident in LDS (bf16 operands, fp32 accumulate --
+ * the arithmetic of clift_linear_k3_fwd + clift_gemm(precision 1) with bf16-stored activations).  h1 / h2 / h3: nullable bf16-stored
+ * (M, 256) destinations of the hidden activations, passed only when a backward pass will need them; E = 0: no output layer, h3
+ * (required) is the result; E > 0: out (M, ldo) fp32. */
+int clift_xyz_head_bf16_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
+                            const float* b1, const float* W2, int ldw2, const float* b2, const float* Wout, int ldwo,
+                            const float* bout, int E, int M, void* h1, void* h2, void* h3, float* out, int ldo,
+                            clift_stream_t s);
 /* dW (Nout,3; pitch ldw) += dH^T x ; db (Nout) += colsum(dH). */
 int clift_linear_k3_bwd(const float* x4, const float* dH, int ldh, int M, int Nout, float* dW, int ldw, float* db,
                         int dh_bf16 /* dH is bf16-stored */, clift_stream_t s);

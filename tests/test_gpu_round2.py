@@ -538,3 +538,46 @@ def test_masked_narrow_dgrad_stream_128_wide(M):
     ref = (A[:, :3].double() @ W.double()) * (mask.double() > 0)
     rel_close(out[:M, :128], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="masked narrow dgrad N=128")
     assert bool((out[M:] == -7.0).all()) and bool((out[:, 128:] == -7.0).all())
+
+
+# ============================================================================ bf16 mode: a whole xyz head forward in one launch
+@pytest.mark.parametrize("M", [1, 63, 65, 5000, 140001, 600000])
+def test_bf16_fused_head_forward_matches_per_layer_path(M):
+    """clift_xyz_head_bf16_fwd (K = 3 layer + two 256 x 256 bf16 layers (+ the E-wide output layer) with the activations resident in LDS)
+    against the per-layer bf16 path (clift_linear_k3_fwd + k_layer_bf16 + narrow GEMM): same arithmetic => the kept activations are
+    bit-identical, the output layer agrees to summation-order round-off; instance head (E = 3, everything fused) and semantic head
+    (C = 22: three layers fused, fourth hidden layer and output layer per layer); with and without keeping the activations."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + 17)
+    xa = torch.zeros((M, 4)); xa[:, :3] = torch.rand((M, 3), generator=g) * 2 - 1
+    xa = xa.to(DEV)
+
+    def lin(o, i, s):
+        W = torch.zeros((o, (i + 3) // 4 * 4)); W[:, :i] = torch.randn((o, i), generator=g) * s
+        return W.to(DEV)[:, :i], (torch.randn(o, generator=g) * 0.2).to(DEV)
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        for n_out, n_hidden in ((3, 3), (22, 4)):
+            layers = [lin(256, 3, 0.8)] + [lin(256, 256, 0.09) for _ in range(n_hidden - 1)] + [lin(n_out, 256, 0.1)]
+            res = {}
+            for fused in (False, True):
+                engine.FUSE_HEAD_BF16 = fused
+                for keep in (True, False):
+                    out = torch.full((M, n_out + 3), -7.0, device=DEV)
+                    acts = engine.xyz_mlp_fwd(layers, xa, M, out, n_out + 3, 1, keep_first=keep)
+                    res[(fused, keep)] = (out.clone(), acts)
+            ref_out, ref_acts = res[(False, True)]
+            for keep in (True, False):
+                out, acts = res[(True, keep)]
+                sc = float(ref_out[:, 1:1 + n_out].abs().max())
+                assert float((out[:, 1:1 + n_out] - ref_out[:, 1:1 + n_out]).abs().max()) <= 2e-5 * sc + 1e-7, (M, n_out, keep)
+                assert bool((out[:, 0] == -7.0).all()) and bool((out[:, 1 + n_out:] == -7.0).all())
+                if keep:
+                    assert len(acts) == len(ref_acts)
+                    for a, b in zip(acts, ref_acts):
+                        assert a.dtype == torch.bfloat16 and torch.equal(a, b)
+                else:
+                    assert acts == [None]
+    finally:
+        engine.FUSE_HEAD_BF16 = True
+        engine.set_mlp_precision(prev)
