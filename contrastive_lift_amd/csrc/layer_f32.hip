@@ -172,13 +172,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     };
     // step 4 (k-step 26 of the tile after that, i.e. behind a barrier): lanes 0..15 of wave w fetch the eight shares of (row 4 w + lane / 4, column lane % 4) ...
     auto outv_fetch = [&](int tile) {
-        if (lane < 16) {
-            unsigned b = part0 + (unsigned)(((tile & 1) * 256 + 4 * wave + (lane >> 2)) * 16 + (lane & 3) * 4);
-            asm volatile("" : "+v"(b));
+        // (every lane reads -- lanes 16..63 repeat the addresses of lanes 0..15: a run-time branch around asm reads whose results are
+        // published by a later asm wait would let the compiler copy the registers before the data has arrived)
+        unsigned b = part0 + (unsigned)(((tile & 1) * 256 + 4 * wave + ((lane >> 2) & 3)) * 16 + (lane & 3) * 4);
+        asm volatile("" : "+v"(b));
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8)
-                asm volatile("ds_read_b32 %0, %1" : "=v"(wv[w8 >> 2][w8 & 3]) : "v"(b + (unsigned)(w8 * 32 * 16)) : "memory");
-        }
+        for (int w8 = 0; w8 < 8; ++w8)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(wv[w8 >> 2][w8 & 3]) : "v"(b + (unsigned)(w8 * 32 * 16)) : "memory");
     };
     // ... step 5 (k-step 28): add them up in a fixed order, add the bias, store
     auto outv_store = [&](int tile) {

@@ -129,14 +129,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     };
     // lanes 0..31 of wave w own (row 8 w + lane / 4 of the tile, output lane % 4): the four column-waves' shares of that row
     auto outv_fetch = [&](int tile) {
-        if (lane < 32) {
-            const int row = 8 * wave + (lane >> 2);
-            unsigned b = part0 + (unsigned)(((tile & 1) * 256 + (4 * (row >> 5)) * 32 + (row & 31)) * 16 + (lane & 3) * 4);
-            asm volatile("" : "+v"(b));
+        // (every lane reads -- lanes 32..63 repeat the addresses of lanes 0..31: no run-time branch between asm reads and the asm wait that
+        // publishes their registers)
+        const int row = 8 * wave + ((lane >> 2) & 7);
+        unsigned b = part0 + (unsigned)(((tile & 1) * 256 + (4 * (row >> 5)) * 32 + (row & 31)) * 16 + (lane & 3) * 4);
+        asm volatile("" : "+v"(b));
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4)
-                asm volatile("ds_read_b32 %0, %1" : "=v"(wv[0][0][w4]) : "v"(b + (unsigned)(w4 * 32 * 16)) : "memory");
-        }
+        for (int w4 = 0; w4 < 4; ++w4)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(wv[0][0][w4]) : "v"(b + (unsigned)(w4 * 32 * 16)) : "memory");
     };
     auto outv_store = [&](int tile) {
         if (lane < 32) {

@@ -207,22 +207,27 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     for (int t = 0; t < ntiles; ++t) {
         // MASK: the previous epilogue waited for everything older than its stores, the DMA of this tile included.  !MASK: the DMA of this tile
         // is older than the previous tile's stores -- four of them in a wave that stores all its column groups, otherwise drain
-        if (t > 0 && ((MASK && 32 * wave < g.N) || (!MASK && full_wave))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t > 0 && ((MASK && 32 * wave < g.N) || (!MASK && full_wave))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < ntiles) dma(t + 1);
         const int m = rbeg + t * ROWS + li;
         f32x4 mk[4];
         u32x2v mh[4];
-        const bool wave_on = 32 * wave < g.N;          // (masked form: N is a multiple of 32; a wave past N only helps with the DMA)
-        if (!MASK || !wave_on) {
+        // (masked form: N is a multiple of 32; a wave past N only helps with the DMA.  Its mask loads stay in the instruction stream --
+        // pointed at columns that exist -- because a run-time branch between an asm load and the asm wait that publishes its registers
+        // lets the compiler copy those registers before the data has arrived)
+        const bool wave_on = 32 * wave < g.N;
+        const int mcol = wave_on ? 32 * wave : 0;
+        if (!MASK) {
         } else if (!HB) {
-            const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
+            const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + mcol + 4 * lh;
             asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
                          "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
                          : "=&v"(mk[0]), "=&v"(mk[1]), "=&v"(mk[2]), "=&v"(mk[3]) : "v"(mp) : "memory");
         } else {
-            const unsigned short* mp = reinterpret_cast<const unsigned short*>(g.mask) + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh;
+            const unsigned short* mp = reinterpret_cast<const unsigned short*>(g.mask) + (size_t)min(m, rend - 1) * g.ldmask + mcol + 4 * lh;
             asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:16\n\t"
                          "global_load_dwordx2 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48"
                          : "=&v"(mh[0]), "=&v"(mh[1]), "=&v"(mh[2]), "=&v"(mh[3]) : "v"(mp) : "memory");
@@ -242,8 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, fa[j].z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, fa[j].w, acc1, 0, 0, 0);
         }
-        if (!MASK || !wave_on) {
-            if (MASK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep the masked form's invariant: nothing older than the stores is pending
+        if (!MASK) {
         } else if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mh[0]), "+v"(mh[1]), "+v"(mh[2]), "+v"(mh[3]) : : "memory");
 #pragma unroll
