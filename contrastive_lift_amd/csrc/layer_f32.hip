@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     // issue queue); one instruction every other k-step disappears under the MFMAs (probe: 124 -> 145 TFLOP/s for the same work).  So the rows
     // of tile t+1 are copied at steps 0, 2, 4, 6 of tile t, and the results of tile t-1 -- kept in 16 registers -- are stored at steps 8, 10,
     // 12, 14 of tile t (dgrad: the mask loads of tile t go at steps 16 .. 22).
-    float4 prev[4];
+    float4 prev[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     int prev_m = rend;                                                       // row of `prev`; rend = nothing to store yet
     if (GEN) { fill_positions(0); __syncthreads(); }
     // ---- OUTV state
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         if (lane < 16) {
             const int c = lane & 3, mrow = rbeg + tile * LF_ROWS + 4 * wave + (lane >> 2);
             const float v = ((wv[0][0] + wv[0][1]) + (wv[0][2] + wv[0][3])) + ((wv[1][0] + wv[1][1]) + (wv[1][2] + wv[1][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
-            if (c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
+            if (tile >= 0 && c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
         }
     };
 #pragma unroll
@@ -236,12 +236,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
                 const int q = (j - 8) >> 1;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
             }
-            if (OUTV && t >= 1) {                       // output layer of tile t-1 (its activation is still in `prev`)
+            if (OUTV) {
+                // output layer of tile t-1 (its activation is still in `prev`) and the cross-wave sum of tile t-2 (parked during tile t-1, behind
+                // this tile's barrier).  The asm reads and the arithmetic run for EVERY t -- for t = 0 / 1 on zeros, into shares nobody stores --
+                // so that no run-time branch separates an asm read from the asm wait that publishes its registers; only the store is guarded.
                 if (j >= 8 && j < 24) outv_fma(j - 8);
                 if (j >= 7 && j < 23) outv_issue(j - 7);
                 if (j == 25) outv_park(t - 1);
-            }
-            if (OUTV && t >= 2) {                       // ... and the cross-wave sum of tile t-2 (parked during tile t-1, behind this tile's barrier)
                 if (j == 26) outv_fetch(t - 2);
                 if (j == 28) outv_store(t - 2);
             }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
         __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + (c ^ (row & 7)) * 4,
                                          (lds_ptr_t)(lds + (t & 1) * TILE + 64 * (NDMA * wave + i)), 16, 0, 0);
     };
-    float4 prev[4];
+    float4 prev[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     int prev_m = rend;
     // ---- OUTV state and steps
     const unsigned wl0 = (unsigned)(uintptr_t)(lds_ptr_t)wl4, part0 = (unsigned)(uintptr_t)(lds_ptr_t)part;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
         if (lane < 32) {
             const int c = lane & 3, mrow = rbeg + tile * LN_ROWS + 8 * wave + (lane >> 2);
             const float v = ((wv[0][0][0] + wv[0][0][1]) + (wv[0][0][2] + wv[0][0][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
-            if (c < op.E && mrow < rend) {
+            if (tile >= 0 && c < op.E && mrow < rend) {
                 if (op.pre) op.pre[(size_t)mrow * op.ldp + c] = v;
                 op.out[(size_t)mrow * op.ldo + c] = op.sigmoid ? 1.f / (1.f + expf(-v)) : v;
             }
@@ -188,12 +188,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
                 const int q = j - NDMA;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
             }
-            if (OUTV && t >= 1) {                       // output layer of tile t-1 (its activation is still in `prev`)
+            if (OUTV) {
+                // output layer of tile t-1 (its activation is still in `prev`) and the cross-wave sum of tile t-2 (parked during tile t-1, behind
+                // this tile's barrier); executed for every t (zeros at t = 0 / 1, never stored) so that no run-time branch separates an asm read
+                // from the asm wait that publishes its registers; only the store is guarded
                 if (j >= 1 && j < 9) outv_fma(j - 1);
                 if (j < 8) outv_issue(j);
                 if (j == 10) outv_park(t - 1);
-            }
-            if (OUTV && t >= 2) {                       // cross-wave sum of tile t-2 (parked during tile t-1, behind this tile's barrier)
                 if (j == 12) outv_fetch(t - 2);
                 if (j == 14) outv_store(t - 2);
             }
