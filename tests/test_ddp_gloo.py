@@ -93,7 +93,7 @@ def test_state_dict_roundtrip_and_layout():
     p = m2.get_parameter("density_plane.1")
     assert p.stride()[1] == 1 and p.data_ptr() >= m2.param_flat.data_ptr()           # channels-last view into the arena
     w = m2.get_parameter("render_appearance_mlp.mlp.0.weight")
-    assert w.stride() == (152, 1)
+    assert w.stride() == (160, 1)          # 150 inputs padded to the 160-float pitch of the persistent 128-wide layer kernel
     groups = m2.get_optimizable_parameters(1e-2, 5e-4, 1e-8)
     assert len(groups) == 7 and groups[0]["lr"] == 1e-2 and groups[-1]["lr"] == 5e-4
     assert len(m2.get_optimizable_instance_parameters(1e-2, 5e-4, using_DINO=True)) == 1
