@@ -215,7 +215,7 @@ def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
     prev = engine.set_mlp_precision("bf16")
     try:
-        model, renderer, _ = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+        model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
         tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0,
                                                             mlp_dtype="bf16"), current_epoch=4)
         for i in range(warmup):
@@ -226,9 +226,23 @@ def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
             tr.training_step(batches[i % len(batches)], lean=a.lean)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
+        # frame render in bf16 mode (the xyz heads run as one fused kernel each: csrc/head_bf16.hip)
+        from contrastive_lift_amd import inference as inf
+        ratio = renderer.step_ratio
+        renderer.update_step_ratio(ratio * 0.5)
+        try:
+            rays = pool[:262144].contiguous()
+            inf.render_rays(model, renderer, rays[:32768], 32768)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            inf.render_rays(model, renderer, rays, 32768)
+            torch.cuda.synchronize()
+            inf_rate = rays.shape[0] / (time.perf_counter() - t)
+        finally:
+            renderer.update_step_ratio(ratio)
     finally:
         engine.set_mlp_precision(prev)
-    return dict(bf16_ms_per_step=round(dt * 1e3, 3), bf16_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt)
+    return dict(bf16_ms_per_step=round(dt * 1e3, 3), bf16_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt, bf16_inference_rays_per_s=inf_rate)
 
 
 def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):

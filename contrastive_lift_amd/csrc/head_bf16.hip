@@ -135,31 +135,32 @@ __global__ __launch_bounds__(512, 2) void k_head_bf16_fwd(HeadP p, int rows_per_
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(layer == 0 ? w1[s] : w2[s], a1, acc[1], 0, 0, 0);
                 if (s & 1) __builtin_amdgcn_sched_barrier(0);          // (fragments at most two steps ahead: the weights own the register file)
             }
-            // lane (li, lh) holds row li of each 32-row half, columns 32 wave + 8 q + 4 lh + (0..3)
+            // lane (li, lh) holds row li of each 32-row half, columns 32 wave + 8 q + 4 lh + (0..3).  Column group outermost: its bias and its
+            // output-layer weights are fetched from LDS once and serve both row halves.
             unsigned short* hs = layer == 0 ? p.h2 : p.h3;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int row = 32 * x + li, m = r0 + row;
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bl + layer * 256 + 32 * wave + 8 * q + 4 * lh);
+                float4 wq[4];
+                if (layer == 1 && p.E > 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bq = *reinterpret_cast<const float4*>(bl + layer * 256 + 32 * wave + 8 * q + 4 * lh);
+                    for (int c = 0; c < 4; ++c) wq[c] = *reinterpret_cast<const float4*>(wl + c * 256 + 32 * wave + 8 * q + 4 * lh);
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int row = 32 * x + li, m = r0 + row;
                     float v[4];
                     v[0] = fmaxf(acc[x][4 * q + 0] + bq.x, 0.f); v[1] = fmaxf(acc[x][4 * q + 1] + bq.y, 0.f);
                     v[2] = fmaxf(acc[x][4 * q + 2] + bq.z, 0.f); v[3] = fmaxf(acc[x][4 * q + 3] + bq.w, 0.f);
                     const uint2 pk = make_uint2(hb_pack(v[0], v[1]), hb_pack(v[2], v[3]));
-                    if (layer == 0 || p.E == 0) {
-                        // next layer's operand tile (layer 0) -- written also by the last layer when the result is the activation itself (E == 0)
-                        if (layer == 0) reinterpret_cast<uint2*>(D + row * 32 + ((4 * wave + q) ^ (row & 15)))[lh] = pk;
-                    }
+                    if (layer == 0) reinterpret_cast<uint2*>(D + row * 32 + ((4 * wave + q) ^ (row & 15)))[lh] = pk;      // next layer's operand tile
                     if (hs && m < rend) *reinterpret_cast<uint2*>(hs + (size_t)m * 256 + 32 * wave + 8 * q + 4 * lh) = pk;
                     if (layer == 1 && p.E > 0) {          // output layer on the bf16-rounded activation: this lane's share of the E sums of row `row`
                         const float r0v = bf16_bits_to_float((unsigned short)(pk.x & 0xffffu)), r1v = bf16_bits_to_float((unsigned short)(pk.x >> 16));
                         const float r2v = bf16_bits_to_float((unsigned short)(pk.y & 0xffffu)), r3v = bf16_bits_to_float((unsigned short)(pk.y >> 16));
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float4 wq = *reinterpret_cast<const float4*>(wl + c * 256 + 32 * wave + 8 * q + 4 * lh);
-                            pv[x][c] = fmaf(r3v, wq.w, fmaf(r2v, wq.z, fmaf(r1v, wq.y, fmaf(r0v, wq.x, pv[x][c]))));
-                        }
+                        for (int c = 0; c < 4; ++c)
+                            pv[x][c] = fmaf(r3v, wq[c].w, fmaf(r2v, wq[c].z, fmaf(r1v, wq[c].y, fmaf(r0v, wq[c].x, pv[x][c]))));
                     }
                 }
             }

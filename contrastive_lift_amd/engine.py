@@ -97,6 +97,31 @@ _PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32x6": 2}
 MLP_PRECISION = _PRECISIONS[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
 
 
+class _Precision:
+    """Temporarily run the matrix-core launches at another operand precision (wave-uniform host state, restored on exit)."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        global MLP_PRECISION
+        self.prev, MLP_PRECISION = MLP_PRECISION, self.p
+
+    def __exit__(self, *a):
+        global MLP_PRECISION
+        MLP_PRECISION = self.prev
+
+
+# bf16 mode: the 128-wide appearance MLP stays on the exact-fp32 persistent kernels (layer_n128.hip) -- they are FASTER than the tiled
+# bf16 kernels on these short-K layers (fp32 persistent ~0.76 ms vs bf16 tiled ~1.0 ms per step, profiles/r02_bf16_*), and it is the
+# more accurate choice.  The 256-wide xyz heads, where the bf16 streaming / fused kernels pay, run in bf16.
+APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
+
+
+def _app_precision():
+    return _Precision(0) if (MLP_PRECISION == 1 and APP_FP32_IN_BF16) else _Precision(MLP_PRECISION)
+
+
 def act_dtype():
     """Storage type of the hidden activations / hidden gradients of the xyz-MLP heads: bf16 in bf16 mode (they are only ever
     consumed as bf16 matrix-core operands or as ReLU masks there), fp32 otherwise."""
@@ -413,6 +438,10 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
 
         def app_chain(keep):
+            with _app_precision():
+                _app_chain_fwd(keep)
+
+        def _app_chain_fwd(keep):
             Wb = views["appearance_basis_mat.weight"]
             nf, nc = Wb.shape
             ldf = (nf + 3) // 4 * 4
@@ -530,6 +559,10 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
 
         # ---------------- appearance head
         def app_chain(keep):
+            with _app_precision():
+                _app_chain_bwd(keep)
+
+        def _app_chain_bwd(keep):
             app = _lin_params(None, "render_appearance_mlp.mlp", views)
             gapp = _lin_params(None, "render_appearance_mlp.mlp", gviews)
             (W1, b1), (W2, b2), (W3, b3) = app
