@@ -162,7 +162,10 @@ if __name__ == "__main__":
     ap.add_argument("--render_trajectory", action="store_true")
     ap.add_argument("--bandwidth", type=float, default=0.15, required=False)
     ap.add_argument("--cluster_size", type=int, default=500, required=False, help="min_cluster_size for HDBSCAN")
-    ap.add_argument("--use_dbscan", action="store_true")
+    ap.add_argument("--use_dbscan", action="store_true",
+                    help="HDBSCAN clustering (reference RP:236-255) -- NOT available here: the hdbscan package is not installed in this "
+                         "image; the flag fails immediately, before anything is rendered.  Use MeanShift (default), --use_silverman or "
+                         "--cached_centroids_path")
     ap.add_argument("--segmentwise", action="store_true")
     ap.add_argument("--subsample", type=int, default=1, required=False)
     ap.add_argument("--use_silverman", action="store_true")
