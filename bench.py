@@ -179,10 +179,11 @@ def main():
                      main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                      f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
         extra["active_samples_per_s_main_pass"] = M / t_main            # cost follows the ACTIVE samples; comparable across scenes
-        if a.inference_probe:       # opt-in probe: changes the launch mix of the dominant kernel, so it stays out of profiled runs
-            t_lean = timed(lambda b: tr.main_pass(b[0], lean=True))            # main pass without the discarded instance heads
-            extra["lean_main_pass_ms"] = round(t_lean * 1e3, 3)
         if not a.no_extras and a.dtype == "fp32":
+            # the reference's main pass computes the instance heads and discards their output (T:155); without that dead work:
+            t_lean = timed(lambda b: tr.main_pass(b[0], lean=True))
+            extra["lean_main_pass_ms"] = round(t_lean * 1e3, 3)
+            extra["lean_step_ms_estimate"] = round((t_lean + t_inst) * 1e3, 3)
             # BASELINE configs[2] (bf16 MLP operands) and configs[4] (frame render) on the same scene, AFTER the timed fp32 region, so
             # that the driver-run record carries them: same step definition, 10 steps after 3 warm-up steps / one 262144-ray tile
             extra.update(inference_probe(cl, model, renderer, pool))

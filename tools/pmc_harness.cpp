@@ -2,7 +2,7 @@
 // A counter pass serialises every dispatch and re-runs nothing else, so the process under the profiler should do as little as
 // possible: this program allocates the operands of ONE 256x256 hidden-layer launch shape with hipMalloc, fills them with a
 // pseudo-random pattern, and issues `reps` launches of the chosen form through the C ABI.
-//   pmc_harness fwd|dgrad|wgrad|wgrad_tiled M reps
+//   pmc_harness fwd|dgrad|wgrad|gen|outv M reps     (gen: clift_xyz_head_first2_fwd, activation kept; outv: clift_xyz_head_last2_fwd, E = 3, hidden dropped)
 // Build: hipcc -O2 --offload-arch=gfx950 tools/pmc_harness.cpp -Iinclude -Lcontrastive_lift_amd -lclift -Wl,-rpath,'$ORIGIN/../contrastive_lift_amd' -o tools/pmc_harness.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
         g.M = M; g.N = 256; g.K = 256; g.A = A; g.lda = 256; g.B = W; g.ldb = 256; g.C = Cc; g.ldc = 256; g.bias = b; g.act = 1; g.split_k = 1;
     } else if (!strcmp(mode, "dgrad")) {
         g.M = M; g.N = 256; g.K = 256; g.A = A; g.lda = 256; g.B = W; g.ldb = 256; g.b_trans = 1; g.C = Cc; g.ldc = 256; g.mask = X; g.ldmask = 256; g.split_k = 1;
+    } else if (gen || outv) {
     } else {        // wgrad: gW (256,256) += dY^T X over M rows
         g.M = 256; g.N = 256; g.K = M; g.A = A; g.lda = 256; g.a_trans = 1; g.B = X; g.ldb = 256; g.b_trans = 1; g.C = gW; g.ldc = 256; g.accumulate = 1;
         g.colsum = gb;
@@ -47,17 +48,28 @@ int main(int argc, char** argv) {
         int sp = (512 + tiles - 1) / tiles; if (sp > (M + 255) / 256) sp = (M + 255) / 256; if (sp < 1) sp = 1;
         g.split_k = sp;
     }
+    float* x4 = dev_random((size_t)M * 4, 5, 1.0f);
+    float* W0 = dev_random(256 * 4, 6, 0.7f);
+    float* Wo = dev_random(4 * 256, 7, 0.1f);
+    float* out3 = nullptr; CK(hipMalloc(&out3, (size_t)M * 4 * sizeof(float)));
+    const bool gen = !strcmp(mode, "gen"), outv = !strcmp(mode, "outv");
+    auto launch = [&]() -> int {
+        if (gen) return clift_xyz_head_first2_fwd(x4, W0, 4, b, W, 256, b, M, X, 256, Cc, 256, nullptr);
+        if (outv) return clift_xyz_head_last2_fwd(A, 256, W, 256, b, Wo, 256, b, 3, M, nullptr, 256, out3, 4, nullptr);
+        return clift_gemm(&g, nullptr);
+    };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    if (clift_gemm(&g, nullptr)) { fprintf(stderr, "clift_gemm: %s\n", clift_last_error()); return 3; }     // warm-up
+    if (launch()) { fprintf(stderr, "launch: %s\n", clift_last_error()); return 3; }     // warm-up
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps; ++r)
-        if (clift_gemm(&g, nullptr)) { fprintf(stderr, "clift_gemm: %s\n", clift_last_error()); return 3; }
+        if (launch()) { fprintf(stderr, "launch: %s\n", clift_last_error()); return 3; }
     CK(hipEventRecord(e1, nullptr));
     CK(hipDeviceSynchronize());
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, fl = 2.0 * M * 65536.0;
     printf("%s M=%d reps=%d: %.1f us/launch, %.1f TFLOP/s; algorithmic bytes/launch = %.0f\n", mode, M, reps, us, fl / us / 1e6,
-           !strcmp(mode, "fwd") ? 8.0 * M * 256 + 262144.0 : !strcmp(mode, "dgrad") ? 12.0 * M * 256 + 262144.0 : 8.0 * M * 256 + 262144.0);
+           !strcmp(mode, "fwd") ? 8.0 * M * 256 + 262144.0 : !strcmp(mode, "dgrad") ? 12.0 * M * 256 + 262144.0 :
+           gen ? 8.0 * M * 256 + 16.0 * M + 262144.0 : outv ? 4.0 * M * 256 + 12.0 * M + 262144.0 : 8.0 * M * 256 + 262144.0);
     return 0;
 }
