@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
     float* gW = nullptr; CK(hipMalloc(&gW, 256 * 256 * sizeof(float))); CK(hipMemset(gW, 0, 256 * 256 * sizeof(float)));
     float* gb = nullptr; CK(hipMalloc(&gb, 256 * sizeof(float))); CK(hipMemset(gb, 0, 256 * sizeof(float)));
     if (!A || !X || !W || !b) { fprintf(stderr, "alloc failed\n"); return 2; }
+    const bool gen = !strcmp(mode, "gen"), outv = !strcmp(mode, "outv");
     clift_gemm_t g; memset(&g, 0, sizeof g);
     if (!strcmp(mode, "fwd")) {
         g.M = M; g.N = 256; g.K = 256; g.A = A; g.lda = 256; g.B = W; g.ldb = 256; g.C = Cc; g.ldc = 256; g.bias = b; g.act = 1; g.split_k = 1;
@@ -52,7 +53,6 @@ int main(int argc, char** argv) {
     float* W0 = dev_random(256 * 4, 6, 0.7f);
     float* Wo = dev_random(4 * 256, 7, 0.1f);
     float* out3 = nullptr; CK(hipMalloc(&out3, (size_t)M * 4 * sizeof(float)));
-    const bool gen = !strcmp(mode, "gen"), outv = !strcmp(mode, "outv");
     auto launch = [&]() -> int {
         if (gen) return clift_xyz_head_first2_fwd(x4, W0, 4, b, W, 256, b, M, X, 256, Cc, 256, nullptr);
         if (outv) return clift_xyz_head_last2_fwd(A, 256, W, 256, b, Wo, 256, b, 3, M, nullptr, 256, out3, 4, nullptr);
