@@ -155,9 +155,18 @@ def set_launch_stream(s):
     _launch_stream = s
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the raw handle of torch's current stream without building a Stream object
+
+
 def stream():
-    s = _launch_stream if _launch_stream is not None else torch.cuda.current_stream()
-    return C.c_void_p(s.cuda_stream)
+    """hipStream_t of the stream launches go to: the side-stream override, else torch's current stream of the current device.
+    (torch.cuda.current_stream() costs ~9 us a call through its device-index helpers -- 0.5 ms per training step at ~60 launches;
+    the raw accessor is ~0.3 us.)"""
+    if _launch_stream is not None:
+        return C.c_void_p(_launch_stream.cuda_stream)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch._C._cuda_getDevice()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def call(name, *args):
