@@ -316,19 +316,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     const float* __restrict__ X = g.B + 128 * (quad & 1);             // X (rows, 4 KXC of ldb)
     float* __restrict__ Cq = g.C + (size_t)(128 * (quad >> 1)) * g.ldc + 128 * (quad & 1);
     const int ncols = quads == 4 ? 128 : g.N;
-    auto dma = [&](int t) {
+    // LDS-DMA piece i of tile t (this wave's share): i < 4: two rows of dY (64 rows x 32 chunks per tile); i >= 4: 64 chunks of X
+    auto dma_piece = [&](int t, int i) {
         const int r0 = rbeg + t * ROWS;
         unsigned char* st = lds + (t & 1) * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {             // dY: 64 rows x 32 chunks, 2 rows per instruction
+        if (i < 4) {
             const int q = 64 * (4 * wave + i) + lane, row = q >> 5, c = q & 31, gr = min(r0 + row, rend - 1);
             __builtin_amdgcn_global_load_lds(Y + (size_t)gr * g.lda + c * 4, (lds_ptr_t)(st + 1024 * (4 * wave + i)), 16, 0, 0);
+        } else {
+            const int j = i - 4;
+            const int q = 64 * (NDX * wave + j) + lane, row = q / KXC, c = q - row * KXC, gr = min(r0 + row, rend - 1);
+            __builtin_amdgcn_global_load_lds(X + (size_t)gr * g.ldb + c * 4, (lds_ptr_t)(st + YB + 1024 * (NDX * wave + j)), 16, 0, 0);
         }
+    };
+    auto dma = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < NDX; ++i) {           // X: 64 rows x KXC chunks
-            const int q = 64 * (NDX * wave + i) + lane, row = q / KXC, c = q - row * KXC, gr = min(r0 + row, rend - 1);
-            __builtin_amdgcn_global_load_lds(X + (size_t)gr * g.ldb + c * 4, (lds_ptr_t)(st + YB + 1024 * (NDX * wave + i)), 16, 0, 0);
-        }
+        for (int i = 0; i < 4 + NDX; ++i) dma_piece(t, i);
     };
     f32x16 acc[NT];
 #pragma unroll
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile t has landed (issued a whole tile ago)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 1 < ntiles) dma(t + 1);
+        const bool more = t + 1 < ntiles;
         const int valid = rend - (rbeg + t * ROWS);
         if (valid < ROWS) {                                                  // last tile of the range: rows past its end contribute nothing
             float* yt = reinterpret_cast<float*>(lds + (t & 1) * STAGE);
@@ -370,6 +373,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
             const int set = grp & 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (grp + 1 < ROWS / 8) rd(grp + 1, set ^ 1);
+            // the next tile's DMA pieces are spread over the groups of this tile (eight waves issuing 8-9 of them at the same moment right
+            // after the barrier stall the vector-memory issue path with the MFMA pipe idle -- the effect measured in layer_f32.hip)
+            if (more) {
+                if (grp < 4 + NDX) dma_piece(t + 1, grp);
+                if (grp == 0 && 4 + NDX > ROWS / 8) dma_piece(t + 1, ROWS / 8);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
