@@ -193,7 +193,11 @@ def main():
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": ("strong" if a.global_rays else "weak"),
-                "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32 (fp32-faithful 6-product bf16 split on the matrix cores)"}[a.dtype],
+                "vs_baseline": None,
+                "value_definition": "nominal ray-samples of one full training_step = (main-pass rays + instance-pass rays) x S, over all ranks, / step time; the "
+                                    "main pass alone (the 4096 rays of the metric's name) is `main_pass_samples_per_s`, and because cost follows the ACTIVE "
+                                    "samples (f_active of the nominal ones) `active_samples_per_s_main_pass` is the scene-independent figure",
+                "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32 (fp32-faithful 6-product bf16 split on the matrix cores)"}[a.dtype],
                 "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
                                         "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype == "fp32" else
