@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--global-rays", type=int, default=0,
                     help="strong scaling (BASELINE configs[3]: 8192 rays per step over the job): rays per GPU = global / world, "
                          "instance rays stay per-GPU (one instance image per rank, as the reference's DDP)")
+    ap.add_argument("--nosync", action="store_true",
+                    help="sync-free steps: the active-sample count is never read back; buffers sized by a learnt capacity, kernels clamp to the "
+                         "device-side count (exact fp32 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and frame-render extras measured after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
@@ -77,7 +80,7 @@ def main():
 
     model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
     S = int(renderer.n_samples)
-    cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype)
+    cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype, nosync=a.nosync)
     tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
     n_batches = 4
     batches = [synthetic.make_batches(pool, a.rays, a.inst_rays, a.classes, 25, seed=100 + rank * 17 + i, device=dev) for i in range(n_batches)]
@@ -173,7 +176,7 @@ def main():
         t_main = timed(lambda b: tr.main_pass(b[0], lean=a.lean))
         t_inst = timed(lambda b: tr.instance_pass(b[1]))
         ctxs = tr.main_pass(batches[0][0], lean=a.lean)
-        M = sum(c.M for c in ctxs)
+        M = sum((int(c.ray_start[-1]) if getattr(c, "capped", False) else c.M) for c in ctxs)
         inbox = sum(int((c.alpha > 0).sum()) for c in ctxs)
         extra = dict(main_pass_ms=round(t_main * 1e3, 3), instance_pass_ms=round(t_inst * 1e3, 3),
                      main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
@@ -204,7 +207,7 @@ def main():
                                        (f"BASELINE configs[2]-style bf16 mode on the configs[1] shapes (C={a.classes}, E=3/D=6, grid {a.grid}^3): MLP "
                                         "operands bf16 (weights rounded in-kernel, hidden activations / gradients bf16-stored), fp32 accumulate; everything else fp32"),
                            "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
-                           "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean),
+                           "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean), "sync_free": bool(a.nosync),
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
                 "roofline": roof, "cpu_baseline": cpu}
         line.update(extra)

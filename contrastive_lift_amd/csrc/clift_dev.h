@@ -61,6 +61,24 @@ static inline VmG to_dev(const clift_vm_grad_t* g) {
     return p;
 }
 
+// ----------------------------------------------------------------------------- dynamic row limit
+// A training step that never reads the active-sample count back to the host (no synchronisation, capturable in a hipGraph) sizes
+// its buffers and its grids by a CAPACITY and lets every per-sample kernel clamp its row count to the true count, which lives in
+// device memory: clift_bind_rows_limit(ptr) publishes the address once (one copy of the pointer per translation unit -- device
+// globals are per object file), the caller keeps INT_MAX there except between clift_scan_counts(..., limit = ptr) and the end of the pass.
+static __device__ const int* g_rows_limit = nullptr;
+__device__ __forceinline__ int limit_rows(int M) {
+    const int* p = g_rows_limit;
+    return p ? min(M, *p) : M;
+}
+__device__ __forceinline__ bool rows_limited() { return g_rows_limit != nullptr; }
+__device__ __forceinline__ bool rows_cut(long row) {          // is this row past the true count?
+    const int* p = g_rows_limit;
+    return p && row >= (long)*p;
+}
+#define CLIFT_ROWS_LIMIT_BINDER(tu) \
+    void clift_bind_rows_limit_##tu(const int* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_limit), &p, sizeof(p)); }
+
 // ----------------------------------------------------------------------------- wave primitives (64 lanes)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -20,5 +20,25 @@ int clift_check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int clift_version(void) { return 6; }
+extern "C" int clift_version(void) { return 7; }
+
+// per-translation-unit binders (CLIFT_ROWS_LIMIT_BINDER in each kernel file)
+void clift_bind_rows_limit_march(const int* p);
+void clift_bind_rows_limit_heads_io(const int* p);
+void clift_bind_rows_limit_gemm(const int* p);
+void clift_bind_rows_limit_layer_f32(const int* p);
+void clift_bind_rows_limit_layer_n128(const int* p);
+void clift_bind_rows_limit_narrow_stream(const int* p);
+
+extern "C" int clift_bind_rows_limit(const int* dev_limit) {
+    clift_bind_rows_limit_march(dev_limit);
+    clift_bind_rows_limit_heads_io(dev_limit);
+    clift_bind_rows_limit_gemm(dev_limit);
+    clift_bind_rows_limit_layer_f32(dev_limit);
+    clift_bind_rows_limit_layer_n128(dev_limit);
+    clift_bind_rows_limit_narrow_stream(dev_limit);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { clift_set_error("clift_bind_rows_limit: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
 extern "C" const char* clift_last_error(void) { return g_err; }

@@ -18,6 +18,7 @@
 // (both transposed, reduction over the sample dimension split over blockIdx.z with atomic accumulation).
 #include <cstring>
 #include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(gemm)
 
 constexpr int BK = 32;
 
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8 ? 4 : 1)) void k_gemm(G
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    // sample rows run along K in the weight-gradient form (A transposed), along M otherwise: clamp them to the true count of a
+    // sync-free step (clift_dev.h, g_rows_limit); tiles / splits past it find nothing to do
+    if (AT) g.K = limit_rows(g.K); else g.M = limit_rows(g.M);
     const int ntn = (g.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
@@ -294,6 +298,7 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
 __global__ __launch_bounds__(256) void k_linear_k3_fwd(const float* __restrict__ x4, const float* __restrict__ W, int ldw,
                                                         const float* __restrict__ b, int M, int Nout, int relu,
                                                         float* __restrict__ out, int ldo, int out_bf16) {
+    M = limit_rows(M);
     const int nq = Nout / 4, rpi = 256 / nq;                 // column quads per row; rows per block iteration (nq divides 256)
     const int q = threadIdx.x % nq, rl = threadIdx.x / nq, n = q * 4;
     float w0[4], w1[4], w2[4], bb[4];
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void k_linear_k3_fwd_any(const float* __restri
                                                             float* __restrict__ out, int ldo, int out_bf16) {
     const int nq = Nout / 4;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)M * nq) return;
+    if (gid >= (long)limit_rows(M) * nq) return;
     const int m = (int)(gid / nq), n = (int)(gid % nq) * 4;
     const float4 x = ld4(x4 + (size_t)m * 4);
     float o[4];
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(1024) void k_linear_k3_bwd(const float* __restrict_
                                                          int dh_bf16) {
     const int col = threadIdx.x & 255, slab = threadIdx.x >> 8;
     const int n = blockIdx.y * 256 + col;
+    M = limit_rows(M);
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     __shared__ float4 red[3][256];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -430,6 +436,7 @@ __global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float ds[64 * NO];
     const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
     const int j = blockIdx.y * 256 + threadIdx.x;
+    M = limit_rows(M);
     const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
     float acc[NO];
 #pragma unroll
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256) void k_rows_act_fwd(const float* __restrict__ 
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long m = gid >> lg;
     const int c = (int)(gid & (G - 1));
-    const bool row = m < M, on = row && c < C;        // every lane of a group takes part in the shuffles
+    const bool row = m < limit_rows(M), on = row && c < C;        // every lane of a group takes part in the shuffles
     const float x = on ? pre[(size_t)m * ldp + c] : -INFINITY;
     float v;
     if (kind == 1) {
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(256) void k_rows_act_bwd(const float* __restrict__ 
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long m = gid >> lg;
     const int c = (int)(gid & (G - 1));
-    const bool row = m < M, on = row && c < C;
+    const bool row = m < limit_rows(M), on = row && c < C;
     const float g = on ? dout[(size_t)m * lddo + c] : 0.f;
     const float o = (on && kind != 0) ? out[(size_t)m * ldo + c] : 0.f;
     float d;

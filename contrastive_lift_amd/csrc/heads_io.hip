@@ -1,5 +1,6 @@
 // heads_io.hip -- appearance VM gather (a9), MLP input assembly (a10) and alpha compositing (a13), fwd + bwd.
 #include "clift_dev.h"
+CLIFT_ROWS_LIMIT_BINDER(heads_io)
 #include <stdlib.h>
 
 // ============================================================================ appearance gather
@@ -12,6 +13,7 @@ __global__ __launch_bounds__(256) void k_app_gather_fwd(MarchP m, VmP t, const f
     if (gid >= total) return;
     const int g4 = t.comps / 4, G = 3 * g4;
     const int s = (int)(gid / G), j = (int)(gid - (long)s * G);
+    if (rows_cut(s)) return;
     const int i = j / g4, c4 = (j - i * g4) * 4;
     const int sid = act[s];
     const int r = sid / m.S, k = sid - r * m.S;
@@ -86,7 +88,7 @@ extern "C" int clift_app_encode_points(const float* feat, int ldf, int nf, int p
 __global__ __launch_bounds__(256) void k_active_xyz(MarchP m, const float* __restrict__ rays, const float* __restrict__ jitter,
                                                      const int* __restrict__ act, int M, float* __restrict__ xa) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= M) return;
+    if (s >= limit_rows(M)) return;
     const int sid = act[s];
     const int r = sid / m.S, k = sid - r * m.S;
     const RayG g = load_ray(rays, r, m);
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
     const bool xcd = gr.xcd_stride > 0;
     const int C = t.comps, G = 3 * C;
     const long nthreads = (long)gridDim.x * blockDim.x;
+    M = limit_rows(M);
     const long total = (long)((M + seg_len - 1) / seg_len) * G;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += nthreads) {
         const int w = (int)(gid / G), j = (int)(gid - (long)w * G);
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(256) void k_app_encode_fwd(const float* __restrict_
     if (gid >= total) return;
     const int J = nf + 4;
     const int s = (int)(gid / J), j = (int)(gid - (long)s * J);
+    if (rows_cut(s)) return;
     // the row is written through `put` so that it can be bf16-stored (bf16 mode: it is only ever a matrix-core operand)
     float* xf = X + (size_t)s * ldx;
     unsigned short* xh = reinterpret_cast<unsigned short*>(X) + (size_t)s * ldx;
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(256) void k_app_encode_bwd(const float* __restrict_
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int s = (int)(gid / lddf), c = (int)(gid - (long)s * lddf);
+    if (rows_cut(s)) return;
     float v = 0.f;
     if (c < nf) {
         const float* g = dX + (size_t)s * ldx;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd_sample(const float* __res
                                                                float* __restrict__ d_rgb_s, float* __restrict__ d_sem_s,
                                                                float* __restrict__ d_inst_s, float* __restrict__ g_w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+    if (i >= limit_rows(M)) return;
     const int sid = act[i];
     const int r = sid / S;
     const float wv = w[sid];

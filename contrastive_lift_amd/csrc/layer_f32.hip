@@ -21,6 +21,7 @@
 // ordinary global loads with s_waitcnt vmcnt(0), which would drain the prefetched tile and the output stores; each asm wait is
 // tied to the registers it guards as a data dependency, and sched_barriers pin the read-ahead order.
 #include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(layer_f32)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -72,6 +73,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     float4* const wl4 = lds + 2 * LF_TILE + (GEN ? LF_XROWS : 0);            // OUTV: wl4[c * 64 + k / 4]
     float4* const part = wl4 + 256;                                          // OUTV: part[(tile & 1) * 256 + wave * 32 + row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    if (rows_limited()) {          // sync-free step: the launch was sized by a capacity; re-balance the row ranges over the true row count
+        g.M = limit_rows(g.M);
+        rows_per_block = ((g.M + (int)gridDim.x - 1) / (int)gridDim.x + LF_ROWS - 1) / LF_ROWS * LF_ROWS;
+    }
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + LF_ROWS - 1) / LF_ROWS;
@@ -366,6 +371,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_f32_stream(GemmP g, int rows_p
     __shared__ __attribute__((aligned(16))) unsigned char lds[WG_STAGES * WG_STAGE];         // 120 KB, the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int b = blockIdx.x, slice = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
+    if (rows_limited()) {
+        g.K = limit_rows(g.K);
+        rows_per_range = ((g.K + 63) / 64 + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    }
     const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + WG_ROWS - 1) / WG_ROWS;

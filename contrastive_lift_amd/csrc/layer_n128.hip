@@ -11,6 +11,7 @@
 // 40-chunk row keeps the permutation inside its 8-chunk groups); a ds_read_b128 pass of 16 lanes (rows r .. r+15, one chunk index)
 // then touches every bank exactly twice -- the minimum for 256 bytes.
 #include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(layer_n128)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,6 +52,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     float4* const part = wl4 + 128;          // OUTV: part[(tile & 1) * 256 + wave * 32 + row of the wave's half]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wc = wave & 3, wr = wave >> 2;
+    if (rows_limited()) {          // sync-free step: re-balance the row ranges over the true row count (see layer_f32.hip)
+        g.M = limit_rows(g.M);
+        rows_per_block = ((g.M + (int)gridDim.x - 1) / (int)gridDim.x + LN_ROWS - 1) / LN_ROWS * LN_ROWS;
+    }
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + LN_ROWS - 1) / LN_ROWS;
@@ -308,6 +313,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     // (b >> 3) & 3 of the result -- dY columns 128 (quad >> 1) .., X columns 128 (quad & 1) .. -- for row range (b & 7) + 8 (b >> 5): the four
     // quadrant-blocks of a range have ids 8 apart, i.e. share an XCD, so dY and X are fetched from HBM once and re-read from that L2
     const int b = blockIdx.x;
+    if (rows_limited()) {
+        g.K = limit_rows(g.K);
+        const int nranges = quads == 4 ? 64 : (int)gridDim.x;
+        rows_per_range = ((g.K + nranges - 1) / nranges + ROWS - 1) / ROWS * ROWS;
+    }
     const int quad = quads == 4 ? (b >> 3) & 3 : 0, range = quads == 4 ? (b & 7) + 8 * (b >> 5) : b;
     const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
     if (rbeg >= rend) return;

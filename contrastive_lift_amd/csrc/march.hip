@@ -1,6 +1,7 @@
 // march.hip -- ray marching: density VM lookup, transmittance scan, compaction, and their backward.
 // Reference rows: a4 a5 a6 a7 a8.
 #include "clift_dev.h"
+CLIFT_ROWS_LIMIT_BINDER(march)
 
 // ============================================================================ density forward
 // 4 lanes per sample, lane q owns channels [4q, 4q+4) (+16 per extra pass) of all three plane/line pairs:
@@ -454,6 +455,41 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ cn
     if (t == 1023) start[N] = part[1023];
 }
 
+// Capped form for sync-free steps: the compacted buffers hold `cap` rows.  Offsets are clamped to cap (rays past the cap simply lose
+// their samples -- memory-safe, and reported), limit_out[0] = min(total, cap) is the row count every per-sample kernel clamps to
+// (clift_bind_rows_limit), overflow[0] = max(overflow[0], total) when total > cap.
+__global__ __launch_bounds__(1024) void k_scan_counts_capped(const int* __restrict__ cnt, int N, int* __restrict__ start, int cap,
+                                                              int* __restrict__ limit_out, int* __restrict__ overflow) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    const int b = t * per, e = min(b + per, N);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = b; i < e; ++i) { start[i] = min(run, cap); run += cnt[i]; }
+    if (t == 1023) {
+        const int total = part[1023];
+        start[N] = min(total, cap);
+        limit_out[0] = min(total, cap);
+        if (total > cap) atomicMax(overflow, total);
+    }
+}
+
+extern "C" int clift_scan_counts_capped(const int* n_active, int N, int* ray_start, int cap, int* limit_out, int* overflow, clift_stream_t s) {
+    CLIFT_REQUIRE(N >= 0 && cap >= 0, "clift_scan_counts_capped: negative N or cap");
+    k_scan_counts_capped<<<1, 1024, 0, as_stream(s)>>>(n_active, N, ray_start, cap, limit_out, overflow);
+    return clift_check_launch("clift_scan_counts_capped");
+}
+
 extern "C" int clift_scan_counts(const int* n_active, int N, int* ray_start, clift_stream_t s) {
     CLIFT_REQUIRE(N >= 0, "clift_scan_counts: negative N");
     k_scan_counts<<<1, 1024, 0, as_stream(s)>>>(n_active, N, ray_start);
@@ -461,7 +497,7 @@ extern "C" int clift_scan_counts(const int* n_active, int N, int* ray_start, cli
 }
 
 __global__ __launch_bounds__(256) void k_compact_fill(const float* __restrict__ w, const int* __restrict__ start, int N, int S,
-                                                       float thres, int* __restrict__ act) {
+                                                       float thres, int* __restrict__ act, int cap) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= N) return;
     const int l = lane_id();
@@ -471,7 +507,7 @@ __global__ __launch_bounds__(256) void k_compact_fill(const float* __restrict__ 
         const bool on = (k < S) && (w[(size_t)r * S + k] > thres);
         const unsigned long long bal = __ballot(on);
         const int pre = __popcll(bal & ((1ull << l) - 1ull));
-        if (on) act[run + pre] = r * S + k;
+        if (on && run + pre < cap) act[run + pre] = r * S + k;
         run += __popcll(bal);
     }
 }
@@ -479,8 +515,15 @@ __global__ __launch_bounds__(256) void k_compact_fill(const float* __restrict__ 
 extern "C" int clift_compact_fill(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx, clift_stream_t s) {
     if (N <= 0) return 0;
     CLIFT_REQUIRE((long)N * S < 2147483647L, "clift_compact_fill: N*S overflows int32 sample ids");
-    k_compact_fill<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(w, ray_start, N, S, thres, act_idx);
+    k_compact_fill<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(w, ray_start, N, S, thres, act_idx, 2147483647);
     return clift_check_launch("clift_compact_fill");
+}
+
+extern "C" int clift_compact_fill_capped(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx, int cap, clift_stream_t s) {
+    if (N <= 0) return 0;
+    CLIFT_REQUIRE((long)N * S < 2147483647L, "clift_compact_fill_capped: N*S overflows int32 sample ids");
+    k_compact_fill<<<cdiv(N, 4), 256, 0, as_stream(s)>>>(w, ray_start, N, S, thres, act_idx, cap);
+    return clift_check_launch("clift_compact_fill_capped");
 }
 
 // ============================================================================ fold the 8 per-XCD accumulation copies

@@ -7,6 +7,7 @@
 // dY and one X element per MFMA step (row-contiguous, conflict-free without any swizzle).  bf16-stored X is widened in the
 // register (exact), so both storage modes give fp32 products.
 #include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(narrow_stream)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -41,6 +42,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
     constexpr int XBYTES = NS_ROWS * 256 * (XB ? 2 : 4), STAGE = XBYTES + NS_ROWS * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS_STAGES * STAGE];          // the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    if (rows_limited()) {          // sync-free step: re-balance the row ranges over the true row count (see layer_f32.hip)
+        M = limit_rows(M);
+        rows_per_block = ((M + (int)gridDim.x - 1) / (int)gridDim.x + NS_ROWS - 1) / NS_ROWS * NS_ROWS;
+    }
     const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + NS_ROWS - 1) / NS_ROWS;
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     constexpr int ROWS = 32, TILEB = ROWS * 32 * 4;                          // stage: up to 32 rows x 32 floats
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB];   // the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    if (rows_limited()) {
+        g.M = limit_rows(g.M);
+        rows_per_block = ((g.M + (int)gridDim.x - 1) / (int)gridDim.x + ROWS - 1) / ROWS * ROWS;
+    }
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + ROWS - 1) / ROWS;

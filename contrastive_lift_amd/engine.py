@@ -369,7 +369,34 @@ class RenderCtx:
     pass
 
 
-def _density_march(model, renderer, rays, jitter):
+INT_MAX = 2 ** 31 - 1
+_rows_limit = {}
+_limit_owner = None          # the sync-free chunk whose row count the limit currently holds
+
+
+def rows_limit(dev):
+    """The library's dynamic row limit of this device: int32 [limit, overflow], bound once (clift_bind_rows_limit).  limit is INT_MAX
+    (no effect) except inside a sync-free pass; ``reset_rows_limit`` restores that."""
+    key = (dev.type, dev.index)
+    t = _rows_limit.get(key)
+    if t is None:
+        t = torch.tensor([INT_MAX, 0], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        call("clift_bind_rows_limit", ptr(t))
+        _rows_limit[key] = t
+    return t
+
+
+def reset_rows_limit(dev=None):
+    """Back to 'no limit' (stream-ordered).  Called at the end of every sync-free pass, and defensively by the point-wise utilities."""
+    global _limit_owner
+    _limit_owner = None
+    for key, t in _rows_limit.items():
+        if dev is None or key == (dev.type, dev.index):
+            t[0:1].fill_(INT_MAX)
+
+
+def _density_march(model, renderer, rays, jitter, cap=None):
     views = model.named_views()
     N = rays.shape[0]
     S = int(renderer.n_samples)
@@ -386,12 +413,27 @@ def _density_march(model, renderer, rays, jitter):
     call("clift_march_fwd", C.byref(ms), ptr(rays), ptr(jitter), N, ptr(sigma), ptr(alpha), ptr(T), ptr(w), ptr(ray_out),
          ptr(n_active), st)
     ray_start = torch.empty((N + 1,), dtype=torch.int32, device=dev)
-    call("clift_scan_counts", ptr(n_active), N, ptr(ray_start), st)
-    M = int(ray_start[N].item())        # the one host sync of the chunk: sizes the active-sample buffers
-    act_idx = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
-    call("clift_compact_fill", ptr(w), ptr(ray_start), N, S, float(renderer.raymarch_weight_thres), ptr(act_idx), st)
+    if cap is None:
+        call("clift_scan_counts", ptr(n_active), N, ptr(ray_start), st)
+        M = int(ray_start[N].item())        # the one host sync of the chunk: sizes the active-sample buffers
+        act_idx = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+        call("clift_compact_fill", ptr(w), ptr(ray_start), N, S, float(renderer.raymarch_weight_thres), ptr(act_idx), st)
+    else:
+        # sync-free: buffers and grids are sized by the capacity, the true count stays on the device (rows_limit()[0]) where every
+        # per-sample kernel clamps to it; an overflow (count > cap: samples dropped) is recorded in rows_limit()[1] for the caller
+        if MLP_PRECISION != 0:
+            raise _lib.CliftError("sync-free steps (cap=...) are built for the exact-fp32 path only")
+        lim = rows_limit(dev)
+        M = max(int(cap), 1)
+        call("clift_scan_counts_capped", ptr(n_active), N, ptr(ray_start), M, ptr(lim), C.c_void_p(lim.data_ptr() + 4), st)
+        act_idx = torch.empty((M,), dtype=torch.int32, device=dev)
+        call("clift_compact_fill_capped", ptr(w), ptr(ray_start), N, S, float(renderer.raymarch_weight_thres), ptr(act_idx), M, st)
     ctx = RenderCtx()
     ctx.ms, ctx.res, ctx.N, ctx.S, ctx.M = ms, res, N, S, M
+    ctx.capped = cap is not None
+    if ctx.capped:
+        global _limit_owner
+        _limit_owner = ctx
     ctx.rays, ctx.jitter = rays, jitter
     ctx.alpha, ctx.T, ctx.w, ctx.ray_out, ctx.ray_start, ctx.act_idx = alpha, T, w, ray_out, ray_start, act_idx
     return ctx
@@ -409,13 +451,14 @@ def _check_rays(rays, jitter):
     return rays, jitter
 
 
-def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("app", "sem", "fast", "slow")):
+def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("app", "sem", "fast", "slow"),
+                   cap=None):
     """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context.
     ``grad_heads``: the heads a backward pass may be run through ("app", "sem", "fast", "slow"); a head that is not named retains
     no activations (the training main pass never differentiates the instance heads, T:155; inference none)."""
     rays, jitter = _check_rays(rays, jitter)
     views = model.named_views()
-    ctx = _density_march(model, renderer, rays, jitter)
+    ctx = _density_march(model, renderer, rays, jitter, cap)
     N, S, M = ctx.N, ctx.S, ctx.M
     dev = rays.device
     st = stream()
@@ -535,6 +578,11 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
     N, S, M = ctx.N, ctx.S, ctx.M
     dev = ctx.rays.device
     st = stream()
+    if getattr(ctx, "capped", False):
+        global _limit_owner
+        if _limit_owner is not ctx:        # another chunk was marched since: put THIS chunk's row count back (device-to-device, 4 bytes)
+            rows_limit(dev)[0:1].copy_(ctx.ray_start[N:N + 1])
+            _limit_owner = ctx
     Ccls, D = ctx.C, ctx.D
     want_rgb, want_sem, want_inst = ctx.want
     g_rgb = g_rgb.contiguous() if (g_rgb is not None and want_rgb) else None
@@ -651,12 +699,12 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes
-def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem", "fast", "slow")):
+def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem", "fast", "slow"), cap=None):
     """renderer.py:178-217 (head='instance') / :259-300 (head='semantic'): density and weights carry no gradient,
     only the head does.  ``grad_heads`` as in render_forward."""
     rays, jitter = _check_rays(rays, jitter)
     views = model.named_views()
-    ctx = _density_march(model, renderer, rays, jitter)
+    ctx = _density_march(model, renderer, rays, jitter, cap)
     N, S, M = ctx.N, ctx.S, ctx.M
     dev = rays.device
     st = stream()
@@ -728,6 +776,7 @@ def _points(xyz):
 def density_points(model, xyz, activation=True):
     """TensorVMSplit.compute_density / compute_density_without_activation on normalised points (no gradient)."""
     x = _points(xyz)
+    reset_rows_limit(x.device)
     views = model.named_views()
     vd = vm_struct(views, "density", grid_res(views))
     out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
@@ -740,6 +789,7 @@ def density_points(model, xyz, activation=True):
 def appearance_feature_points(model, xyz):
     """TensorVMSplit.compute_appearance_feature: VM products + basis Linear (no gradient)."""
     x = _points(xyz)
+    reset_rows_limit(x.device)
     n = x.shape[0]
     views = model.named_views()
     va = vm_struct(views, "appearance", grid_res(views))
@@ -756,6 +806,7 @@ def appearance_feature_points(model, xyz):
 def xyz_mlp_points(seq, xyz):
     """Evaluate an xyz MLP head on arbitrary points (inference utility, no gradient)."""
     x = _points(xyz)
+    reset_rows_limit(x.device)
     M = x.shape[0]
     xa = torch.zeros((M, 4), dtype=torch.float32, device=x.device)
     xa[:, :3] = x[:, :3]
@@ -770,6 +821,7 @@ def appearance_mlp_points(module, viewdirs, features):
     """MLPRenderFeature.forward(viewdirs, features) (tensoRF.py:400-411), no gradient."""
     f = _lib.f32(features, "features").reshape(-1, features.shape[-1]).contiguous()
     d = _lib.f32(viewdirs, "viewdirs").reshape(-1, 3).contiguous()
+    reset_rows_limit(f.device)
     n, nf = f.shape
     (W1, b1), (W2, b2), (W3, b3) = [(m.weight, m.bias) for m in module.mlp if isinstance(m, torch.nn.Linear)]
     ldx = _pitch(W1)

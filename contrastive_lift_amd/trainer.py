@@ -28,7 +28,8 @@ def default_config(**over):
              decay_step=[9, 10], decay_gamma=0.5, temperature=100.0,
              lambda_segment=1.2, segment_grouping_mode="argmax_conf", segment_optimization_epoch=6, batch_size_segments=32,
              max_rays_segments=1024, use_symmetric_ce=False, ce_alpha=0.85, ce_beta=0.15, reweight_fg=False,
-             mlp_dtype="fp32")     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
+             mlp_dtype="fp32",     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
+             nosync=False)         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
     c.update(over)
     return types.SimpleNamespace(**c)
 
@@ -95,6 +96,11 @@ class HotPathTrainer:
         self.setup_optimizers()
         self.on_train_epoch_start()
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)   # rgb, sem, tv, clustering (last step)
+        # sync-free mode: per pass a capacity for the compacted buffers, learnt from the first (synchronising) steps and followed
+        # asynchronously afterwards; see _capacity / _follow
+        self.nosync = bool(getattr(config, "nosync", False)) and getattr(config, "mlp_dtype", "fp32") in ("fp32", "f32", None)
+        self._caps = {}
+        self.overflow_steps = 0
 
     # ------------------------------------------------------------------ optimizers (T:98-103)
     def setup_optimizers(self):
@@ -121,6 +127,47 @@ class HotPathTrainer:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             g.mul_(1.0 / self.world)
 
+    # ------------------------------------------------------------------ sync-free capacity bookkeeping
+    NOSYNC_WARMUP, NOSYNC_HEADROOM = 2, 1.3
+
+    def _capacity(self, key, n_rays):
+        """Capacity (rows of the compacted buffers) of a chunk of ``n_rays`` rays in pass ``key``, or None while that pass is still being
+        learnt (the first steps synchronise like the default mode).  Before answering, absorb the asynchronous report of the previous
+        step: true row count (the capacity follows its maximum with 30 % headroom) and overflow (count > capacity: that step dropped
+        samples -- counted in ``overflow_steps`` and the capacity is raised at once)."""
+        if not self.nosync:
+            return None
+        st = self._caps.setdefault((key, n_rays), {"seen": 0, "max": 0, "cap": None, "probe": None})
+        pr = st["probe"]
+        if pr is not None and pr[1].query():
+            m, over = int(pr[0][0]), int(pr[0][1])
+            st["probe"] = None
+            st["max"] = max(st["max"], m, over)
+            if over > 0:
+                self.overflow_steps += 1
+                engine.rows_limit(self.device)[1:2].zero_()
+        if st["seen"] < self.NOSYNC_WARMUP:
+            return None
+        limit_all = n_rays * int(self.renderer.n_samples)
+        st["cap"] = min(limit_all, max(4096, -(-int(self.NOSYNC_HEADROOM * st["max"]) // 4096) * 4096))
+        return st["cap"]
+
+    def _follow(self, key, n_rays, ctx):
+        """After a chunk's forward: remember its row count -- read directly in the learning steps, through a pinned 8-byte copy + event
+        (no wait) in the sync-free ones."""
+        if not self.nosync:
+            return
+        st = self._caps[(key, n_rays)]
+        st["seen"] += 1
+        if not ctx.capped:
+            st["max"] = max(st["max"], int(ctx.M))
+        elif st["probe"] is None:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(engine.rows_limit(self.device), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["probe"] = (host, ev)
+
     # ------------------------------------------------------------------ main pass (T:151-208)
     def main_pass(self, batch, jitter=None, white_bg=None, lean=False, segments=None, segment_jitter=None):
         """batch: dict with rays (B,8), rgbs (B,3), probabilities (B,C), confidences (B,), mask (B,) bool/float.
@@ -140,8 +187,11 @@ class HotPathTrainer:
                 wb = self.white_bg or bool(torch.rand((1,)) < 0.5)       # renderer.py:164
             else:
                 wb = bool(white_bg)
+            n_c = min(chunk, B - i)
             o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,
-                                           want_inst=not lean, grad_heads=("app", "sem"))        # T:155: the instance output is discarded
+                                           want_inst=not lean, grad_heads=("app", "sem"),        # T:155: the instance output is discarded
+                                           cap=self._capacity("main", n_c))
+            self._follow("main", n_c, ctx)
             ctxs.append(ctx)
             outs.append(o)
         rgb = outs[0]["rgb"] if len(outs) == 1 else torch.cat([o["rgb"] for o in outs], 0)
@@ -175,6 +225,8 @@ class HotPathTrainer:
             self._segment_term(segments, segment_jitter, gv, w_sem * float(c.lambda_segment))
         tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         self.losses[2] = tv
+        if self.nosync:
+            engine.reset_rows_limit(self.device)
         self._allreduce(self.main_range)
         self.opt_main.step(skip=() if sem_on else ("net_sem",))      # no semantic term yet: the head's grad is None in the reference
         self.last_outputs = (rgb, sem)
@@ -191,7 +243,8 @@ class HotPathTrainer:
             return
         if jitter is None and c.perturb != 0:
             jitter = c.perturb * torch.rand(n, device=self.device)
-        feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic", grad_heads=("sem",))
+        feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic", grad_heads=("sem",), cap=self._capacity("seg", n))
+        self._follow("seg", n, ctx)
         C = feats.shape[1]
         G = int(seg["n_groups"])
         group = seg["group"].to(device=self.device, dtype=torch.int32).contiguous()
@@ -216,7 +269,9 @@ class HotPathTrainer:
             rays = img["rays"]
             n = rays.shape[0]
             jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
-            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",))      # slow half: detached (T:268)
+            (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",),     # slow half: detached (T:268)
+                                                      cap=self._capacity("inst", n))
+            self._follow("inst", n, ctx)
             if c.instance_loss_mode == "slow_fast":
                 # reference order: the features (fast and slow halves) are rendered first (T:214), THEN the EMA step of the slow
                 # net at the top of the loss (T:258-259) -- the slow features of this step come from the pre-update weights
@@ -238,6 +293,8 @@ class HotPathTrainer:
                     g_inst = g_inst + 0.1 * inst / (nrm.clamp_min(1e-30) * inst.shape[0])
             self.losses[3] = self.losses[3] + loss
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
+        if self.nosync:
+            engine.reset_rows_limit(self.device)
         self._allreduce(self.inst_range)
         self.opt_inst.step()
 

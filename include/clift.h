@@ -121,6 +121,19 @@ int clift_scan_counts(const int* n_active, int N, int* ray_start, clift_stream_t
 int clift_compact_fill(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx,
                        clift_stream_t s);
 
+/* ---- sync-free steps (no read-back of the active-sample count; the reference syncs at every boolean-mask gather,
+ * renderer.py:97,105).  The caller sizes the compacted buffers by a capacity `cap` and binds ONE device int as the
+ * library's dynamic row limit: every per-sample kernel then clamps its row count to min(its argument, *limit) and the
+ * persistent kernels re-balance their row ranges over the true count.  The caller keeps INT_MAX in *limit outside a
+ * pass; clift_scan_counts_capped writes min(total, cap) into it (limit_out = the bound address), clamps the offsets to
+ * cap and records total in *overflow when total > cap (samples past the capacity are dropped -- memory-safe, and the
+ * caller is expected to raise the capacity); clift_compact_fill_capped writes only rows < cap. */
+int clift_bind_rows_limit(const int* dev_limit);   /* NULL unbinds; one-time, synchronous */
+int clift_scan_counts_capped(const int* n_active, int N, int* ray_start, int cap, int* limit_out, int* overflow,
+                             clift_stream_t s);
+int clift_compact_fill_capped(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx, int cap,
+                              clift_stream_t s);
+
 /* ---- a9: tensoRF.py:127-134 (plane x line products, plane-major concat) on the compacted samples.
  * F (M, 3*comps); xa (M, 4) = [xn.x, xn.y, xn.z, 0] (input of the xyz MLP heads, tensoRF.py:142-156). */
 int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter,

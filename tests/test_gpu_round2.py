@@ -581,3 +581,51 @@ def test_bf16_fused_head_forward_matches_per_layer_path(M):
     finally:
         engine.FUSE_HEAD_BF16 = True
         engine.set_mlp_precision(prev)
+
+
+# ============================================================================ sync-free steps (device-side row count)
+def test_sync_free_training_steps_match_synchronising_ones():
+    """config.nosync: after two learning steps the trainer never reads the active-sample count back -- buffers and grids are sized by a
+    capacity, every per-sample kernel clamps to the count on the device (clift_bind_rows_limit) and the persistent kernels re-balance
+    their row ranges over it.  Same batches, jitter and white-background flags through a default and a sync-free trainer: losses
+    equal, gradients equal up to accumulation order, parameters after six steps within a fraction of a learning-rate step; chunked
+    main pass (two chunks: the limit is handed back and forth between chunks for the backward); no overflow; the limit is INT_MAX again
+    after every pass."""
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    g = torch.Generator().manual_seed(5)
+    jit = [torch.rand(2048, generator=g).to(DEV) for _ in range(6)]
+    jit_i = [torch.rand(512, generator=g).to(DEV) for _ in range(6)]
+    runs = {}
+    for nosync in (False, True):
+        for chunk in (0, 1024):
+            model, renderer, pool = synthetic.make_scene(grid=64, num_classes=6, max_instances=3, seed=9, device=DEV, image=128, n_cams=2)
+            cfg = default_config(chunk=chunk, instance_optimization_epoch=0, late_semantic_optimization=0, nosync=nosync)
+            tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
+            batches = [synthetic.make_batches(pool, 2048, 512, 6, 9, seed=40 + i, device=DEV) for i in range(3)]
+            hist = []
+            for step in range(6):
+                b = batches[step % 3]
+                tr.main_pass(b[0], jitter=jit[step], white_bg=bool(step % 2))
+                gm = {k: v.detach().clone() for k, v in model.named_grad_views().items() if not k.startswith("render_instance")}
+                lm = tr.losses.clone()
+                tr.instance_pass(b[1], jitter=jit_i[step])
+                hist.append((gm, lm, float(tr.losses[3])))
+                if nosync:
+                    assert int(engine.rows_limit(torch.device(DEV, torch.cuda.current_device()))[0]) == engine.INT_MAX
+            if nosync:
+                assert tr.overflow_steps == 0
+                caps = {k: v["cap"] for k, v in tr._caps.items()}
+                assert all(c is not None and c % 4096 == 0 for c in caps.values()), caps
+            runs[(nosync, chunk)] = (hist, model.param_flat.detach().clone())
+    for chunk in (0, 1024):
+        ref, got = runs[(False, chunk)], runs[(True, chunk)]
+        for step in (0, 3, 5):                      # 0: learning step (synchronising in both), 3 and 5: sync-free
+            gm0, lm0, li0 = ref[0][step]
+            gm1, lm1, li1 = got[0][step]
+            rel_close(lm1[:3], lm0[:3], 2e-4, what=f"losses step {step} chunk {chunk}")
+            rel_close(li1, li0, 2e-3, what=f"slow-fast loss step {step} chunk {chunk}")
+            if step == 3:
+                for k in gm0:
+                    grad_close(gm1[k], gm0[k], what=f"sync-free grad {k} (chunk {chunk})", outlier_frac=5e-3)
+        assert float((got[1] - ref[1]).abs().max()) <= 0.5 * 1e-2
