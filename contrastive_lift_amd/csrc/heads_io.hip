@@ -118,18 +118,19 @@ constexpr int APP_SEG = 8;
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
                                                             const float* __restrict__ jitter, const int* __restrict__ act, int M,
-                                                            const float* __restrict__ dF, int seg_len) {
+                                                            const float* __restrict__ dF, int seg_len, int plane_sel) {
+    // plane_sel < 0: all three planes in this launch (lane = (plane, channel)); 0..2: only that plane (A/B probe of the L2 working set)
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = line_lds_floats(t.res, t.comps);
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
     const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
     const bool xcd = gr.xcd_stride > 0;
-    const int C = t.comps, G = 3 * C;
+    const int C = t.comps, G = 3 * C, GL = plane_sel < 0 ? G : C;
     const long nthreads = (long)gridDim.x * blockDim.x;
     M = limit_rows(M);
-    const long total = (long)((M + seg_len - 1) / seg_len) * G;
+    const long total = (long)((M + seg_len - 1) / seg_len) * GL;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += nthreads) {
-        const int w = (int)(gid / G), j = (int)(gid - (long)w * G);
+        const int w = (int)(gid / GL), j = (int)(gid - (long)w * GL) + (plane_sel < 0 ? 0 : plane_sel * C);
         const int i = j / C, c = j - i * C;
         int a, b, v;
         vm_axes(i, a, b, v);
@@ -206,18 +207,22 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     CLIFT_REQUIRE(h_app->comps % 4 == 0, "clift_app_gather_bwd: comps must be a multiple of 4");
     if (M <= 0) return 0;
     const int seg = APP_SEG;
-    const long total = (long)cdiv(M, seg) * 3 * h_app->comps;
     const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
-    const int want = cdiv(total, threads);
-    const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
-    if (use_lds) {
-        if (lds_bytes > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg);
-    } else {
-        k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg);
+    const bool split = getenv("CLIFT_APP_SPLIT") != nullptr;          // A/B probe: one launch per plane
+    for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
+        const int sel = split ? pass : -1;
+        const long total = (long)cdiv(M, seg) * (split ? 1 : 3) * h_app->comps;
+        const int want = cdiv(total, threads);
+        const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
+        if (use_lds) {
+            if (lds_bytes > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel);
+        } else {
+            k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel);
+        }
     }
     return clift_check_launch("clift_app_gather_bwd");
 }
