@@ -95,7 +95,7 @@ def main():
         tr.training_step(batches[i % n_batches], lean=a.lean)
     # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
     # replays exactly these steps with per-launch events
-    snap = (model.param_flat.clone(), tr.opt_main.state_dict(), tr.opt_inst.state_dict())
+    snap = (model.param_flat.clone(), tr.opt_main.state_dict(), tr.opt_inst.state_dict(), tr._rng_state())
     sync_all()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -112,9 +112,16 @@ def main():
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
         engine.gemm (clift_gemm) and engine.first2 (clift_xyz_head_first2_fwd: the K = 3 layer generated inside the persistent kernel
         of the first 256 x 256 layer -- kind "fwd_gen", FLOPs of both layers)."""
-        model.param_flat.copy_(snap[0])
-        tr.opt_main.load_state_dict(snap[1])
-        tr.opt_inst.load_state_dict(snap[2])
+        def restore():
+            model.param_flat.copy_(snap[0])
+            tr.opt_main.load_state_dict(snap[1])
+            tr.opt_inst.load_state_dict(snap[2])
+            tr.load_rng_state(snap[3])          # the per-ray jitter: same samples, same launch sizes
+        restore()
+        if os.environ.get("CLIFT_BENCH_PRESTEP"):
+            tr.training_step(batches[0], lean=a.lean)
+            sync_all()
+            restore()
         out = []
 
         def bracket(kind, M, N, K, extra_flops, fn):
@@ -149,8 +156,16 @@ def main():
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays
     # GPU-bound, so an event pair measures the kernel and not a host gap; pass 2: every matrix-core launch, for the informational all_gemm
     # split (the ~60 events per step make that pass host-bound, so its per-launch times are upper bounds).
-    rec = replay(lambda kind, N: kind in ("fwd", "fwd_gen", "fwd_out") and N > 128)
-    rec_all = replay(lambda kind, N: True)
+    # The pass runs TWICE and each launch keeps the shorter of its two measurements: an event pair also contains any moment the GPU
+    # sat idle between the two records, and a single host hiccup (seen: 40 ms inside one bracket of the first process on a fresh box)
+    # would otherwise pass for kernel time.  The replays are deterministic (same state, same batches), so launch i is the same work.
+    def resolve(recs):
+        return [(kind, M, N, K, e0.elapsed_time(e1), xf) for kind, M, N, K, e0, e1, xf in recs]
+    dom_sel = lambda kind, N: kind in ("fwd", "fwd_gen", "fwd_out") and N > 128
+    rec, rec_b = resolve(replay(dom_sel)), resolve(replay(dom_sel))
+    if len(rec) == len(rec_b) and all(x[:4] == y[:4] for x, y in zip(rec, rec_b)):
+        rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, rec_b)]
+    rec_all = resolve(replay(lambda kind, N: True))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,16 +309,17 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
     count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
     tot_f, tot_ms, by = 0.0, 0.0, {}
     dom_f, dom_ms, dom_n = 0.0, 0.0, 0
-    for kind, M, N, K, e0, e1, xf in rec:
-        ms = e0.elapsed_time(e1)
+    for kind, M, N, K, ms, xf in rec:
         fl = 2.0 * M * N * K + xf
         tot_f += fl
         tot_ms += ms
         b = by.setdefault(kind, [0.0, 0.0, 0])
         b[0] += fl; b[1] += ms; b[2] += 1
     inst = {}
-    for kind, M, N, K, e0, e1, xf in rec_dom:
-        ms = e0.elapsed_time(e1)
+    dump = os.environ.get("CLIFT_BENCH_DUMP")
+    for kind, M, N, K, ms, xf in rec_dom:
+        if dump:
+            print(f"[dom] {kind} M={M} N={N} K={K} {ms:.4f} ms", file=sys.stderr)
         dom_f += 2.0 * M * N * K + xf; dom_ms += ms; dom_n += 1
         b = inst.setdefault(kind, [0.0, 0.0, 0])
         b[0] += 2.0 * M * N * K + xf; b[1] += ms; b[2] += 1
@@ -313,7 +329,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
         # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its
         # activations.  Algorithmic bytes per launch = A read + C written (M x 256 x 2 bytes each, bf16-stored) + weights (256 KB, L2).
         esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
-        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _, _ in rec_dom)
+        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec_dom)
         gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         return {"bound": "hbm", "kernel": "k_layer_bf16<false,3> (persistent streamed 256x256 forward layers: weights in registers, LDS-DMA ring, v_mfma_f32_32x32x16_bf16; bf16-stored activations)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,

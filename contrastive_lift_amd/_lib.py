@@ -76,7 +76,7 @@ _SIGNATURES = {
     "clift_compact_fill": ([_P, _P, _I, _I, _F, _P, _P], C.c_int),
     "clift_app_gather_fwd": ([_P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_active_xyz": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
-    "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_app_encode_bwd": ([_P, _I, _I, _I, _P, _I, _I, _P, _I, _P], C.c_int),
     "clift_gemm": ([_P, _P], C.c_int),

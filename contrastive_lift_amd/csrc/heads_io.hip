@@ -118,7 +118,8 @@ constexpr int APP_SEG = 8;
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
                                                             const float* __restrict__ jitter, const int* __restrict__ act, int M,
-                                                            const float* __restrict__ dF, int seg_len, int plane_sel) {
+                                                            const float* __restrict__ dF, int seg_len, int plane_sel,
+                                                            const float* __restrict__ xa) {
     // plane_sel < 0: all three planes in this launch (lane = (plane, channel)); 0..2: only that plane (A/B probe of the L2 working set)
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = line_lds_floats(t.res, t.comps);
@@ -144,11 +145,16 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
         float cv[4] = {0.f, 0.f, 0.f, 0.f}, ca[4] = {0.f, 0.f, 0.f, 0.f};
         const int s0 = w * seg_len, s1 = min(M, s0 + seg_len);
         for (int s = s0; s < s1; ++s) {
-            const int sid = act[s];
-            const int r = sid / m.S, k = sid - r * m.S;
-            const RayG g = load_ray(rays, r, m);
             float xn[3];
-            sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+            if (xa) {                                // the forward gather left the normalised position of every active sample in xa (M, 4):
+                const float4 p4 = *reinterpret_cast<const float4*>(xa + (size_t)s * 4);      // one broadcast 16-byte load instead of an
+                xn[0] = p4.x; xn[1] = p4.y; xn[2] = p4.z;                                    // integer division + the ray's slab set-up
+            } else {
+                const int sid = act[s];
+                const int r = sid / m.S, k = sid - r * m.S;
+                const RayG g = load_ray(rays, r, m);
+                sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+            }
             const Tap2 tx = make_tap(xn[a], t.res[a]), ty = make_tap(xn[b], t.res[b]), tz = make_tap(xn[v], t.res[v]);
             const float w4[4] = {tx.w0 * ty.w0, tx.w1 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w1};
             int nk[4] = {ty.i0 * W + tx.i0, ty.i0 * W + tx.i1, ty.i1 * W + tx.i0, ty.i1 * W + tx.i1};
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
 
 extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
                                     const float* rays, const float* jitter, const int* act_idx, int M, const float* dF,
-                                    clift_stream_t s) {
+                                    const float* xa, clift_stream_t s) {
     CLIFT_REQUIRE(h_app->comps % 4 == 0, "clift_app_gather_bwd: comps must be a multiple of 4");
     if (M <= 0) return 0;
     const int seg = APP_SEG;
@@ -219,9 +225,9 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
         if (use_lds) {
             if (lds_bytes > 48 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel);
+            k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel, xa);
         } else {
-            k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel);
+            k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel, xa);
         }
     }
     return clift_check_launch("clift_app_gather_bwd");

@@ -640,7 +640,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), stream())
+                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa), stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 

@@ -141,9 +141,11 @@ int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, cons
 /* xa only (instance / segment passes: renderer.py:204,285 evaluate the xyz heads without appearance). */
 int clift_active_xyz(const clift_march_t* h_m, const float* rays, const float* jitter, const int* act_idx, int M,
                      float* xa, clift_stream_t s);
+/* xa (nullable): the (M, 4) normalised positions clift_app_gather_fwd / clift_active_xyz produced for the same act_idx -- when
+ * given, the backward reads them instead of re-deriving each sample's position from its ray (same values, fewer instructions). */
 int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
                          const float* rays, const float* jitter, const int* act_idx, int M, const float* dF,
-                         clift_stream_t s);
+                         const float* xa, clift_stream_t s);
 
 /* ---- a10 input assembly: tensoRF.py:400-408,413-418.  X (M, ldx) = [feat(nf), dir(3), sin/cos PE(feat),
  * sin/cos PE(dir), zero pad]; ldx >= nf + 3 + 2*pe_feat*nf + 2*pe_view*3. */
