@@ -2,6 +2,7 @@
 #include "clift_dev.h"
 CLIFT_ROWS_LIMIT_BINDER(heads_io)
 #include <stdlib.h>
+#include <string.h>
 
 // ============================================================================ appearance gather
 // Thread = (active sample, 4-channel group).  The 3*comps/4 threads of one sample write one contiguous row of
@@ -112,26 +113,25 @@ extern "C" int clift_active_xyz(const clift_march_t* h_m, const float* rays, con
 // costs one load when the walk enters it and one atomic when the walk leaves it.  Line gradients accumulate in LDS and are
 // flushed once per block; plane gradients go to the per-XCD accumulation copies.
 // Measured at 265 k active samples (profiles/r01_scatter_notes.txt): 1 -> 667 us (no merging; the pre-walk kernel: 624), 2 -> 520,
-// 4 -> 469, 8 -> 461.
-constexpr int APP_SEG = 8;
+// 4 -> 469, 8 -> 461; with the LINE entries merged in registers as well (round 2, profiles/r02_scatter_notes.txt): 4 -> 359, 8 -> 327,
+// 16 -> 318, 32 -> 311.  Used when the caller has no xa or comps > 64; otherwise k_app_gather_bwd_u below (237 us).
+constexpr int APP_SEG = 16;
 
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr, const float* __restrict__ rays,
                                                             const float* __restrict__ jitter, const int* __restrict__ act, int M,
-                                                            const float* __restrict__ dF, int seg_len, int plane_sel,
-                                                            const float* __restrict__ xa) {
-    // plane_sel < 0: all three planes in this launch (lane = (plane, channel)); 0..2: only that plane (A/B probe of the L2 working set)
+                                                            const float* __restrict__ dF, int seg_len, const float* __restrict__ xa) {
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = line_lds_floats(t.res, t.comps);
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
     const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
     const bool xcd = gr.xcd_stride > 0;
-    const int C = t.comps, G = 3 * C, GL = plane_sel < 0 ? G : C;
+    const int C = t.comps, G = 3 * C;
     const long nthreads = (long)gridDim.x * blockDim.x;
     M = limit_rows(M);
-    const long total = (long)((M + seg_len - 1) / seg_len) * GL;
+    const long total = (long)((M + seg_len - 1) / seg_len) * G;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += nthreads) {
-        const int w = (int)(gid / GL), j = (int)(gid - (long)w * GL) + (plane_sel < 0 ? 0 : plane_sel * C);
+        const int w = (int)(gid / G), j = (int)(gid - (long)w * G);
         const int i = j / C, c = j - i * C;
         int a, b, v;
         vm_axes(i, a, b, v);
@@ -143,6 +143,15 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
         float* gl = gr.line[i] + xoff + c;
         int ck[4] = {-1, -1, -1, -1};      // open texels (y * W + x), -1 = empty
         float cv[4] = {0.f, 0.f, 0.f, 0.f}, ca[4] = {0.f, 0.f, 0.f, 0.f};
+        // the two open LINE entries, same idea: the LDS float atomics are the slowest thing in this kernel (probe: 491 -> 158 us without
+        // them, ~2.3 clocks per lane-op per CU), and a ray stays ~3 samples between two line texels
+        int lk[2] = {-1, -1};
+        float lacc[2] = {0.f, 0.f};
+        auto line_out = [&](int key, float val) {
+            if (LDS_LINES) atomicAdd(ll + key * C, val);
+            else if (xcd) __hip_atomic_fetch_add(gl + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(gl + (size_t)key * C, val);
+        };
         const int s0 = w * seg_len, s1 = min(M, s0 + seg_len);
         for (int s = s0; s < s1; ++s) {
             float xn[3];
@@ -186,23 +195,199 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
             const float gP = d * L, gL = d * P;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { ck[q] = nk[q]; cv[q] = nv[q]; ca[q] = fmaf(w4[q], gP, na[q]); }
-            if (LDS_LINES) {
-                if (tz.w0 != 0.f) atomicAdd(ll + tz.i0 * C, tz.w0 * gL);
-                if (tz.w1 != 0.f) atomicAdd(ll + tz.i1 * C, tz.w1 * gL);
-            } else if (xcd) {
-                if (tz.w0 != 0.f) __hip_atomic_fetch_add(gl + (size_t)tz.i0 * C, tz.w0 * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (tz.w1 != 0.f) __hip_atomic_fetch_add(gl + (size_t)tz.i1 * C, tz.w1 * gL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                if (tz.w0 != 0.f) unsafeAtomicAdd(gl + (size_t)tz.i0 * C, tz.w0 * gL);
-                if (tz.w1 != 0.f) unsafeAtomicAdd(gl + (size_t)tz.i1 * C, tz.w1 * gL);
-            }
+            const int n0 = tz.w0 != 0.f ? tz.i0 : -1, n1 = tz.w1 != 0.f ? tz.i1 : -1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (lk[q] >= 0 && lk[q] != n0 && lk[q] != n1) line_out(lk[q], lacc[q]);
+            const float a0 = n0 < 0 ? 0.f : (lk[0] == n0 ? lacc[0] : (lk[1] == n0 ? lacc[1] : 0.f));
+            const float a1 = n1 < 0 ? 0.f : (lk[0] == n1 ? lacc[0] : (lk[1] == n1 ? lacc[1] : 0.f));
+            lk[0] = n0; lk[1] = n1;
+            lacc[0] = fmaf(tz.w0, gL, a0); lacc[1] = fmaf(tz.w1, gL, a1);
         }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (lk[q] >= 0) line_out(lk[q], lacc[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (ck[q] >= 0) {
                 if (xcd) __hip_atomic_fetch_add(gp + (size_t)ck[q] * C, ca[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else unsafeAtomicAdd(gp + (size_t)ck[q] * C, ca[q]);
             }
+    }
+    if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
+}
+
+// ---------------------------------------------------------------------------- the same walk, one WAVE per (segment, plane)
+// With the line entries merged the walk above is bound by its own instruction stream (probes at 265 k samples: 327 us; 315 without the plane
+// atomics, 337 without the line output): ~300 VALU instructions per step of tap arithmetic and key matching, identical in all `comps` lanes
+// of a plane.  (A float4-of-channels-per-lane form shares that arithmetic -- 132 us without its atomics -- but its plane atomics, four
+// scalars per lane 16 bytes apart, cost 580 us: atomics must stay one contiguous run of floats per instruction.)
+// Here a wave owns ONE (segment of AU_SEG consecutive active samples, plane) pair, lane = channel, so everything but the channel values is
+// wave-uniform, and the walk is split in two:
+//   phase 1: lane p computes step p of the walk's INDEX work, all steps at once -- taps, the four texel keys and weights, and (with the
+//            keys of step p-1 from the neighbouring lane) which open texels step p leaves and where each of its texels comes from (an open
+//            slot, a load, nothing); same for the two line entries -- and parks a 64-byte record in the wave's LDS slot;
+//   phase 2: the serial walk reads record p (broadcast LDS reads, moved to scalar registers), so its branches are scalar and its vector
+//            work is what is genuinely per channel: <= 4 atomics, <= 4 + 2 loads, ~25 FMAs / selects per step.
+constexpr int AU_SEG = 32;
+struct alignas(16) WalkRec {
+    int nk[4];          // texel keys (y * W + x) of the step, -1 = tap out of range
+    float w4[4];        // their bilinear weights
+    int n0, n1;         // line entries, -1 = out of range
+    float wz0, wz1;
+    int ctrl;           // bits 0-3 leave open plane slot q | 4-15 source of new slot q (3 bits: 0-3 open slot, 4 load, 5 nothing) |
+    int pad[3];         // 16-17 leave open line slot q | 18-19, 20-21 source of line slot 0 / 1 (0, 1 open slot, 2 load, 3 nothing) | 22 planes unchanged | 23 lines unchanged
+};
+
+template <bool LDS_LINES>
+__global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
+                                                              int seg_len) {
+    extern __shared__ __attribute__((aligned(16))) float lds_lines[];
+    const int nl = LDS_LINES ? line_lds_floats(t.res, t.comps) : 0;
+    if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    WalkRec* const recs = reinterpret_cast<WalkRec*>(lds_lines + (nl + 3) / 4 * 4) + wave * AU_SEG;
+    const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
+    const bool xcd = gr.xcd_stride > 0;
+    const int C = t.comps, G = 3 * C;
+    const int c = lane < C ? lane : C - 1;           // lanes >= comps idle through phase 2 (they repeat the last channel's loads, never write)
+    const bool live = lane < C;
+    M = limit_rows(M);
+    const long items = 3L * ((M + seg_len - 1) / seg_len);
+    for (long it = (long)blockIdx.x * nwaves + wave; it < items; it += (long)gridDim.x * nwaves) {
+        const int seg = (int)(it / 3), i = (int)(it - 3L * seg);
+        int a, b, v;
+        vm_axes(i, a, b, v);
+        const int W = t.res[a];
+        const int s0 = seg * seg_len, n = min(seg_len, M - s0);
+        // ---------------- phase 1
+        {
+            const int p = lane;
+            int nk[4] = {-1, -1, -1, -1}, n0 = -1, n1 = -1;
+            float w4[4] = {0.f, 0.f, 0.f, 0.f}, wz0 = 0.f, wz1 = 0.f;
+            if (p < n) {
+                const float4 p4 = *reinterpret_cast<const float4*>(xa + (size_t)(s0 + p) * 4);
+                const float xn[3] = {p4.x, p4.y, p4.z};
+                const Tap2 tx = make_tap(xn[a], t.res[a]), ty = make_tap(xn[b], t.res[b]), tz = make_tap(xn[v], t.res[v]);
+                w4[0] = tx.w0 * ty.w0; w4[1] = tx.w1 * ty.w0; w4[2] = tx.w0 * ty.w1; w4[3] = tx.w1 * ty.w1;
+                nk[0] = ty.i0 * W + tx.i0; nk[1] = ty.i0 * W + tx.i1; nk[2] = ty.i1 * W + tx.i0; nk[3] = ty.i1 * W + tx.i1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (w4[q] == 0.f) nk[q] = -1;        // clamped out-of-range taps: never loaded, never written
+                wz0 = tz.w0; wz1 = tz.w1;
+                n0 = tz.w0 != 0.f ? tz.i0 : -1; n1 = tz.w1 != 0.f ? tz.i1 : -1;
+            }
+            int pk[4], pn0, pn1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pk[q] = __shfl_up(nk[q], 1); if (p == 0) pk[q] = -1; }
+            pn0 = __shfl_up(n0, 1); pn1 = __shfl_up(n1, 1);
+            if (p == 0) { pn0 = -1; pn1 = -1; }
+            int ctrl = 0;
+            bool same = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (pk[q] >= 0 && pk[q] != nk[0] && pk[q] != nk[1] && pk[q] != nk[2] && pk[q] != nk[3]) { ctrl |= 1 << q; same = false; }
+                int src = nk[q] < 0 ? 5 : 4;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (nk[q] >= 0 && pk[o] == nk[q]) src = o;
+                ctrl |= src << (4 + 3 * q);
+                if (!(src == q || (src == 5 && pk[q] < 0))) same = false;
+            }
+            bool lsame = true;
+            if (pn0 >= 0 && pn0 != n0 && pn0 != n1) { ctrl |= 1 << 16; lsame = false; }
+            if (pn1 >= 0 && pn1 != n0 && pn1 != n1) { ctrl |= 1 << 17; lsame = false; }
+            const int ls0 = n0 < 0 ? 3 : (pn0 == n0 ? 0 : (pn1 == n0 ? 1 : 2));
+            const int ls1 = n1 < 0 ? 3 : (pn0 == n1 ? 0 : (pn1 == n1 ? 1 : 2));
+            ctrl |= (ls0 << 18) | (ls1 << 20);
+            if (!((ls0 == 0 || (ls0 == 3 && pn0 < 0)) && (ls1 == 1 || (ls1 == 3 && pn1 < 0)))) lsame = false;
+            if (same) ctrl |= 1 << 22;
+            if (lsame) ctrl |= 1 << 23;
+            if (p < n) {
+                int4* dst = reinterpret_cast<int4*>(recs + p);
+                dst[0] = make_int4(nk[0], nk[1], nk[2], nk[3]);
+                dst[1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
+                dst[2] = make_int4(n0, n1, __float_as_int(wz0), __float_as_int(wz1));
+                dst[3] = make_int4(ctrl, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase 2
+        const float* pp = t.plane[i] + c;
+        const float* lp = t.line[i] + c;
+        float* gp = gr.plane[i] + xoff + c;
+        float* ll = lds_lines + line_lds_offset(t, i) + c;
+        float* gl = gr.line[i] + xoff + c;
+        const float* dcol = dF + (size_t)s0 * G + i * C + c;
+        auto plane_out = [&](int key, float val) {
+            if (!live) return;
+            if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(gp + (size_t)key * C, val);
+        };
+        auto line_out = [&](int key, float val) {
+            if (!live) return;
+            if (LDS_LINES) atomicAdd(ll + key * C, val);
+            else if (xcd) __hip_atomic_fetch_add(gl + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(gl + (size_t)key * C, val);
+        };
+        int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};                  // wave-uniform
+        float cv[4] = {0.f, 0.f, 0.f, 0.f}, ca[4] = {0.f, 0.f, 0.f, 0.f};
+        float lv[2] = {0.f, 0.f}, lacc[2] = {0.f, 0.f};
+        float d_next = dcol[0];
+        for (int p = 0; p < n; ++p) {
+            const int4* src = reinterpret_cast<const int4*>(recs + p);
+            const int4 r0 = src[0], r1 = src[1], r2 = src[2];
+            const int ctrl = __builtin_amdgcn_readfirstlane(src[3].x);
+            const float d = d_next;
+            if (p + 1 < n) d_next = dcol[(size_t)(p + 1) * G];
+            const int nk[4] = {__builtin_amdgcn_readfirstlane(r0.x), __builtin_amdgcn_readfirstlane(r0.y), __builtin_amdgcn_readfirstlane(r0.z),
+                               __builtin_amdgcn_readfirstlane(r0.w)};
+            const float w4[4] = {__int_as_float(__builtin_amdgcn_readfirstlane(r1.x)), __int_as_float(__builtin_amdgcn_readfirstlane(r1.y)),
+                                 __int_as_float(__builtin_amdgcn_readfirstlane(r1.z)), __int_as_float(__builtin_amdgcn_readfirstlane(r1.w))};
+            const int n0 = __builtin_amdgcn_readfirstlane(r2.x), n1 = __builtin_amdgcn_readfirstlane(r2.y);
+            const float wz0 = __int_as_float(__builtin_amdgcn_readfirstlane(r2.z)), wz1 = __int_as_float(__builtin_amdgcn_readfirstlane(r2.w));
+            if (!(ctrl & (1 << 22))) {                 // the plane footprint moved
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ctrl & (1 << q)) plane_out(ck[q], ca[q]);
+                float nv[4], na[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sq = (ctrl >> (4 + 3 * q)) & 7;
+                    float val = 0.f, sum = 0.f;
+                    if (sq == 0) { val = cv[0]; sum = ca[0]; }
+                    else if (sq == 1) { val = cv[1]; sum = ca[1]; }
+                    else if (sq == 2) { val = cv[2]; sum = ca[2]; }
+                    else if (sq == 3) { val = cv[3]; sum = ca[3]; }
+                    else if (sq == 4) val = pp[(size_t)nk[q] * C];
+                    nv[q] = val; na[q] = sum;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ck[q] = nk[q]; cv[q] = nv[q]; ca[q] = na[q]; }
+            }
+            if (!(ctrl & (1 << 23))) {                 // the line footprint moved
+                if (ctrl & (1 << 16)) line_out(lk[0], lacc[0]);
+                if (ctrl & (1 << 17)) line_out(lk[1], lacc[1]);
+                const int s0l = (ctrl >> 18) & 3, s1l = (ctrl >> 20) & 3;
+                float v0 = 0.f, a0 = 0.f, v1 = 0.f, a1 = 0.f;
+                if (s0l == 0) { v0 = lv[0]; a0 = lacc[0]; } else if (s0l == 1) { v0 = lv[1]; a0 = lacc[1]; } else if (s0l == 2) v0 = lp[(size_t)n0 * C];
+                if (s1l == 0) { v1 = lv[0]; a1 = lacc[0]; } else if (s1l == 1) { v1 = lv[1]; a1 = lacc[1]; } else if (s1l == 2) v1 = lp[(size_t)n1 * C];
+                lk[0] = n0; lk[1] = n1; lv[0] = v0; lv[1] = v1; lacc[0] = a0; lacc[1] = a1;
+            }
+            const float P = fmaf(w4[3], cv[3], fmaf(w4[2], cv[2], fmaf(w4[1], cv[1], w4[0] * cv[0])));
+            const float L = fmaf(wz1, lv[1], wz0 * lv[0]);
+            const float gP = d * L, gL = d * P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ca[q] = fmaf(w4[q], gP, ca[q]);
+            lacc[0] = fmaf(wz0, gL, lacc[0]); lacc[1] = fmaf(wz1, gL, lacc[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (lk[q] >= 0) line_out(lk[q], lacc[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ck[q] >= 0) plane_out(ck[q], ca[q]);
+        __builtin_amdgcn_wave_barrier();               // the next item's phase 1 overwrites the records
     }
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
@@ -216,19 +401,38 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
-    const bool split = getenv("CLIFT_APP_SPLIT") != nullptr;          // A/B probe: one launch per plane
-    for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-        const int sel = split ? pass : -1;
-        const long total = (long)cdiv(M, seg) * (split ? 1 : 3) * h_app->comps;
-        const int want = cdiv(total, threads);
-        const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
-        if (use_lds) {
-            if (lds_bytes > 48 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel, xa);
+    const char* mode = getenv("CLIFT_APP_SCATTER");                   // "walk" = lane-per-(plane, channel) walk (the only form without xa)
+    if (xa != nullptr && h_app->comps <= 64 && !(mode && strcmp(mode, "walk") == 0)) {
+        // one wave per (segment, plane): the line slab + a 2 KB record slot per wave; as many waves per CU as that allows
+        const int rec_bytes = AU_SEG * (int)sizeof(WalkRec);
+        const int slab = (lds_bytes + 15) / 16 * 16;
+        int wpb = 16, bpc = 1;                                         // waves per block, blocks per CU
+        bool lds_l = true;
+        const int useg = AU_SEG;
+        if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 16; bpc = 2; }
+        else if (2 * (slab + 8 * rec_bytes) <= 160 * 1024 - 1024) { wpb = 8; bpc = 2; }
+        const long items = 3L * cdiv(M, useg);
+        const int want = cdiv(items, wpb);
+        const int blocks = want < 256 * bpc ? want : 256 * bpc;
+        const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
+        if (lds_l) {
+            if (dyn > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd_u<true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            k_app_gather_bwd_u<true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, dF, xa, useg);
         } else {
-            k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, sel, xa);
+            k_app_gather_bwd_u<false><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, dF, xa, useg);
         }
+        return clift_check_launch("clift_app_gather_bwd");
+    }
+    const long total = (long)cdiv(M, seg) * 3 * h_app->comps;
+    const int want = cdiv(total, threads);
+    const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
+    if (use_lds) {
+        if (lds_bytes > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        k_app_gather_bwd<true><<<blocks, threads, lds_bytes, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, xa);
+    } else {
+        k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, xa);
     }
     return clift_check_launch("clift_app_gather_bwd");
 }

@@ -263,6 +263,9 @@ def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
          ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
 
 
+# appearance table gradients: hand the forward's sample positions to the scatter (its wave-per-(segment, plane) walk); "walk" = the
+# lane-per-(plane, channel) walk that re-derives them from the rays
+APP_SCATTER_XA = os.environ.get("CLIFT_APP_SCATTER", "walk4") != "walk"
 FUSE_HEAD_BF16 = os.environ.get("CLIFT_FUSE_HEAD_BF16", "1") != "0"   # bf16 mode: first three layers (+ narrow output layer) of an xyz head in one launch
 
 
@@ -640,7 +643,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa), stream())
+                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 

@@ -142,7 +142,9 @@ int clift_app_gather_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, cons
 int clift_active_xyz(const clift_march_t* h_m, const float* rays, const float* jitter, const int* act_idx, int M,
                      float* xa, clift_stream_t s);
 /* xa (nullable): the (M, 4) normalised positions clift_app_gather_fwd / clift_active_xyz produced for the same act_idx -- when
- * given, the backward reads them instead of re-deriving each sample's position from its ray (same values, fewer instructions). */
+ * given (and comps <= 64), the backward runs in its wave-per-(segment, plane) form: the index work of a 32-sample segment is done once, in
+ * parallel, and the serial walk keeps only the per-channel arithmetic (same per-sample terms, merged over 32 instead of 16 samples, i.e. a
+ * different fp32 summation order). */
 int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
                          const float* rays, const float* jitter, const int* act_idx, int M, const float* dF,
                          const float* xa, clift_stream_t s);

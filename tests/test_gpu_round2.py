@@ -629,3 +629,33 @@ def test_sync_free_training_steps_match_synchronising_ones():
                 for k in gm0:     # ReLU-kink / activity-threshold flips are expected, hence the wider outlier allowance: seen 16 of 3072)
                     grad_close(gm1[k], gm0[k], what=f"sync-free grad {k} (chunk {chunk})", outlier_frac=2e-2, outlier_cap=1e-1)
         assert float((got[1] - ref[1]).abs().max()) <= 0.5 * 1e-2
+
+
+# ============================================================================ appearance table gradients: float4-lane walk vs scalar-lane walk
+@pytest.mark.parametrize("res,N", [((20, 28, 36), 700), ((64, 64, 64), 2048), ((128, 128, 128), 4096)])
+def test_appearance_scatter_four_channel_lanes_match_one_channel_lanes(res, N, monkeypatch):
+    """clift_app_gather_bwd with xa (a lane owns four channels, positions read from the forward's xa) against the same entry point without xa
+    (one channel per lane, positions re-derived from the rays): the same per-sample terms merged along the same ray segments, so every
+    appearance plane / line gradient agrees to fp32 summation order (1e-4 relative + 2e-5 of the tensor's scale).  Non-cubic grid (every
+    plane with its own W x H and line length), a 64^3 grid and the bench's 128^3 / 4096 rays."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd import engine
+    C_, E = 9, 3
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    P, rays, rng = scene(op, orays, 77, res, C_, E, N, img=64, amp=3.0, sg=0.35)
+    jitter = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
+    got = {}
+    for with_xa in (False, True):
+        monkeypatch.setattr(engine, "APP_SCATTER_XA", with_xa)
+        m = build_model(cl, P, res, C_, E, -3.0, "softmax")
+        r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+        _, grads = _run_forward_backward(cl, m, r, rays, jitter, False, cots + [1.0])
+        got[with_xa] = {k: (None if g is None else g.detach().cpu()) for k, g in grads.items()}
+    n_app = 0
+    for k, ref in got[False].items():
+        if k.startswith(("appearance_plane", "appearance_line")):
+            assert float(ref.abs().max()) > 0, k
+            grad_close(got[True][k], ref, what=f"float4-lane scatter {k}", rtol=1e-4, scale_atol=2e-5, outlier_frac=0.0, outlier_cap=2e-4)
+            n_app += 1
+    assert n_app == 6
