@@ -70,7 +70,7 @@ _SIGNATURES = {
     "clift_app_encode_points": ([_P, _I, _I, _I, _I, _P, _I, _L, _P, _I, _P], C.c_int),
     "clift_march_fwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "clift_march_bwd": ([_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
-    "clift_density_bwd": ([_P, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "clift_density_bwd": ([_P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_xcd_reduce": ([_P, _L, _L, _P, _P], C.c_int),
     "clift_scan_counts": ([_P, _I, _P, _P], C.c_int),
     "clift_compact_fill": ([_P, _P, _I, _I, _F, _P, _P], C.c_int),

@@ -1,6 +1,8 @@
 // march.hip -- ray marching: density VM lookup, transmittance scan, compaction, and their backward.
 // Reference rows: a4 a5 a6 a7 a8.
 #include "clift_dev.h"
+#include <string.h>
+#include <stdlib.h>
 CLIFT_ROWS_LIMIT_BINDER(march)
 
 // ============================================================================ density forward
@@ -290,14 +292,236 @@ __global__ __launch_bounds__(1024) void k_density_bwd(MarchP m, VmP t, VmG gr, c
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
 
+// ---------------------------------------------------------------------------- the same walk, one WAVE per (ray, 32-sample chunk)
+// The walk above spends ~700 VALU instructions per step, nearly all of it tap arithmetic and key matching that is identical in the
+// `comps` lanes of a group.  Here (comps <= 16) a wave owns one chunk of DU_SEG consecutive samples of one ray, lane = (plane, channel)
+// (3 comps live lanes), and the walk is split in two:
+//   phase 1: lane p handles sample k0 + p: gradient, position, in-box test; the active samples are compacted (ballot) and for each of
+//            the three planes the lane computes the taps and files the four texels of the footprint in PARITY SLOTS -- texel (x, y) always
+//            sits in slot (x & 1) + 2 (y & 1), and a 2 x 2 footprint has exactly one texel of each parity, so a footprint that moves by a
+//            texel replaces the texels of one parity IN PLACE: no matching of four old against four new keys, no moving of sums between
+//            slots; a slot is written out exactly when its key changes.  With the keys of the previous ACTIVE sample (fetched from that
+//            lane) the lane sets one "write out" and one "restart" bit per slot (same for the two line entries, slot = z & 1) and parks a
+//            64-byte record per (step, plane) in the wave's LDS slot.  With sigma from the forward it also computes the softplus derivative
+//            1 - exp(-sigma) there, once per sample;
+//   phase 2: the serial walk over the active samples: a lane reads its plane's record; the table values of DU_U steps are loaded together
+//            (one memory round trip per DU_U steps; nothing but the six gradient sums is carried from step to step), then per step:
+//            <= 6 atomics, 6 restarts, ~12 FMAs.
+// Per-sample terms: the bilinear sum runs in slot order instead of corner order and (with sigma) the derivative is 1 - exp(-softplus)
+// instead of the sigmoid: fp32 round-off apart from the walk above.
+constexpr int DU_SEG = 32;
+constexpr int DU_U = 4;                // steps whose loads are issued together
+struct alignas(16) DensRec {
+    int ks[4];          // texel keys (y * W + x) by parity slot, -1 = tap out of range
+    float ws[4];        // their weights
+    int kz[2];          // line entries by parity slot (z & 1), -1 = out of range
+    float wz[2];
+    int ctrl;           // bits 0-3 / 4-5: write out plane slot s / line slot s before this step; bits 8-11 / 12-13: restart its sum
+    float up;           // dL/dsigma (x the softplus derivative when sigma is given)
+    int pad[2];
+};
+
+// Parity of the texel a tap pair starts at: index i0 when it is in range, else the one before i1.
+__device__ __forceinline__ int tap_parity(const Tap2& tp) { return tp.w0 != 0.f ? (tp.i0 & 1) : ((tp.i1 & 1) ^ 1); }
+
+template <bool LDS_LINES>
+__global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr, const float* __restrict__ rays, const float* __restrict__ jitter,
+                                                           int N, int lg_c, const float* __restrict__ dsigma, const float* __restrict__ sigma) {
+    extern __shared__ __attribute__((aligned(16))) float lds_lines[];
+    const int nl = LDS_LINES ? line_lds_floats(t.res, t.comps) : 0;
+    if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    DensRec* const recs = reinterpret_cast<DensRec*>(lds_lines + (nl + 3) / 4 * 4) + wave * (3 * DU_SEG);
+    const size_t xoff = gr.xcd_stride > 0 ? (size_t)xcc_id() * (size_t)gr.xcd_stride : 0;
+    const bool xcd = gr.xcd_stride > 0;
+    const int C = t.comps;
+    const bool live = lane < 3 * C;
+    const int pi = live ? (lane >> lg_c) : 2, c = lane & (C - 1);            // this lane's plane and channel
+    const float* pp = (pi == 0 ? t.plane[0] : pi == 1 ? t.plane[1] : t.plane[2]) + c;
+    const float* lp = (pi == 0 ? t.line[0] : pi == 1 ? t.line[1] : t.line[2]) + c;
+    float* gp = (pi == 0 ? gr.plane[0] : pi == 1 ? gr.plane[1] : gr.plane[2]) + xoff + c;
+    float* gl = (pi == 0 ? gr.line[0] : pi == 1 ? gr.line[1] : gr.line[2]) + xoff + c;
+    float* ll = lds_lines + (pi == 0 ? 0 : pi == 1 ? t.res[2] * C : (t.res[2] + t.res[1]) * C) + c;
+    const int nchunk = (m.S + DU_SEG - 1) / DU_SEG;
+    const long items = (long)N * nchunk;
+    for (long it = (long)blockIdx.x * nwaves + wave; it < items; it += (long)gridDim.x * nwaves) {
+        const int r = (int)(it / nchunk), k0 = (int)(it - (long)r * nchunk) * DU_SEG;
+        // ---------------- phase 1
+        const int p = lane, k = k0 + p;
+        const bool valid = p < DU_SEG && k < m.S;
+        const float ds = valid ? dsigma[(size_t)r * m.S + k] : 0.f;
+        if (__ballot(ds != 0.f) == 0ull) continue;                          // nothing flows into this chunk (most chunks behind a surface)
+        const RayG g = load_ray(rays, r, m);
+        float xn[3] = {0.f, 0.f, 0.f};
+        bool active = false;
+        if (ds != 0.f) active = sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+        const unsigned long long mask = __ballot(active);
+        const int na = __popcll(mask);
+        if (na == 0) continue;
+        {
+            const unsigned long long below = mask & ((1ull << p) - 1ull);
+            const int j = __popcll(below);
+            const int pl = below ? 63 - __clzll(below) : p;                 // lane of the previous active sample
+            float up = ds;
+            if (sigma && active) up = ds * -expm1f(-sigma[(size_t)r * m.S + k]);       // d softplus(x) / dx = sigmoid(x) = 1 - exp(-softplus(x))
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int a, b, v;
+                vm_axes(i, a, b, v);
+                const int W = t.res[a];
+                int ks[4] = {-1, -1, -1, -1}, kz[2] = {-1, -1};
+                float ws[4] = {0.f, 0.f, 0.f, 0.f}, wz[2] = {0.f, 0.f};
+                if (active) {
+                    const VmTaps tp = vm_taps(t, i, xn);
+                    const float w4[4] = {tp.tx.w0 * tp.ty.w0, tp.tx.w1 * tp.ty.w0, tp.tx.w0 * tp.ty.w1, tp.tx.w1 * tp.ty.w1};
+                    const int nk[4] = {tp.ty.i0 * W + tp.tx.i0, tp.ty.i0 * W + tp.tx.i1, tp.ty.i1 * W + tp.tx.i0, tp.ty.i1 * W + tp.tx.i1};
+                    const int par = tap_parity(tp.tx) + 2 * tap_parity(tp.ty);
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int q = sl ^ par;                              // corner (qx, qy) sits in slot ((x0 + qx) & 1, (y0 + qy) & 1)
+                        const float wq = q == 0 ? w4[0] : q == 1 ? w4[1] : q == 2 ? w4[2] : w4[3];
+                        const int kq = q == 0 ? nk[0] : q == 1 ? nk[1] : q == 2 ? nk[2] : nk[3];
+                        ws[sl] = wq;
+                        ks[sl] = wq == 0.f ? -1 : kq;                        // clamped out-of-range taps: never loaded, never written
+                    }
+                    const int pz = tap_parity(tp.tz);
+                    const int z0 = tp.tz.w0 != 0.f ? tp.tz.i0 : -1, z1 = tp.tz.w1 != 0.f ? tp.tz.i1 : -1;
+                    kz[0] = pz ? z1 : z0; kz[1] = pz ? z0 : z1;
+                    wz[0] = pz ? tp.tz.w1 : tp.tz.w0; wz[1] = pz ? tp.tz.w0 : tp.tz.w1;
+                }
+                int ctrl = 0;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    int pk = __shfl(ks[sl], pl);
+                    if (j == 0) pk = -1;
+                    if (pk != ks[sl]) ctrl |= (pk >= 0 ? (1 << sl) : 0) | (1 << (8 + sl));
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    int pk = __shfl(kz[sl], pl);
+                    if (j == 0) pk = -1;
+                    if (pk != kz[sl]) ctrl |= (pk >= 0 ? (1 << (4 + sl)) : 0) | (1 << (12 + sl));
+                }
+                if (active) {
+                    int4* dst = reinterpret_cast<int4*>(recs + (j * 3 + i));
+                    dst[0] = make_int4(ks[0], ks[1], ks[2], ks[3]);
+                    dst[1] = make_int4(__float_as_int(ws[0]), __float_as_int(ws[1]), __float_as_int(ws[2]), __float_as_int(ws[3]));
+                    dst[2] = make_int4(kz[0], kz[1], __float_as_int(wz[0]), __float_as_int(wz[1]));
+                    dst[3] = make_int4(ctrl, __float_as_int(up), 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase 2
+        auto plane_out = [&](int key, float val) {
+            if (!live) return;
+            if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(gp + (size_t)key * C, val);
+        };
+        auto line_out = [&](int key, float val) {
+            if (!live) return;
+            if (LDS_LINES) atomicAdd(ll + key * C, val);
+            else if (xcd) __hip_atomic_fetch_add(gl + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(gl + (size_t)key * C, val);
+        };
+        int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
+        float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
+        for (int j0 = 0; j0 < na; j0 += DU_U) {
+            int4 kq[DU_U];
+            int2 kzz[DU_U];
+            float tv[DU_U][4], tl[DU_U][2];
+#pragma unroll
+            for (int u = 0; u < DU_U; ++u) {
+                const int4* src = reinterpret_cast<const int4*>(recs + (min(j0 + u, na - 1) * 3 + pi));
+                kq[u] = src[0];
+                kzz[u] = *reinterpret_cast<const int2*>(src + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < DU_U; ++u) {
+                tv[u][0] = pp[(size_t)max(kq[u].x, 0) * C]; tv[u][1] = pp[(size_t)max(kq[u].y, 0) * C];
+                tv[u][2] = pp[(size_t)max(kq[u].z, 0) * C]; tv[u][3] = pp[(size_t)max(kq[u].w, 0) * C];
+                tl[u][0] = lp[(size_t)max(kzz[u].x, 0) * C]; tl[u][1] = lp[(size_t)max(kzz[u].y, 0) * C];
+            }
+#pragma unroll
+            for (int u = 0; u < DU_U; ++u) {
+                if (j0 + u >= na) break;                                       // uniform
+                const int4* src = reinterpret_cast<const int4*>(recs + ((j0 + u) * 3 + pi));
+                const int4 r1 = src[1], r2 = src[2], r3 = src[3];
+                const int ks[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, kz[2] = {kzz[u].x, kzz[u].y};
+                const float ws[4] = {__int_as_float(r1.x), __int_as_float(r1.y), __int_as_float(r1.z), __int_as_float(r1.w)};
+                const float wz[2] = {__int_as_float(r2.z), __int_as_float(r2.w)};
+                const int ctrl = r3.x;
+                float up = __int_as_float(r3.y);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (ctrl & (1 << sl)) plane_out(ck[sl], ca[sl]);
+                    if (ctrl & (1 << (8 + sl))) ca[sl] = 0.f;
+                    ck[sl] = ks[sl];
+                }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    if (ctrl & (1 << (4 + sl))) line_out(lk[sl], lacc[sl]);
+                    if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
+                    lk[sl] = kz[sl];
+                }
+                float P = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], ks[sl] >= 0 ? tv[u][sl] : 0.f, P);
+                const float L = fmaf(wz[1], kz[1] >= 0 ? tl[u][1] : 0.f, wz[0] * (kz[0] >= 0 ? tl[u][0] : 0.f));
+                if (!sigma) {
+                    // no sigma from the forward: the sample's feature again -- per channel the planes in order 0, 1, 2, then the channel butterfly
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc = fmaf(__shfl(P, i * C + c), __shfl(L, i * C + c), acc);
+                    for (int dlt = 1; dlt < C; dlt <<= 1) acc += __shfl_xor(acc, dlt);
+                    const float x = acc + m.shift;
+                    up *= (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+                }
+                const float gP = up * L, gL = up * P;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
+                lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (lk[q] >= 0) line_out(lk[q], lacc[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (ck[q] >= 0) plane_out(ck[q], ca[q]);
+        __builtin_amdgcn_wave_barrier();               // the next item's phase 1 overwrites the records
+    }
+    if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
+}
+
 extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const clift_vm_grad_t* h_grad,
-                                 const float* rays, const float* jitter, int N, const float* dsigma, clift_stream_t s) {
+                                 const float* rays, const float* jitter, int N, const float* dsigma, const float* sigma, clift_stream_t s) {
     const int Cc = h_dens->comps;
     CLIFT_REQUIRE(Cc >= 4 && Cc <= 64 && (Cc & (Cc - 1)) == 0, "clift_density_bwd: comps must be a power of two in [4,64] (got %d)", Cc);
     if (N <= 0) return 0;
     int lg = 0;
     while ((1 << lg) < Cc) ++lg;
     const int DENS_SEG = DENS_SEG_DEFAULT;
+    const char* mode = getenv("CLIFT_DENS_SCATTER");                  // "walk" = the group-per-segment walk (the only form for comps > 16)
+    if (Cc <= 16 && !(mode && strcmp(mode, "walk") == 0)) {
+        const int slab = (line_lds_floats(h_dens->res, Cc) * 4 + 15) / 16 * 16;
+        const int rec_bytes = 3 * DU_SEG * (int)sizeof(DensRec);     // 6 KB per wave
+        int wpb = 16, bpc = 1;
+        bool lds_l = true;
+        if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 8; bpc = 3; }
+        const long items = (long)N * cdiv(h_m->n_samples, DU_SEG);
+        const long want = cdiv(items, wpb);
+        const int blocks = (int)(want < 256 * bpc ? want : 256 * bpc);
+        const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
+        if (lds_l) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd_u<true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            k_density_bwd_u<true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, N, lg, dsigma, sigma);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd_u<false>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            k_density_bwd_u<false><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), to_dev(h_grad), rays, jitter, N, lg, dsigma, sigma);
+        }
+        return clift_check_launch("clift_density_bwd");
+    }
     const long nseg = (long)N * cdiv(h_m->n_samples, DENS_SEG);
     const int lds_bytes = line_lds_floats(h_dens->res, Cc) * 4;
     int threads, per_cu;

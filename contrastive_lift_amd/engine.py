@@ -263,6 +263,9 @@ def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
          ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
 
 
+# density table gradients: hand the forward's sigma to the scatter (softplus derivative = 1 - exp(-sigma), once per sample) instead of
+# letting it re-sum the sample's feature over planes and channels
+DENS_BWD_SIGMA = os.environ.get("CLIFT_DENS_BWD_SIGMA", "1") != "0"
 # appearance table gradients: hand the forward's sample positions to the scatter (its wave-per-(segment, plane) walk); "walk" = the
 # lane-per-(plane, channel) walk that re-derives them from the rays
 APP_SCATTER_XA = os.environ.get("CLIFT_APP_SCATTER", "walk4") != "walk"
@@ -439,6 +442,7 @@ def _density_march(model, renderer, rays, jitter, cap=None):
         _limit_owner = ctx
     ctx.rays, ctx.jitter = rays, jitter
     ctx.alpha, ctx.T, ctx.w, ctx.ray_out, ctx.ray_start, ctx.act_idx = alpha, T, w, ray_out, ray_start, act_idx
+    ctx.sigma = sigma
     return ctx
 
 
@@ -696,7 +700,8 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
          ptr(ctx.ray_out), ptr(g_w), ptr(g_op), ptr(g_dist), ptr(dsigma), stream())
     vd = vm_struct(views, "density", ctx.res)
     gd = vm_grad_struct(model, gviews, "density")
-    call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma), stream())
+    call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma),
+         ptr(ctx.sigma) if DENS_BWD_SIGMA else None, stream())
     vm_grad_finish(model, gviews, "density", gd)
     keep.append(dsigma)
 

@@ -110,9 +110,11 @@ int clift_march_bwd(const clift_march_t* h_m, const float* rays, const float* ji
                     const float* T, const float* w, const float* ray_out, const float* g_w,
                     const float* g_opacity, const float* g_dist, float* dsigma, clift_stream_t s);
 
-/* Backward of a6: scatter dsigma through softplus and the VM products into the table gradients. */
+/* Backward of a6: scatter dsigma through softplus and the VM products into the table gradients.  sigma (nullable) = the (N,S) output of
+ * clift_density_fwd for the same rays: with it the softplus derivative is 1 - exp(-sigma) per sample; without it the sample's feature is
+ * summed again over planes and channels (same value to fp32 round-off). */
 int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const clift_vm_grad_t* h_grad,
-                      const float* rays, const float* jitter, int N, const float* dsigma, clift_stream_t s);
+                      const float* rays, const float* jitter, int N, const float* dsigma, const float* sigma, clift_stream_t s);
 
 /* ---- compaction of active samples (replaces the boolean-mask gathers renderer.py:103-108):
  * ray_start (N+1) = exclusive scan of n_active; act_idx[ray_start[r] .. ray_start[r+1]) = r*S + k in

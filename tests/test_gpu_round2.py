@@ -659,3 +659,33 @@ def test_appearance_scatter_four_channel_lanes_match_one_channel_lanes(res, N, m
             grad_close(got[True][k], ref, what=f"float4-lane scatter {k}", rtol=1e-4, scale_atol=2e-5, outlier_frac=0.0, outlier_cap=2e-4)
             n_app += 1
     assert n_app == 6
+
+
+@pytest.mark.parametrize("res,N", [((20, 28, 36), 700), ((64, 64, 64), 2048), ((128, 128, 128), 4096)])
+def test_density_scatter_wave_walk_matches_group_walk(res, N, monkeypatch):
+    """clift_density_bwd in its wave-per-(ray, 32-sample chunk) form (index work of the chunk done once, serial walk with per-channel work
+    only) against the group-per-4-sample-segment walk (CLIFT_DENS_SCATTER=walk), with and without the forward's sigma: the same per-sample
+    terms up to fp32 round-off, merged over longer runs, so every density plane / line gradient agrees to fp32 summation order."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    C_, E = 9, 3
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    P, rays, rng = scene(op, orays, 78, res, C_, E, N, img=64, amp=3.0, sg=0.35)
+    jitter = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
+    got = {}
+    from contrastive_lift_amd import engine
+    for mode in ("walk", "wave", "wave_nosigma"):
+        monkeypatch.setenv("CLIFT_DENS_SCATTER", mode.split("_")[0])
+        monkeypatch.setattr(engine, "DENS_BWD_SIGMA", mode != "wave_nosigma")
+        m = build_model(cl, P, res, C_, E, -3.0, "softmax")
+        r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+        _, grads = _run_forward_backward(cl, m, r, rays, jitter, False, cots + [1.0])
+        got[mode] = {k: (None if g is None else g.detach().cpu()) for k, g in grads.items()}
+    n = 0
+    for k, ref in got["walk"].items():
+        if k.startswith(("density_plane", "density_line")):
+            assert float(ref.abs().max()) > 0, k
+            for mode in ("wave", "wave_nosigma"):
+                grad_close(got[mode][k], ref, what=f"{mode} density scatter {k}", rtol=1e-4, scale_atol=2e-5, outlier_frac=0.0, outlier_cap=2e-4)
+            n += 1
+    assert n == 6
