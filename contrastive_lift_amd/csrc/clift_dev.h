@@ -187,6 +187,9 @@ __device__ __forceinline__ Tap2 make_tap(float x, int size) {
     return t;
 }
 
+// Parity of the texel a tap pair starts at: index i0 when it is in range, else the one before i1 (scatter walks: parity slots).
+__device__ __forceinline__ int tap_parity(const Tap2& tp) { return tp.w0 != 0.f ? (tp.i0 & 1) : ((tp.i1 & 1) ^ 1); }
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 acc) {
     acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y); acc.z = fmaf(s, a.z, acc.z); acc.w = fmaf(s, a.w, acc.w);

@@ -1,5 +1,6 @@
 // heads_io.hip -- appearance VM gather (a9), MLP input assembly (a10) and alpha compositing (a13), fwd + bwd.
 #include "clift_dev.h"
+#include <type_traits>
 CLIFT_ROWS_LIMIT_BINDER(heads_io)
 #include <stdlib.h>
 #include <string.h>
@@ -222,21 +223,25 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
 // atomics, 337 without the line output): ~300 VALU instructions per step of tap arithmetic and key matching, identical in all `comps` lanes
 // of a plane.  (A float4-of-channels-per-lane form shares that arithmetic -- 132 us without its atomics -- but its plane atomics, four
 // scalars per lane 16 bytes apart, cost 580 us: atomics must stay one contiguous run of floats per instruction.)
-// Here a wave owns ONE (segment of AU_SEG consecutive active samples, plane) pair, lane = channel, so everything but the channel values is
-// wave-uniform, and the walk is split in two:
-//   phase 1: lane p computes step p of the walk's INDEX work, all steps at once -- taps, the four texel keys and weights, and (with the
-//            keys of step p-1 from the neighbouring lane) which open texels step p leaves and where each of its texels comes from (an open
-//            slot, a load, nothing); same for the two line entries -- and parks a 64-byte record in the wave's LDS slot;
-//   phase 2: the serial walk reads record p (broadcast LDS reads, moved to scalar registers), so its branches are scalar and its vector
-//            work is what is genuinely per channel: <= 4 atomics, <= 4 + 2 loads, ~25 FMAs / selects per step.
+// Here (comps <= 64) a wave owns ONE (segment of AU_SEG consecutive active samples, plane) pair, lane = channel, and the walk is split
+// like k_density_bwd_u (march.hip):
+//   phase 1: lane p computes step p of the walk's INDEX work, all steps at once: taps, and the footprint's four texels filed in PARITY
+//            SLOTS -- texel (x, y) always sits in slot (x & 1) + 2 (y & 1); a 2 x 2 footprint has one texel of each parity, so a footprint
+//            that moves replaces texels IN PLACE and a slot is written out exactly when its key changes (no 4 x 4 key matching, no sums
+//            moving between slots); with the keys of step p-1 from the neighbouring lane: one "write out" and one "restart" bit per slot,
+//            same for the two line entries (slot = z & 1); a 64-byte record per step in the wave's LDS slot;
+//   phase 2: the serial walk: the table values and dF rows of AU_U steps are loaded together (one memory round trip per AU_U steps,
+//            nothing but the six gradient sums carried from step to step), then per step <= 6 atomics, 6 restarts, ~12 FMAs.
+// Per-sample terms: the bilinear sum runs in slot order instead of corner order (fp32 round-off apart from the walk above).
 constexpr int AU_SEG = 32;
+constexpr int AU_U = 4;                // steps whose loads are issued together
 struct alignas(16) WalkRec {
-    int nk[4];          // texel keys (y * W + x) of the step, -1 = tap out of range
-    float w4[4];        // their bilinear weights
-    int n0, n1;         // line entries, -1 = out of range
-    float wz0, wz1;
-    int ctrl;           // bits 0-3 leave open plane slot q | 4-15 source of new slot q (3 bits: 0-3 open slot, 4 load, 5 nothing) |
-    int pad[3];         // 16-17 leave open line slot q | 18-19, 20-21 source of line slot 0 / 1 (0, 1 open slot, 2 load, 3 nothing) | 22 planes unchanged | 23 lines unchanged
+    int ks[4];          // texels by parity slot, as BYTE offsets (y * W + x) * comps * 4 into the channels-last table; -1 = tap out of range
+    float ws[4];        // their bilinear weights
+    int kz[2];          // line entries by parity slot (z & 1), byte offsets z * comps * 4; -1 = out of range
+    float wz[2];
+    int ctrl;           // bits 0-3 / 4-5: write out plane slot s / line slot s before this step; bits 8-11 / 12-13: restart its sum
+    int pad[3];
 };
 
 template <bool LDS_LINES>
@@ -263,123 +268,123 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
         // ---------------- phase 1
         {
             const int p = lane;
-            int nk[4] = {-1, -1, -1, -1}, n0 = -1, n1 = -1;
-            float w4[4] = {0.f, 0.f, 0.f, 0.f}, wz0 = 0.f, wz1 = 0.f;
+            int ks[4] = {-1, -1, -1, -1}, kz[2] = {-1, -1};
+            float ws[4] = {0.f, 0.f, 0.f, 0.f}, wz[2] = {0.f, 0.f};
             if (p < n) {
                 const float4 p4 = *reinterpret_cast<const float4*>(xa + (size_t)(s0 + p) * 4);
                 const float xn[3] = {p4.x, p4.y, p4.z};
                 const Tap2 tx = make_tap(xn[a], t.res[a]), ty = make_tap(xn[b], t.res[b]), tz = make_tap(xn[v], t.res[v]);
-                w4[0] = tx.w0 * ty.w0; w4[1] = tx.w1 * ty.w0; w4[2] = tx.w0 * ty.w1; w4[3] = tx.w1 * ty.w1;
-                nk[0] = ty.i0 * W + tx.i0; nk[1] = ty.i0 * W + tx.i1; nk[2] = ty.i1 * W + tx.i0; nk[3] = ty.i1 * W + tx.i1;
+                const float w4[4] = {tx.w0 * ty.w0, tx.w1 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w1};
+                const int nk[4] = {ty.i0 * W + tx.i0, ty.i0 * W + tx.i1, ty.i1 * W + tx.i0, ty.i1 * W + tx.i1};
+                const int par = tap_parity(tx) + 2 * tap_parity(ty);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (w4[q] == 0.f) nk[q] = -1;        // clamped out-of-range taps: never loaded, never written
-                wz0 = tz.w0; wz1 = tz.w1;
-                n0 = tz.w0 != 0.f ? tz.i0 : -1; n1 = tz.w1 != 0.f ? tz.i1 : -1;
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int q = sl ^ par;                  // corner (qx, qy) sits in slot ((x0 + qx) & 1, (y0 + qy) & 1)
+                    const float wq = q == 0 ? w4[0] : q == 1 ? w4[1] : q == 2 ? w4[2] : w4[3];
+                    const int kq = q == 0 ? nk[0] : q == 1 ? nk[1] : q == 2 ? nk[2] : nk[3];
+                    ws[sl] = wq;
+                    ks[sl] = wq == 0.f ? -1 : kq * (4 * C);  // clamped out-of-range taps: never loaded, never written
+                }
+                const int pz = tap_parity(tz);
+                const int z0 = tz.w0 != 0.f ? tz.i0 * (4 * C) : -1, z1 = tz.w1 != 0.f ? tz.i1 * (4 * C) : -1;
+                kz[0] = pz ? z1 : z0; kz[1] = pz ? z0 : z1;
+                wz[0] = pz ? tz.w1 : tz.w0; wz[1] = pz ? tz.w0 : tz.w1;
             }
-            int pk[4], pn0, pn1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { pk[q] = __shfl_up(nk[q], 1); if (p == 0) pk[q] = -1; }
-            pn0 = __shfl_up(n0, 1); pn1 = __shfl_up(n1, 1);
-            if (p == 0) { pn0 = -1; pn1 = -1; }
             int ctrl = 0;
-            bool same = true;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (pk[q] >= 0 && pk[q] != nk[0] && pk[q] != nk[1] && pk[q] != nk[2] && pk[q] != nk[3]) { ctrl |= 1 << q; same = false; }
-                int src = nk[q] < 0 ? 5 : 4;
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-                    if (nk[q] >= 0 && pk[o] == nk[q]) src = o;
-                ctrl |= src << (4 + 3 * q);
-                if (!(src == q || (src == 5 && pk[q] < 0))) same = false;
+            for (int sl = 0; sl < 4; ++sl) {
+                int pk = __shfl_up(ks[sl], 1);
+                if (p == 0) pk = -1;
+                if (pk != ks[sl]) ctrl |= (pk >= 0 ? (1 << sl) : 0) | (1 << (8 + sl));
             }
-            bool lsame = true;
-            if (pn0 >= 0 && pn0 != n0 && pn0 != n1) { ctrl |= 1 << 16; lsame = false; }
-            if (pn1 >= 0 && pn1 != n0 && pn1 != n1) { ctrl |= 1 << 17; lsame = false; }
-            const int ls0 = n0 < 0 ? 3 : (pn0 == n0 ? 0 : (pn1 == n0 ? 1 : 2));
-            const int ls1 = n1 < 0 ? 3 : (pn0 == n1 ? 0 : (pn1 == n1 ? 1 : 2));
-            ctrl |= (ls0 << 18) | (ls1 << 20);
-            if (!((ls0 == 0 || (ls0 == 3 && pn0 < 0)) && (ls1 == 1 || (ls1 == 3 && pn1 < 0)))) lsame = false;
-            if (same) ctrl |= 1 << 22;
-            if (lsame) ctrl |= 1 << 23;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                int pk = __shfl_up(kz[sl], 1);
+                if (p == 0) pk = -1;
+                if (pk != kz[sl]) ctrl |= (pk >= 0 ? (1 << (4 + sl)) : 0) | (1 << (12 + sl));
+            }
             if (p < n) {
                 int4* dst = reinterpret_cast<int4*>(recs + p);
-                dst[0] = make_int4(nk[0], nk[1], nk[2], nk[3]);
-                dst[1] = make_int4(__float_as_int(w4[0]), __float_as_int(w4[1]), __float_as_int(w4[2]), __float_as_int(w4[3]));
-                dst[2] = make_int4(n0, n1, __float_as_int(wz0), __float_as_int(wz1));
+                dst[0] = make_int4(ks[0], ks[1], ks[2], ks[3]);
+                dst[1] = make_int4(__float_as_int(ws[0]), __float_as_int(ws[1]), __float_as_int(ws[2]), __float_as_int(ws[3]));
+                dst[2] = make_int4(kz[0], kz[1], __float_as_int(wz[0]), __float_as_int(wz[1]));
                 dst[3] = make_int4(ctrl, 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2
-        const float* pp = t.plane[i] + c;
-        const float* lp = t.line[i] + c;
-        float* gp = gr.plane[i] + xoff + c;
-        float* ll = lds_lines + line_lds_offset(t, i) + c;
-        float* gl = gr.line[i] + xoff + c;
+        // wave-uniform bases + 32-bit byte offsets (record offset + 4 c): one add per access, no 64-bit multiplies
+        const float* pp = t.plane[i];
+        const float* lp = t.line[i];
+        float* gp = gr.plane[i] + xoff;
+        float* ll = lds_lines + line_lds_offset(t, i);
+        float* gl = gr.line[i] + xoff;
         const float* dcol = dF + (size_t)s0 * G + i * C + c;
+        const int c4 = 4 * c;
+        auto at = [](auto* base, int off) {            // (pointer arithmetic, not integer casts: the address space must stay visible)
+            typedef typename std::conditional<std::is_const<typename std::remove_pointer<decltype(base)>::type>::value, const char, char>::type B;
+            return reinterpret_cast<decltype(base)>(reinterpret_cast<B*>(base) + (unsigned)off);
+        };
         auto plane_out = [&](int key, float val) {
             if (!live) return;
-            if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(gp + (size_t)key * C, val);
+            if (xcd) __hip_atomic_fetch_add(at(gp, key + c4), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(at(gp, key + c4), val);
         };
         auto line_out = [&](int key, float val) {
             if (!live) return;
-            if (LDS_LINES) atomicAdd(ll + key * C, val);
-            else if (xcd) __hip_atomic_fetch_add(gl + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(gl + (size_t)key * C, val);
+            if (LDS_LINES) atomicAdd(at(ll, key + c4), val);
+            else if (xcd) __hip_atomic_fetch_add(at(gl, key + c4), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(at(gl, key + c4), val);
         };
-        int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};                  // wave-uniform
-        float cv[4] = {0.f, 0.f, 0.f, 0.f}, ca[4] = {0.f, 0.f, 0.f, 0.f};
-        float lv[2] = {0.f, 0.f}, lacc[2] = {0.f, 0.f};
-        float d_next = dcol[0];
-        for (int p = 0; p < n; ++p) {
-            const int4* src = reinterpret_cast<const int4*>(recs + p);
-            const int4 r0 = src[0], r1 = src[1], r2 = src[2];
-            const int ctrl = __builtin_amdgcn_readfirstlane(src[3].x);
-            const float d = d_next;
-            if (p + 1 < n) d_next = dcol[(size_t)(p + 1) * G];
-            const int nk[4] = {__builtin_amdgcn_readfirstlane(r0.x), __builtin_amdgcn_readfirstlane(r0.y), __builtin_amdgcn_readfirstlane(r0.z),
-                               __builtin_amdgcn_readfirstlane(r0.w)};
-            const float w4[4] = {__int_as_float(__builtin_amdgcn_readfirstlane(r1.x)), __int_as_float(__builtin_amdgcn_readfirstlane(r1.y)),
-                                 __int_as_float(__builtin_amdgcn_readfirstlane(r1.z)), __int_as_float(__builtin_amdgcn_readfirstlane(r1.w))};
-            const int n0 = __builtin_amdgcn_readfirstlane(r2.x), n1 = __builtin_amdgcn_readfirstlane(r2.y);
-            const float wz0 = __int_as_float(__builtin_amdgcn_readfirstlane(r2.z)), wz1 = __int_as_float(__builtin_amdgcn_readfirstlane(r2.w));
-            if (!(ctrl & (1 << 22))) {                 // the plane footprint moved
+        int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
+        float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
+        for (int p0 = 0; p0 < n; p0 += AU_U) {
+            int4 kq[AU_U];
+            int2 kzz[AU_U];
+            float tv[AU_U][4], tl[AU_U][2], td[AU_U];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ctrl & (1 << q)) plane_out(ck[q], ca[q]);
-                float nv[4], na[4];
+            for (int u = 0; u < AU_U; ++u) {
+                const int4* src = reinterpret_cast<const int4*>(recs + min(p0 + u, n - 1));
+                kq[u] = src[0];
+                kzz[u] = *reinterpret_cast<const int2*>(src + 2);
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sq = (ctrl >> (4 + 3 * q)) & 7;
-                    float val = 0.f, sum = 0.f;
-                    if (sq == 0) { val = cv[0]; sum = ca[0]; }
-                    else if (sq == 1) { val = cv[1]; sum = ca[1]; }
-                    else if (sq == 2) { val = cv[2]; sum = ca[2]; }
-                    else if (sq == 3) { val = cv[3]; sum = ca[3]; }
-                    else if (sq == 4) val = pp[(size_t)nk[q] * C];
-                    nv[q] = val; na[q] = sum;
+            for (int u = 0; u < AU_U; ++u) {
+                tv[u][0] = *at(pp, max(kq[u].x, 0) + c4); tv[u][1] = *at(pp, max(kq[u].y, 0) + c4);
+                tv[u][2] = *at(pp, max(kq[u].z, 0) + c4); tv[u][3] = *at(pp, max(kq[u].w, 0) + c4);
+                tl[u][0] = *at(lp, max(kzz[u].x, 0) + c4); tl[u][1] = *at(lp, max(kzz[u].y, 0) + c4);
+                td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
+            }
+#pragma unroll
+            for (int u = 0; u < AU_U; ++u) {
+                if (p0 + u >= n) break;                                        // uniform
+                const int4* src = reinterpret_cast<const int4*>(recs + (p0 + u));
+                const int4 r1 = src[1], r2 = src[2];
+                const int ctrl = src[3].x;
+                const int ks[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, kz[2] = {kzz[u].x, kzz[u].y};
+                const float ws[4] = {__int_as_float(r1.x), __int_as_float(r1.y), __int_as_float(r1.z), __int_as_float(r1.w)};
+                const float wz[2] = {__int_as_float(r2.z), __int_as_float(r2.w)};
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    if (ctrl & (1 << sl)) plane_out(ck[sl], ca[sl]);
+                    if (ctrl & (1 << (8 + sl))) ca[sl] = 0.f;
+                    ck[sl] = ks[sl];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ck[q] = nk[q]; cv[q] = nv[q]; ca[q] = na[q]; }
-            }
-            if (!(ctrl & (1 << 23))) {                 // the line footprint moved
-                if (ctrl & (1 << 16)) line_out(lk[0], lacc[0]);
-                if (ctrl & (1 << 17)) line_out(lk[1], lacc[1]);
-                const int s0l = (ctrl >> 18) & 3, s1l = (ctrl >> 20) & 3;
-                float v0 = 0.f, a0 = 0.f, v1 = 0.f, a1 = 0.f;
-                if (s0l == 0) { v0 = lv[0]; a0 = lacc[0]; } else if (s0l == 1) { v0 = lv[1]; a0 = lacc[1]; } else if (s0l == 2) v0 = lp[(size_t)n0 * C];
-                if (s1l == 0) { v1 = lv[0]; a1 = lacc[0]; } else if (s1l == 1) { v1 = lv[1]; a1 = lacc[1]; } else if (s1l == 2) v1 = lp[(size_t)n1 * C];
-                lk[0] = n0; lk[1] = n1; lv[0] = v0; lv[1] = v1; lacc[0] = a0; lacc[1] = a1;
-            }
-            const float P = fmaf(w4[3], cv[3], fmaf(w4[2], cv[2], fmaf(w4[1], cv[1], w4[0] * cv[0])));
-            const float L = fmaf(wz1, lv[1], wz0 * lv[0]);
-            const float gP = d * L, gL = d * P;
+                for (int sl = 0; sl < 2; ++sl) {
+                    if (ctrl & (1 << (4 + sl))) line_out(lk[sl], lacc[sl]);
+                    if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
+                    lk[sl] = kz[sl];
+                }
+                float P = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ca[q] = fmaf(w4[q], gP, ca[q]);
-            lacc[0] = fmaf(wz0, gL, lacc[0]); lacc[1] = fmaf(wz1, gL, lacc[1]);
+                for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], ks[sl] >= 0 ? tv[u][sl] : 0.f, P);
+                const float L = fmaf(wz[1], kz[1] >= 0 ? tl[u][1] : 0.f, wz[0] * (kz[0] >= 0 ? tl[u][0] : 0.f));
+                const float gP = td[u] * L, gL = td[u] * P;
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
+                lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)

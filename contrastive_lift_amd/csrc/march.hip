@@ -1,6 +1,7 @@
 // march.hip -- ray marching: density VM lookup, transmittance scan, compaction, and their backward.
 // Reference rows: a4 a5 a6 a7 a8.
 #include "clift_dev.h"
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 CLIFT_ROWS_LIMIT_BINDER(march)
@@ -312,17 +313,14 @@ __global__ __launch_bounds__(1024) void k_density_bwd(MarchP m, VmP t, VmG gr, c
 constexpr int DU_SEG = 32;
 constexpr int DU_U = 4;                // steps whose loads are issued together
 struct alignas(16) DensRec {
-    int ks[4];          // texel keys (y * W + x) by parity slot, -1 = tap out of range
+    int ks[4];          // texels by parity slot, as BYTE offsets (y * W + x) * comps * 4 into the channels-last table; -1 = tap out of range
     float ws[4];        // their weights
-    int kz[2];          // line entries by parity slot (z & 1), -1 = out of range
+    int kz[2];          // line entries by parity slot (z & 1), byte offsets z * comps * 4; -1 = out of range
     float wz[2];
     int ctrl;           // bits 0-3 / 4-5: write out plane slot s / line slot s before this step; bits 8-11 / 12-13: restart its sum
     float up;           // dL/dsigma (x the softplus derivative when sigma is given)
     int pad[2];
 };
-
-// Parity of the texel a tap pair starts at: index i0 when it is in range, else the one before i1.
-__device__ __forceinline__ int tap_parity(const Tap2& tp) { return tp.w0 != 0.f ? (tp.i0 & 1) : ((tp.i1 & 1) ^ 1); }
 
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr, const float* __restrict__ rays, const float* __restrict__ jitter,
@@ -382,10 +380,10 @@ __global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr,
                         const float wq = q == 0 ? w4[0] : q == 1 ? w4[1] : q == 2 ? w4[2] : w4[3];
                         const int kq = q == 0 ? nk[0] : q == 1 ? nk[1] : q == 2 ? nk[2] : nk[3];
                         ws[sl] = wq;
-                        ks[sl] = wq == 0.f ? -1 : kq;                        // clamped out-of-range taps: never loaded, never written
+                        ks[sl] = wq == 0.f ? -1 : kq * (4 * C);              // clamped out-of-range taps: never loaded, never written
                     }
                     const int pz = tap_parity(tp.tz);
-                    const int z0 = tp.tz.w0 != 0.f ? tp.tz.i0 : -1, z1 = tp.tz.w1 != 0.f ? tp.tz.i1 : -1;
+                    const int z0 = tp.tz.w0 != 0.f ? tp.tz.i0 * (4 * C) : -1, z1 = tp.tz.w1 != 0.f ? tp.tz.i1 * (4 * C) : -1;
                     kz[0] = pz ? z1 : z0; kz[1] = pz ? z0 : z1;
                     wz[0] = pz ? tp.tz.w1 : tp.tz.w0; wz[1] = pz ? tp.tz.w0 : tp.tz.w1;
                 }
@@ -413,16 +411,21 @@ __global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr,
         }
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2
+        // per-lane bases (plane and channel folded in) + the records' 32-bit byte offsets: one 64-bit add per access, no multiplies
+        auto at = [](auto* base, int off) {            // (pointer arithmetic, not integer casts: the address space must stay visible)
+            typedef typename std::conditional<std::is_const<typename std::remove_pointer<decltype(base)>::type>::value, const char, char>::type B;
+            return reinterpret_cast<decltype(base)>(reinterpret_cast<B*>(base) + (unsigned)off);
+        };
         auto plane_out = [&](int key, float val) {
             if (!live) return;
-            if (xcd) __hip_atomic_fetch_add(gp + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(gp + (size_t)key * C, val);
+            if (xcd) __hip_atomic_fetch_add(at(gp, key), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(at(gp, key), val);
         };
         auto line_out = [&](int key, float val) {
             if (!live) return;
-            if (LDS_LINES) atomicAdd(ll + key * C, val);
-            else if (xcd) __hip_atomic_fetch_add(gl + (size_t)key * C, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(gl + (size_t)key * C, val);
+            if (LDS_LINES) atomicAdd(at(ll, key), val);
+            else if (xcd) __hip_atomic_fetch_add(at(gl, key), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else unsafeAtomicAdd(at(gl, key), val);
         };
         int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
         float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
@@ -438,9 +441,9 @@ __global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr,
             }
 #pragma unroll
             for (int u = 0; u < DU_U; ++u) {
-                tv[u][0] = pp[(size_t)max(kq[u].x, 0) * C]; tv[u][1] = pp[(size_t)max(kq[u].y, 0) * C];
-                tv[u][2] = pp[(size_t)max(kq[u].z, 0) * C]; tv[u][3] = pp[(size_t)max(kq[u].w, 0) * C];
-                tl[u][0] = lp[(size_t)max(kzz[u].x, 0) * C]; tl[u][1] = lp[(size_t)max(kzz[u].y, 0) * C];
+                tv[u][0] = *at(pp, max(kq[u].x, 0)); tv[u][1] = *at(pp, max(kq[u].y, 0));
+                tv[u][2] = *at(pp, max(kq[u].z, 0)); tv[u][3] = *at(pp, max(kq[u].w, 0));
+                tl[u][0] = *at(lp, max(kzz[u].x, 0)); tl[u][1] = *at(lp, max(kzz[u].y, 0));
             }
 #pragma unroll
             for (int u = 0; u < DU_U; ++u) {
