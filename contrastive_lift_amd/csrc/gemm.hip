@@ -486,9 +486,10 @@ extern "C" int clift_wgrad_narrow(const float* dY, int ldd, int no, const float*
                                   int x_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_wgrad_narrow: out_features must be in [1,32] (got %d)", no);
     if (M <= 0 || ni <= 0) return 0;
-    if (ni == 256 && M >= 4096 && ldd % 4 == 0 && ldd >= no && ldd <= 32 && (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)X) & 15) == 0 &&
-        ldx % (x_bf16 ? 8 : 4) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
-        return clift_wgrad_narrow_stream_launch(dY, ldd, no, X, ldx, M, gW, ldw, gb, x_bf16, as_stream(s));   // matrix-core stream over X
+    if ((ni == 256 || (!x_bf16 && ni >= 32 && ni < 256 && ni % 4 == 0)) && M >= 4096 && ldd % 4 == 0 && ldd >= no && ldd <= 32 &&
+        (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)X) & 15) == 0 && ldx % (x_bf16 ? 8 : 4) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr &&
+        getenv("CLIFT_NARROW_WGRAD_VALU") == nullptr)
+        return clift_wgrad_narrow_stream_launch(dY, ldd, no, X, ldx, ni, M, gW, ldw, gb, x_bf16, as_stream(s));   // matrix-core stream over X
     const int rpb = 128;        // (insensitive between 64 and 520 rows per block: the kernel is FMA-bound, not launch-shape-bound)
     const dim3 grid(cdiv(M, rpb), cdiv(ni, 256));
     hipStream_t st = as_stream(s);

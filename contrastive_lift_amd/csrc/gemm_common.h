@@ -43,7 +43,7 @@ int clift_wgrad_f32_stream_launch(const GemmP& p, hipStream_t st);
 int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_n128.hip
 int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st);
 int clift_wgrad_f32_quads_launch(const GemmP& p, hipStream_t st);
-int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int M, float* gW, int ldw, float* gb, int x_bf16,
+int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw, float* gb, int x_bf16,
                                      hipStream_t st);                                             // narrow_stream.hip
 int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st);
 int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M, float* dW, int ldw, float* db, int dh_bf16, hipStream_t st);

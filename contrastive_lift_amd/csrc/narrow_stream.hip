@@ -35,7 +35,8 @@ static __device__ __forceinline__ void ns_wait_vm(int n) {          // wave-unif
 template <bool XB>
 __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __restrict__ dY, int ldd, int no, const float* __restrict__ X, int ldx,
                                                                 int M, int rows_per_block, float* __restrict__ gW, long sc, long sn, float* __restrict__ gb,
-                                                                int ones_class, float* __restrict__ ones_row) {
+                                                                int ones_class, float* __restrict__ ones_row, int nx) {
+    // nx = columns of X (<= 256, a multiple of 4; 256 when bf16-stored): waves whose 32 columns start past nx only copy and wait.
     // gW[c * sc + j * sn] += sum_m dY[m][c] X[m][j].  ones_class >= 0: that class reads as 1.0 whatever dY holds and its row goes to
     // ones_row[j] (+= sum_m X[m][j]) instead of gW -- the K = 3 first-layer backward: dY = the sample positions (x, y, z, pad),
     // X = the hidden gradient, ones_row = the bias gradient.
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wave * 4 + i, gr = min(r0 + row, rend - 1);
-                __builtin_amdgcn_global_load_lds(X + (size_t)gr * ldx + lane * 4, (lds_ptr_t)(st + row * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(X + (size_t)gr * ldx + min(lane * 4, nx - 4), (lds_ptr_t)(st + row * 1024), 16, 0, 0);
             }
         } else {
             const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
             for (int e = valid * ldd + tid; e < NS_ROWS * ldd; e += 512) dt[e] = 0.f;
             __syncthreads();
         }
+        if (32 * wave >= nx) continue;                                                   // (wave-uniform; the barrier above is the tile's only one)
         float a[16], b[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {                                                   // rows 2 s + lh
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
     for (int r = 0; r < 16; ++r) {
         const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
         const int j = 32 * wave + li;
+        if (j >= nx) continue;
         if (c == ones_class) unsafeAtomicAdd(ones_row + j, acc0[r] + acc1[r]);
         else if (c < no) unsafeAtomicAdd(gW + (size_t)c * sc + (size_t)j * sn, acc0[r] + acc1[r]);
     }
@@ -138,14 +141,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
     }
 }
 
-// Eligibility decided by the caller (gemm.hip): ni = 256, no <= ldd <= 32, ldd % 4 == 0, M >= 4096, 16-byte-aligned rows.
-int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int M, float* gW, int ldw, float* gb, int x_bf16,
+// Eligibility decided by the caller (gemm.hip): ni = 256 (fp32 X: any multiple of 4 up to 256), no <= ldd <= 32, ldd % 4 == 0, M >= 4096,
+// 16-byte-aligned rows.
+int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw, float* gb, int x_bf16,
                                      hipStream_t st) {
     const int tiles = cdiv(M, NS_ROWS);
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
-    if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr);
-    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr);
+    if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr, 256);
+    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr, ni);
     return clift_check_launch("clift_wgrad_narrow(stream)");
 }
 
@@ -155,8 +159,8 @@ int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M,
     const int tiles = cdiv(M, NS_ROWS);
     const int blocks = tiles < 256 ? tiles : 256;
     const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
-    if (dh_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db);
-    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db);
+    if (dh_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db, 256);
+    else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db, 256);
     return clift_check_launch("clift_linear_k3_bwd(stream)");
 }
 

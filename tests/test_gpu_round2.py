@@ -689,3 +689,35 @@ def test_density_scatter_wave_walk_matches_group_walk(res, N, monkeypatch):
                 grad_close(got[mode][k], ref, what=f"{mode} density scatter {k}", rtol=1e-4, scale_atol=2e-5, outlier_frac=0.0, outlier_cap=2e-4)
             n += 1
     assert n == 6
+
+
+@pytest.mark.parametrize("M,no,ldd,ni", [(4099, 3, 4, 128), (249003, 3, 4, 128), (40001, 27, 28, 144), (8191, 27, 28, 144), (5000, 22, 24, 36), (4096, 8, 8, 252)])
+def test_narrow_wgrad_stream_on_narrower_activations(M, no, ldd, ni):
+    """k_wgrad_narrow_stream with X narrower than 256 columns (the appearance output layer: 3 x 128; the appearance basis matrix: 27 x 144):
+    waves whose 32 columns start past the width only copy and wait.  Against fp64 and against the VALU kernel (CLIFT_NARROW_WGRAD_VALU),
+    accumulating onto existing contents, with and without a bias gradient, ragged row counts."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + no + ni)
+    dY = torch.zeros((M, ldd))
+    dY[:, :no] = torch.randn((M, no), generator=g)
+    X = torch.relu(torch.randn((M, ni), generator=g)).to(DEV)
+    dYd = dY.to(DEV)
+    refw = dY[:, :no].double().T @ X.cpu().double() + 0.25
+    refb = dY[:, :no].double().sum(0) - 1.0
+    outs = []
+    for valu in (False, True):
+        if valu:
+            os.environ["CLIFT_NARROW_WGRAD_VALU"] = "1"
+        try:
+            gW = torch.full((no, ni), 0.25, device=DEV)
+            gb = torch.full((no,), -1.0, device=DEV)
+            engine.wgrad(no, ni, M, dYd, ldd, X, ni, gW, gb)
+            gW_nb = torch.full((no, ni), 0.25, device=DEV)
+            engine.call("clift_wgrad_narrow", engine.ptr(dYd), ldd, no, engine.ptr(X), ni, ni, M, engine.ptr(gW_nb), ni, None, 0, engine.stream())
+        finally:
+            os.environ.pop("CLIFT_NARROW_WGRAD_VALU", None)
+        rel_close(gW, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what=f"narrow wgrad ni={ni} valu={valu}")
+        rel_close(gb, refb, 2e-5, atol=2e-5 * M ** 0.5, what="bias sums")
+        rel_close(gW_nb, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="no-bias form")
+        outs.append(gW)
+    rel_close(outs[0], outs[1], 2e-5, atol=2e-5 * float(refw.abs().max()), what="stream vs VALU kernel")
