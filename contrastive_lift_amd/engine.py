@@ -578,9 +578,11 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
 
 # ----------------------------------------------------------------------------- backward
 def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_dist=None, density_grad=True,
-                    slow_grad=False):
+                    slow_grad=False, before_density=None):
     """Accumulate parameter gradients into ``gviews`` (name -> tensor with the parameter's layout).
-    g_rgb (N,3), g_sem (N,C), g_inst (N,D): output gradients or None; g_dist: device scalar tensor or None."""
+    g_rgb (N,3), g_sem (N,C), g_inst (N,D): output gradients or None; g_dist: device scalar tensor or None.
+    ``before_density``: called once, after every head chain (MLPs, appearance tables) has been issued on the current stream and before
+    the density backward -- the data-parallel trainer starts the all-reduce of those gradients there, under the density backward."""
     views = model.named_views()
     N, S, M = ctx.N, ctx.S, ctx.M
     dev = ctx.rays.device
@@ -679,6 +681,11 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             if model.slow_fast_mode and slow_grad:
                 br.run(3, inst_chain("render_instance_mlp.slow_mlp", ctx.inst_slow_acts, model.render_instance_mlp.output_channels))
         if density_grad:
+            if before_density is not None:
+                if br.enabled:
+                    br.join()                 # (side-stream mode: the head chains have to be on the current stream first)
+                before_density()
+                before_density = None
             br.run(4, lambda keep: _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep))
             density_grad = False
         br.join()
@@ -686,6 +693,8 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
         # no active samples but the white background still routes d rgb into the opacity
         inside = ((ctx.rgb_raw >= 0) & (ctx.rgb_raw <= 1)).to(torch.float32)
         g_op = -(g_rgb * inside).sum(-1)
+    if before_density is not None:
+        before_density()
     # ---------------- density path (when it was not already run as a branch above)
     if density_grad:
         _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, [])

@@ -111,6 +111,9 @@ class HotPathTrainer:
         self.opt_main = ArenaAdam(m, [("grids", a0, a1, c.lr * 20), ("net_app", b0, b1, c.lr), ("net_sem", s0, s1, c.lr)],
                                   (0.9, 0.99), c.weight_decay)
         self.main_range = m.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")
+        self.late_range = m.arena.range_of("grid_density")                       # final only after the density backward
+        self.early_range = m.arena.range_of("grid_app", "net_app", "net_sem")     # final once the head chains are issued
+        self.overlap_allreduce = bool(getattr(c, "overlap_allreduce", True))
         # The slow MLP is listed in the reference's instance optimizer when not DINO-style (F:241-244), but its output is detached
         # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
         i0, i1 = m.arena.range_of("inst_fast")
@@ -126,6 +129,16 @@ class HotPathTrainer:
             g = self.model.grad_flat[rng[0]:rng[1]]
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             g.mul_(1.0 / self.world)
+
+    def _allreduce_start(self, rng):
+        """Asynchronous form: the collective is queued behind what the current stream holds now and runs beside what is launched next."""
+        g = self.model.grad_flat[rng[0]:rng[1]]
+        return g, dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _allreduce_finish(self, started):
+        g, work = started
+        work.wait()
+        g.mul_(1.0 / self.world)
 
     # ------------------------------------------------------------------ sync-free capacity bookkeeping
     NOSYNC_WARMUP, NOSYNC_HEADROOM = 2, 1.3
@@ -214,20 +227,33 @@ class HotPathTrainer:
                       _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
         g_dist = torch.full((1,), w_rgb * self.current_lambda_dist_reg / len(ctxs), dtype=torch.float32, device=self.device)
         gv = m.named_grad_views()
+        seg_term = segments is not None and sem_on and float(getattr(c, "lambda_segment", 0.0)) != 0.0
+        # Data-parallel runs: the TV term depends on the parameters only, so it goes FIRST (the scatter kernels accumulate on top of it),
+        # and once the last chunk's head chains are issued everything but the density tables is final: that range (appearance tables +
+        # both MLPs, ~3/4 of the bytes) is all-reduced under the density backward, the density tables after it.
+        early = self.world > 1 and self.overlap_allreduce and not seg_term
+        started = []
+        if early:
+            self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         for k, ctx in enumerate(ctxs):
             s = slice(k * chunk, k * chunk + ctx.N)
-            engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True)
-        if segments is not None and sem_on and float(getattr(c, "lambda_segment", 0.0)) != 0.0:
+            hook = (lambda: started.append(self._allreduce_start(self.early_range))) if (early and k == len(ctxs) - 1) else None
+            engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True, before_density=hook)
+        if seg_term:
             if getattr(c, "use_symmetric_ce", False):
                 # the reference calls loss_semantics(features, CLASS INDICES) here (T:194); SCELoss takes log(labels) of them
                 # (loss.py:53) -- that combination does not run in the reference either
                 raise NotImplementedError("segment-consistency term with use_symmetric_ce: SCELoss is undefined on class-index targets")
             self._segment_term(segments, segment_jitter, gv, w_sem * float(c.lambda_segment))
-        tv = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
-        self.losses[2] = tv
+        if not early:
+            self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         if self.nosync:
             engine.reset_rows_limit(self.device)
-        self._allreduce(self.main_range)
+        if early:
+            self._allreduce(self.late_range)
+            self._allreduce_finish(started[0])
+        else:
+            self._allreduce(self.main_range)
         self.opt_main.step(skip=() if sem_on else ("net_sem",))      # no semantic term yet: the head's grad is None in the reference
         self.last_outputs = (rgb, sem)
         return ctxs

@@ -56,7 +56,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, overlap=True):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -64,6 +64,7 @@ def _dp_worker(rank, world, port, q):
     try:
         tr, batch, jit = _setup(chunk=0)
         assert tr.world == world
+        tr.overlap_allreduce = overlap        # True: appearance tables + MLPs all-reduced under the density backward, density tables after it
         B = batch[0]["rays"].shape[0]
         h = B // world
         sl = slice(rank * h, (rank + 1) * h)
@@ -76,7 +77,8 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_match_single_process():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_data_parallel_two_ranks_match_single_process(overlap):
     import torch.multiprocessing as mp
     tr, batch, jit = _setup(chunk=0)
     tr.main_pass(batch[0], jitter=jit, white_bg=False)
@@ -85,7 +87,7 @@ def test_data_parallel_two_ranks_match_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(2)]
