@@ -91,17 +91,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Everything the measurement itself uses for the first time -- a device-to-host copy (the generator state in the snapshot), timing
+    # events, their read-back -- is used once BEFORE the warm-up: the runtime creates queues / signal pools lazily, and in the first GPU
+    # process on a fresh box that one-off cost (44-51 ms) landed in the first timed step.
+    _ = tr._rng_state()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record(); torch.zeros(8, device=dev).cpu(); ev[1].record(); torch.cuda.synchronize(); _ = ev[0].elapsed_time(ev[1])
     for i in range(a.warmup):
         tr.training_step(batches[i % n_batches], lean=a.lean)
     # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
     # replays exactly these steps with per-launch events
     snap = (model.param_flat.clone(), tr.opt_main.state_dict(), tr.opt_inst.state_dict(), tr._rng_state())
     sync_all()
+    # one event per step boundary (recorded, never waited on inside the loop): the per-step GPU times afterwards show whether the K steps were
+    # uniform or whether one of them carried a one-off stall (seen: ~40 ms once in the first GPU process on a fresh box)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         tr.training_step(batches[i % n_batches], lean=a.lean)
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    if os.environ.get("CLIFT_BENCH_DUMP"):
+        print("[steps] " + " ".join(f"{x:.2f}" for x in step_ms), file=sys.stderr)
+    step_ms.sort()
     # ---- roofline pass: the SAME steps again from the same state (the active-sample count drifts while the field trains, so
     # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
@@ -226,6 +241,8 @@ def main():
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
                 "roofline": roof, "cpu_baseline": cpu}
         line.update(extra)
+        line["step_ms_median"] = step_ms[len(step_ms) // 2]
+        line["step_ms_min_max"] = [step_ms[0], step_ms[-1]]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -282,6 +282,19 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
          (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0 && h->ldb >= 128)) &&
         getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_layer_n128_launch(p, h->b_trans, st);
+    // dX of the first appearance layer, (M x 128) (128 x 160), no mask: columns 0..127 through the persistent 128-wide dgrad kernel,
+    // columns 128..159 through the tiled 32-column kernel (one tiled 128 x 256 launch: 183 us at 265 k rows; the pair: see DESIGN 5b)
+    if (h->precision == 0 && !h->a_trans && h->b_trans && h->N == 160 && h->K == 128 && h->M >= 4096 && splits == 1 && !h->accumulate && !h->c_trans &&
+        !h->mask && !h->bias && h->act == 0 && h->lda >= 128 && h->lda % 4 == 0 && h->ldb >= 160 && h->ldb % 4 == 0 && h->ldc >= 160 && h->ldc % 4 == 0 &&
+        (((uintptr_t)h->C) & 15) == 0 && (((uintptr_t)h->A) & 15) == 0 && (((uintptr_t)h->B) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr) {
+        GemmP p1 = p;
+        p1.N = 128; p1.mask = p1.A; p1.ldmask = p1.lda; p1.act = 7;
+        const int rc = clift_layer_n128_launch(p1, 1, st);
+        if (rc) return rc;
+        GemmP p2 = p;
+        p2.N = 32; p2.B = p.B + 128; p2.C = p.C + 128;
+        return launch_gemm<256, 32, 4, 1>(p2, 0, 1, 1, st);
+    }
     if (h->N > 128) {
         return launch_gemm<128, 256, 2, 4>(p, h->a_trans, h->b_trans, splits, st);
     }

@@ -721,3 +721,19 @@ def test_narrow_wgrad_stream_on_narrower_activations(M, no, ldd, ni):
         rel_close(gW_nb, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="no-bias form")
         outs.append(gW)
     rel_close(outs[0], outs[1], 2e-5, atol=2e-5 * float(refw.abs().max()), what="stream vs VALU kernel")
+
+
+@pytest.mark.parametrize("M", [4096, 4099, 40001, 249003])
+def test_first_appearance_layer_input_gradient_split_launch(M):
+    """dX = dH (M x 128) W (128 x 160), unmasked (the first appearance layer's input gradient, tensoRF.py:389-393 backward): columns 0..127 run
+    through the persistent 128-wide dgrad kernel without a mask, columns 128..159 through the tiled 32-column kernel.  Against fp64; pad
+    columns beyond the pitch are never written."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M)
+    dH = torch.randn((M, 128), generator=g)
+    W = torch.randn((128, 160), generator=g) * 0.1
+    ref = dH.double() @ W.double()
+    out = torch.full((M, 164), -7.0, device=DEV)
+    engine.gemm(M, 160, 128, dH.to(DEV), 128, W.to(DEV), 160, out, 164, b_trans=1)
+    rel_close(out[:, :160], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="split dX")
+    assert bool((out[:, 160:] == -7.0).all())
