@@ -556,11 +556,13 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             if model.slow_fast_mode:
                 br.run(3, slow_chain)
         br.join()
-    rgb_raw = torch.zeros((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
+    # (the sum kernel writes every (ray, channel) when there are heads to sum; only a chunk without active samples needs the zeros)
+    fresh = torch.empty if M > 0 else torch.zeros
+    rgb_raw = fresh((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
     rgb_map = torch.empty((N, 3), dtype=torch.float32, device=dev) if want_rgb else None
-    sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
+    sem_raw = fresh((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
     sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
-    inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D > 0 else None
+    inst_map = fresh((N, D), dtype=torch.float32, device=dev) if D > 0 else None
     if M > 0:
         call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D,
              ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.ray_out), softmax_mode, ctx.white_bg,
@@ -761,9 +763,10 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
             if model.slow_fast_mode:
                 br.run(3, slow_chain)
             br.join()
-    sem_raw = torch.zeros((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
+    fresh = torch.empty if M > 0 else torch.zeros          # (as in render_forward: the sums are written in full unless the chunk is empty)
+    sem_raw = fresh((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
     sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if Ccls else None
-    inst_map = torch.zeros((N, D), dtype=torch.float32, device=dev) if D else None
+    inst_map = fresh((N, D), dtype=torch.float32, device=dev) if D else None
     call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls, D, None, ptr(ctx.sem_s), ptr(ctx.inst_s),
          ptr(ctx.ray_out), ctx.softmax_mode, 0, None, None, ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
     ctx.sem_raw = sem_raw
