@@ -176,10 +176,18 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
 // MASK = false (fp32 only): plain dX = dOut W with N = g.N <= 256 output columns (a multiple of 4): the dgrad of the appearance basis
 // (27 -> 144, tensoRF.py:65,127-134), which the tiled kernel ran at 1.4 TB/s.  Waves whose 32 columns lie past N only help with the DMA.
-template <int KJ, bool HB, bool MASK>
-__global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block) {
+// WG (fp32, masked, N = 256): the output layer's WEIGHT gradient in the same pass -- gW[c][n] += sum_m dOut[m][c] h[m][n], gb[c] += sum_m dOut[m][c] --
+// where h IS the mask tensor (the post-ReLU activation): the separate k_wgrad_narrow_stream launch streams the M x 256 activation from
+// memory a second time.  A lane holds its row's 16 mask values; the wave turns its 32 x 32 block through a private padded LDS buffer
+// (4 ds_write_b128, 16 ds_read_b32 per lane) so that rows become the MFMA reduction index, reads dOut column-wise from the tile that is
+// already in LDS, and adds 16 MFMAs per tile into one accumulator kept for the whole row range (flushed once, like k_wgrad_narrow_stream).
+constexpr int DN_TPITCH = 36;            // floats per row of the transposition buffer (16-byte rows, conflict-free both ways)
+template <int KJ, bool HB, bool MASK, bool WG = false>
+__global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block, float* __restrict__ gW = nullptr, int ldgw = 0,
+                                                                float* __restrict__ gb = nullptr, int no = 0) {
+    static_assert(!WG || (MASK && !HB), "the fused weight gradient exists for the fp32 masked form");
     constexpr int ROWS = 32, TILEB = ROWS * 32 * 4;                          // stage: up to 32 rows x 32 floats
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB];   // the only LDS object
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB + (WG ? 8 * ROWS * DN_TPITCH * 4 : 0)];   // the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     if (rows_limited()) {
         g.M = limit_rows(g.M);
@@ -216,6 +224,11 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 #pragma unroll
     for (int j = 0; j < KJ; ++j) foff[j] = (unsigned)((li * lda + ((8 * j + 4 * lh + 3 < lda) ? 8 * j + 4 * lh : 0)) * 4);
     const bool full_wave = 32 * wave + 32 <= g.N;                            // all four column groups of this wave are stored
+    f32x16 accw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+    float bsum = 0.f;
+    const unsigned tb0 = lds0 + (unsigned)(2 * TILEB + wave * ROWS * DN_TPITCH * 4);      // this wave's transposition buffer
     dma(0);
     for (int t = 0; t < ntiles; ++t) {
         // MASK: the previous epilogue waited for everything older than its stores, the DMA of this tile included.  !MASK: the DMA of this tile
@@ -225,6 +238,14 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < ntiles) dma(t + 1);
+        if (WG) {
+            const int valid = rend - (rbeg + t * ROWS);
+            if (valid < ROWS) {                                              // last tile of the range: rows past its end add nothing to gW
+                float* dt = reinterpret_cast<float*>(lds + (t & 1) * TILEB);
+                for (int e = valid * lda + tid; e < ROWS * lda; e += 512) dt[e] = 0.f;
+                __syncthreads();
+            }
+        }
         const int m = rbeg + t * ROWS + li;
         f32x4 mk[4];
         u32x2v mh[4];
@@ -263,6 +284,29 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
         if (!MASK) {
         } else if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mh[0]), "+v"(mh[1]), "+v"(mh[2]), "+v"(mh[3]) : : "memory");
+        if (WG) {
+            // the wave's 32 x 32 block of h: row-per-lane registers -> LDS [row][36] -> column-per-lane registers (rows 2 s + lh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                asm volatile("ds_write_b128 %0, %1" : : "v"(tb0 + (unsigned)((li * DN_TPITCH + 8 * q + 4 * lh) * 4)), "v"(mk[q]) : "memory");
+            float hb[16], da[16];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                asm volatile("ds_read_b32 %0, %1" : "=v"(hb[s_]) : "v"(tb0 + (unsigned)(((2 * s_ + lh) * DN_TPITCH + li) * 4)) : "memory");
+                asm volatile("ds_read_b32 %0, %1" : "=v"(da[s_]) : "v"(sb + (unsigned)(((2 * s_ + lh) * lda + min(li, lda - 1)) * 4)) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]), "+v"(hb[4]), "+v"(hb[5]), "+v"(hb[6]), "+v"(hb[7]),
+                         "+v"(hb[8]), "+v"(hb[9]), "+v"(hb[10]), "+v"(hb[11]), "+v"(hb[12]), "+v"(hb[13]), "+v"(hb[14]) : : "memory");
+            asm volatile("" : "+v"(hb[15]), "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(da[4]), "+v"(da[5]), "+v"(da[6]), "+v"(da[7]),
+                         "+v"(da[8]), "+v"(da[9]), "+v"(da[10]), "+v"(da[11]), "+v"(da[12]), "+v"(da[13]) : : "memory");
+            asm volatile("" : "+v"(da[14]), "+v"(da[15]) : : "memory");
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) {
+                const float av = li < lda ? da[s_] : 0.f;                    // lanes past the padded class count feed zeros
+                accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hb[s_], accw, 0, 0, 0);
+                bsum += av;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float o[4] = {acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1], acc0[4 * q + 2] + acc1[4 * q + 2],
@@ -287,6 +331,44 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             }
         }
     }
+    if (WG) {
+        // lane (li, lh) holds gW rows c = 8 q + 4 lh + e, column 32 wave + li
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
+            if (c < no) unsafeAtomicAdd(gW + (size_t)c * ldgw + 32 * wave + li, accw[r]);
+        }
+        if (gb && wave == 0) {       // every wave read the same dOut; wave 0 folds the two row parities and adds the bias gradient
+            const unsigned u = __float_as_uint(bsum);
+            const u32x2v sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            if (lh == 0 && li < no) unsafeAtomicAdd(gb + li, tot);
+        }
+    }
+}
+
+// Backward of a narrow output layer over a 256-wide ReLU hidden layer in ONE pass over the hidden activation H (tensoRF.py:480-481,
+// 593-594 backward): dX = (H > 0) . (dOut W), gW += dOut^T H, gb += column sums of dOut.  dOut (M, ldd) fp32 with zero pad columns,
+// W (no, 256) pitch ldw, H (M, 256) pitch ldh, dX (M, 256) pitch ldx; no <= ldd <= 32, ldd % 4 == 0, M >= 1, 16-byte-aligned rows.
+extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
+                                   float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(no >= 1 && no <= ldd && ldd <= 32 && ldd % 4 == 0, "clift_out_layer_bwd: need no <= ldd <= 32, ldd %% 4 == 0 (got no=%d ldd=%d)", no, ldd);
+    CLIFT_REQUIRE(ldh % 4 == 0 && ldx % 4 == 0 && ldh >= 256 && ldx >= 256 && ldw >= 256 && ldgw >= 256 && (((uintptr_t)dOut) & 15) == 0 &&
+                  (((uintptr_t)H) & 15) == 0 && (((uintptr_t)dX) & 15) == 0, "clift_out_layer_bwd: 16-byte aligned rows with pitches >= 256 required");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = no; p.A = dOut; p.lda = ldd; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx; p.mask = H; p.ldmask = ldh;
+    const int tiles = cdiv(M, 32);
+    const int blocks = tiles < 256 ? tiles : 256;
+    const int rpb = cdiv(cdiv(M, blocks), 32) * 32;
+    const dim3 grid(cdiv(M, rpb));
+    hipStream_t st = as_stream(s);
+    const int kj = cdiv(no, 8);
+    if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    else k_dgrad_narrow_stream<4, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    return clift_check_launch("clift_out_layer_bwd");
 }
 
 // Eligibility decided by the callers (gemm.hip / gemm_bf16.hip): plain fp32 A with lda in {4, 8, .., 32} = its row pitch, K <= lda, b_trans

@@ -263,6 +263,8 @@ def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
          ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
 
 
+# xyz heads: the output layer's weight gradient and input gradient in one launch (clift_out_layer_bwd)
+FUSE_OUT_BWD = os.environ.get("CLIFT_FUSE_OUT_BWD", "1") != "0"
 # density table gradients: hand the forward's sigma to the scatter (softplus derivative = 1 - exp(-sigma), once per sample) instead of
 # letting it re-sum the sample's feature over planes and channels
 DENS_BWD_SIGMA = os.environ.get("CLIFT_DENS_BWD_SIGMA", "1") != "0"
@@ -360,8 +362,16 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         gW, gb = glayers[li]
         h = acts[li - 1]
         no, ni = W.shape
-        wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
+        if (FUSE_OUT_BWD and li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and
+                MLP_PRECISION == 0 and h.dtype == torch.float32 and d.dtype == torch.float32 and dn.dtype == torch.float32):
+            # output layer: weight gradient and masked input gradient in one pass over the hidden activation
+            call("clift_out_layer_bwd", ptr(d), d.shape[1], no, ptr(W), _pitch(W), ptr(h), h.shape[1], M, ptr(dn), ni, ptr(gW), _pitch(gW),
+                 ptr(gb), stream())
+            d = dn
+            keep.append(d)
+            continue
+        wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
         gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
         keep.append(d)

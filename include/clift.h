@@ -193,6 +193,14 @@ typedef struct {
                                      * the pointers are passed through the float* fields */
 } clift_gemm_t;
 long clift_gemm_workspace_bytes(int N, int K);
+
+/* Backward of a narrow output layer (no <= 32 outputs: 22 classes / 3 instance dims) over a 256-wide ReLU hidden layer in ONE pass over
+ * the hidden activation H (tensoRF.py:480-481, 593-594 backward): dX = (H > 0) . (dOut W), gW += dOut^T H, gb += column sums of dOut.
+ * dOut (M, ldd) fp32 with zero pad columns (no <= ldd <= 32, ldd % 4 == 0), W (no, 256) pitch ldw, H (M, 256) pitch ldh, dX (M, 256)
+ * pitch ldx, gW (no, 256) pitch ldgw (accumulated), gb (no) nullable (accumulated); 16-byte aligned rows.  Replaces one clift_wgrad_narrow +
+ * one masked clift_gemm(b_trans) call, which each stream H from memory. */
+int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
+                        float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 
 /* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4), W (Nout, 3)

@@ -737,3 +737,32 @@ def test_first_appearance_layer_input_gradient_split_launch(M):
     engine.gemm(M, 160, 128, dH.to(DEV), 128, W.to(DEV), 160, out, 164, b_trans=1)
     rel_close(out[:, :160], ref, 2e-5, atol=2e-5 * float(ref.abs().max()), what="split dX")
     assert bool((out[:, 160:] == -7.0).all())
+
+
+@pytest.mark.parametrize("M,no,ldd", [(4096, 22, 24), (4099, 3, 4), (40001, 22, 24), (249003, 3, 4), (5000, 32, 32), (8191, 6, 8), (33, 22, 24)])
+def test_output_layer_backward_in_one_pass(M, no, ldd):
+    """clift_out_layer_bwd: dX = (H > 0) . (dOut W), gW += dOut^T H, gb += column sums of dOut from ONE pass over the hidden activation H.
+    Against fp64 (accumulating onto existing gW / gb, ragged row counts incl. a last partial tile, zero pad columns of dOut), and dX
+    bit-identical to the separate masked dgrad launch (the same MFMA chain)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + no)
+    dOut = torch.zeros((M, ldd))
+    dOut[:, :no] = torch.randn((M, no), generator=g)
+    W = torch.randn((no, 256), generator=g) * 0.1
+    H = torch.relu(torch.randn((M, 256), generator=g))
+    dOd, Wd, Hd = dOut.to(DEV), W.to(DEV), H.to(DEV)
+    dX = torch.full((M, 256), -7.0, device=DEV)
+    gW = torch.full((no, 256), 0.25, device=DEV)
+    gb = torch.full((no,), -1.0, device=DEV)
+    engine.call("clift_out_layer_bwd", engine.ptr(dOd), ldd, no, engine.ptr(Wd), 256, engine.ptr(Hd), 256, M, engine.ptr(dX), 256,
+                engine.ptr(gW), 256, engine.ptr(gb), engine.stream())
+    ref_dx = (dOut[:, :no].double() @ W.double()) * (H > 0)
+    ref_w = dOut[:, :no].double().T @ H.double() + 0.25
+    ref_b = dOut[:, :no].double().sum(0) - 1.0
+    rel_close(dX, ref_dx, 2e-5, atol=2e-5 * float(ref_dx.abs().max()), what="fused dX")
+    rel_close(gW, ref_w, 2e-5, atol=2e-5 * float(ref_w.abs().max()), what="fused gW")
+    rel_close(gb, ref_b, 2e-5, atol=2e-5 * M ** 0.5, what="fused gb")
+    if M >= 4096:
+        dX2 = torch.empty((M, 256), device=DEV)
+        engine.gemm(M, 256, no, dOd, ldd, Wd, 256, dX2, 256, b_trans=1, mask=Hd, ldmask=256)
+        assert torch.equal(dX, dX2)
