@@ -114,6 +114,7 @@ class HotPathTrainer:
         self.late_range = m.arena.range_of("grid_density")                       # final only after the density backward
         self.early_range = m.arena.range_of("grid_app", "net_app", "net_sem")     # final once the head chains are issued
         self.overlap_allreduce = bool(getattr(c, "overlap_allreduce", True))
+        self.force_collectives = False          # tests: issue the collectives in a one-rank group too (RCCL path on a single-GPU box)
         # The slow MLP is listed in the reference's instance optimizer when not DINO-style (F:241-244), but its output is detached
         # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
         i0, i1 = m.arena.range_of("inst_fast")
@@ -125,7 +126,7 @@ class HotPathTrainer:
         self.current_lambda_dist_reg = self.config.lambda_dist_reg * (1 - math.exp(-0.25 * self.current_epoch))
 
     def _allreduce(self, rng):
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             g = self.model.grad_flat[rng[0]:rng[1]]
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             g.mul_(1.0 / self.world)
@@ -231,7 +232,7 @@ class HotPathTrainer:
         # Data-parallel runs: the TV term depends on the parameters only, so it goes FIRST (the scatter kernels accumulate on top of it),
         # and once the last chunk's head chains are issued everything but the density tables is final: that range (appearance tables +
         # both MLPs, ~3/4 of the bytes) is all-reduced under the density backward, the density tables after it.
-        early = self.world > 1 and self.overlap_allreduce and not seg_term
+        early = (self.world > 1 or self.force_collectives) and self.overlap_allreduce and not seg_term
         started = []
         if early:
             self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)

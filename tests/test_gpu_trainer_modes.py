@@ -166,3 +166,48 @@ def test_fp32x6_mode_matches_fp32_path():
                 grad_close(grads["fp32x6"][k], grads["fp32"][k], what=f"fp32x6 {k}")
     finally:
         engine.set_mlp_precision("fp32")
+
+
+def _rccl_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        out = {}
+        for overlap in (True, False):
+            tr, batch, jit = _setup(chunk=0)
+            tr.force_collectives, tr.overlap_allreduce = True, overlap
+            tr.main_pass(batch[0], jitter=jit, white_bg=False)
+            tr.instance_pass(batch[1])
+            torch.cuda.synchronize()
+            out[overlap] = tr.model.param_flat.detach().cpu().numpy()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_in_a_one_rank_group():
+    """The `nccl` (= RCCL) branch of the trainer on the hardware this suite runs on: a one-rank process group, collectives forced on, so
+    the asynchronous all-reduce of the appearance/MLP range under the density backward, the synchronous one of the density range and the
+    instance pass's all-reduce all go through RCCL on the arena's device tensors.  A sum over one rank changes nothing: parameters after a
+    full step must equal the collective-free single-process step up to the scatter kernels' atomic summation order (units of a learning-rate step)."""
+    import torch.multiprocessing as mp
+    tr, batch, jit = _setup(chunk=0)
+    tr.main_pass(batch[0], jitter=jit, white_bg=False)
+    tr.instance_pass(batch[1])
+    p_ref = tr.model.param_flat.detach().cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    for overlap, params in out.items():
+        diff = (torch.from_numpy(params) - p_ref).abs()
+        a, b = tr.main_range
+        g0, g1 = tr.model.arena.range_of("grid_density", "grid_app")
+        assert float(diff[g0:g1].max()) <= 0.1 * 1e-2 and float(diff[g1:b].max()) <= 0.1 * 5e-4, (overlap, float(diff[g0:g1].max()), float(diff[g1:b].max()))
+        i0, i1 = tr.inst_range
+        assert float(diff[i0:i1].max()) <= 0.1 * 5e-4
