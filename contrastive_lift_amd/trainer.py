@@ -29,7 +29,9 @@ def default_config(**over):
              lambda_segment=1.2, segment_grouping_mode="argmax_conf", segment_optimization_epoch=6, batch_size_segments=32,
              max_rays_segments=1024, use_symmetric_ce=False, ce_alpha=0.85, ce_beta=0.15, reweight_fg=False,
              mlp_dtype="fp32",     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
-             nosync=False)         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
+             nosync=False,         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
+             skip_discarded_instance_heads=False)    # extension key: do not evaluate the instance heads in the main pass, where the reference
+                                                     # computes and discards them (T:155) -- same results, ~12 % less work; the train CLI sets it
     c.update(over)
     return types.SimpleNamespace(**c)
 
@@ -325,10 +327,12 @@ class HotPathTrainer:
         self._allreduce(self.inst_range)
         self.opt_inst.step()
 
-    def training_step(self, batch, lean=False):
+    def training_step(self, batch, lean=None):
         """batch[0] = pixel batch dict, batch[1] = list of instance-image dicts (reference CombinedLoader layout)."""
         seg = batch.get(2) if (getattr(self.config, "segment_grouping_mode", "none") != "none" and
                                self.current_epoch >= self.config.segment_optimization_epoch) else None
+        if lean is None:
+            lean = bool(getattr(self.config, "skip_discarded_instance_heads", False))
         self.main_pass(batch[0], lean=lean, segments=seg)
         if self.current_epoch >= self.config.instance_optimization_epoch and batch.get(1):
             self.instance_pass(batch[1])

@@ -86,6 +86,9 @@ def main(argv):
     if isinstance(cfg.image_dim, int):
         cfg.image_dim = [cfg.image_dim, cfg.image_dim]
     cfg.experiment = experiment_name(cfg)
+    if getattr(cfg, "skip_discarded_instance_heads", None) is None:
+        # the reference's main pass evaluates the instance heads and throws the result away (T:155: `_`); same training either way
+        cfg.skip_discarded_instance_heads = True
     seed = cfg.seed if cfg.seed is not None else 0
     torch.manual_seed(seed)                                                # identical initial weights on every rank
     cfg.instance_optimization_epoch = cfg.instance_optimization_epoch + cfg.late_semantic_optimization     # T:46
