@@ -24,6 +24,7 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+PMC_RECORD = "profiles/r02_pmc_k_layer_f32.json"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
@@ -50,24 +51,78 @@ def parse():
     ap.add_argument("--nosync", action="store_true",
                     help="sync-free steps: the active-sample count is never read back; buffers sized by a learnt capacity, kernels clamp to the "
                          "device-side count (exact fp32 only)")
+    ap.add_argument("--inference-sharded", action="store_true",
+                    help="BASELINE configs[4]: time full 1296x968 frames through inference.render_rays_sharded (row tiles over the ranks, one "
+                         "all-gather per frame) instead of training steps; a 'step' is one frame, value = rays/s over the job")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only launch the ranks, form the process group, all-reduce one number and print the line's n_gpus / rccl_ranks "
+                         "fields (no render work; runs without a GPU over gloo)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and frame-render extras measured after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` without a launcher: re-exec this command under torch.distributed.run with N ranks on this node
+    (one per GPU, RCCL).  On a box with fewer devices than ranks (the 1-GPU test box) the ranks share devices and the process group
+    falls back to gloo -- the line then says so (`dist_backend`, `rccl_ranks: 0`)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < a.gpus:
+        env.setdefault("CLIFT_DIST_BACKEND", "gloo")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(a, world, rank):
+    """The launcher path alone: process group + one collective, no render work (CPU-runnable)."""
+    backend = os.environ.get("CLIFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    total = 1.0
+    if world > 1:
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            t = torch.ones(1, device="cuda")
+        else:
+            dist.init_process_group(backend)
+            t = torch.ones(1)
+        dist.all_reduce(t)
+        total = float(t.item())
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "requested_gpus": a.gpus, "dist_backend": backend if world > 1 else None,
+                          "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else 0), "allreduce_of_ones": total}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.launch_check:
+        return launch_check(a, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
     local = local % torch.cuda.device_count()       # (lets a 2-rank gloo smoke test share one GPU; a no-op on a real node)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         backend = os.environ.get("CLIFT_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            backend = "gloo"                                        # ranks share a device (1-GPU test box): RCCL wants one device per rank
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -80,6 +135,8 @@ def main():
 
     model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
     S = int(renderer.n_samples)
+    if a.inference_sharded:
+        return bench_inference_sharded(a, model, renderer, dev, world, rank, backend)
     cfg = default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype, nosync=a.nosync)
     tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
     n_batches = 4
@@ -97,6 +154,12 @@ def main():
     _ = tr._rng_state()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record(); torch.zeros(8, device=dev).cpu(); ev[1].record(); torch.cuda.synchronize(); _ = ev[0].elapsed_time(ev[1])
+    if world > 1 and tr.overlap_allreduce == "auto":
+        # data-parallel: the trainer decides by measurement whether the asynchronous exchange (early range all-reduced under the density
+        # backward, CUs reserved for RCCL) beats the synchronous one -- its 2 + 2 x 4 calibration passes synchronise the device, so
+        # they run here, before the warm-up
+        for i in range(tr.CAL_WARMUP + 2 * tr.CAL_STEPS):
+            tr.training_step(batches[i % n_batches], lean=a.lean)
     for i in range(a.warmup):
         tr.training_step(batches[i % n_batches], lean=a.lean)
     # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
@@ -224,7 +287,8 @@ def main():
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
-        line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+        line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s",
+                "main_pass_samples_per_s": extra.get("main_pass_samples_per_s"), "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": ("strong" if a.global_rays else "weak"),
                 "vs_baseline": None,
                 "value_definition": "nominal ray-samples of one full training_step = (main-pass rays + instance-pass rays) x S, over all ranks, / step time; the "
@@ -239,13 +303,97 @@ def main():
                            "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
                            "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean), "sync_free": bool(a.nosync),
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu,
+                "dist_backend": backend, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0),
+                "devices_visible": torch.cuda.device_count(),
+                "allreduce_overlap": (tr.overlap_decision or {"overlap": tr.overlap_allreduce}) if world > 1 else None,
+                "allreduce_cu_reserve": tr.allreduce_cu_reserve if world > 1 else None}
         line.update(extra)
         line["step_ms_median"] = step_ms[len(step_ms) // 2]
         line["step_ms_min_max"] = [step_ms[0], step_ms[-1]]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+FRAME_W, FRAME_H = 1296, 968             # BASELINE configs[4]: ScanNet colour frame
+
+
+def head_flops_per_active_sample(model):
+    """Forward matrix-core FLOPs of all heads per ACTIVE sample: 2 x (sum of in x out over every Linear of the appearance MLP + basis,
+    the semantic MLP and both instance MLPs)."""
+    tot = 0
+    for name, t in model.named_views().items():
+        if name.endswith(".weight") and t.dim() == 2 and ("mlp" in name or "basis_mat" in name):
+            tot += 2 * t.shape[0] * t.shape[1]
+    return float(tot)
+
+
+def bench_inference_sharded(a, model, renderer, dev, world, rank, backend):
+    """configs[4]: full 1296 x 968 frames (is_train=False, step ratio halved as RP:104, chunked like RP:114-120) through
+    ``inference.render_rays_sharded``: contiguous row tiles, one per rank, ONE all-gather of the packed outputs per frame.  A step is one
+    frame; value = rays/s over the job (strong scaling: the frame is fixed)."""
+    import numpy as np
+    from contrastive_lift_amd import inference as inf, synthetic
+    from contrastive_lift_amd.rays import generate_ray_table
+    K = np.array([[1170.0, 0, 647.75], [0, 1170.0, 483.75], [0, 0, 1]], np.float32)
+    rays = generate_ray_table(FRAME_H, FRAME_W, K, synthetic.look_at((0.0, 0.0, -0.9)), device=dev)
+    renderer.update_step_ratio(renderer.step_ratio * 0.5)
+    S = int(renderer.n_samples)
+    chunk = a.chunk or 65536
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(max(1, a.warmup)):
+        out = inf.render_rays_sharded(model, renderer, rays, chunk)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = inf.render_rays_sharded(model, renderer, rays, chunk)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        P = rays.shape[0]
+        # active samples of the frame (cost follows them): counted once on this rank's tile, outside the timed region
+        b = inf.tile_bounds(P, world)
+        mine = rays[b[0]:b[1]]
+        act = 0
+        for i in range(0, mine.shape[0], chunk):
+            _, ctx = engine_render_forward(model, renderer, mine[i:i + chunk])
+            act += int(ctx.M)
+        fl = head_flops_per_active_sample(model)
+        t_frame = dt / a.steps
+        tf = act * world * fl / t_frame / 1e12          # tiles are equal-sized; this rank's active fraction stands for the frame
+        print(json.dumps({"metric": "rays/sec (full-frame 1296x968 render, row tiles sharded over the ranks)", "value": P / t_frame,
+                          "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": t_frame * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"fp32": "f32"}.get(a.dtype, a.dtype),
+                          "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4] stand-in: one 1296x968 frame (1,254,528 rays), is_train=False, S=%d, "
+                                                 "chunk %d rays, rgb/semantics/instances/distance outputs" % (S, chunk),
+                                     "rays_per_frame": P, "samples_per_ray": S, "classes": a.classes, "grid": a.grid,
+                                     "parallelism": f"row tiles over {world} rank(s), 1 all-gather per frame"},
+                          "ray_samples_per_s": P * S / t_frame,
+                          "inference_roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": tf / PEAK_FP32_MFMA_TFLOPS, "active_samples_per_ray": act * world / P,
+                                                 "flops_per_active_sample": fl,
+                                                 "note": "head FLOPs of the frame's active samples / frame time / exact-fp32 MFMA peak"},
+                          "dist_backend": backend, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0),
+                          "devices_visible": torch.cuda.device_count()}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def engine_render_forward(model, renderer, rays):
+    from contrastive_lift_amd import engine
+    with torch.no_grad():
+        return engine.render_forward(model, renderer, rays, None, False, grad_heads=())
 
 
 def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
@@ -300,9 +448,17 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         S = int(renderer.n_samples)
+        act = 0
+        for i in range(0, rays.shape[0], chunk):
+            act += int(engine_render_forward(model, renderer, rays[i:i + chunk])[1].M)
     finally:
         renderer.update_step_ratio(ratio)
-    return dict(inference_rays_per_s=rays.shape[0] / dt, inference_ray_samples_per_s=rays.shape[0] * S / dt,
+    fl = head_flops_per_active_sample(model)
+    tf = act * fl / dt / 1e12
+    return dict(inference_roofline={"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                                    "active_samples_per_ray": act / rays.shape[0], "flops_per_active_sample": fl,
+                                    "note": "forward head FLOPs of the tile's active samples / render time / exact-fp32 MFMA peak"},
+                inference_rays_per_s=rays.shape[0] / dt, inference_ray_samples_per_s=rays.shape[0] * S / dt,
                 inference_samples_per_ray=S, inference_probe=f"{rays.shape[0]} rays, chunk {chunk}, fp32 outputs rgb/sem/inst/dist")
 
 
@@ -311,7 +467,7 @@ def measured_traffic_ratio():
     the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-byte-per-lane streaming reads on gfx950) over this very command and over the torch-free single-kernel harness."""
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_k_layer_f32.json")) as f:
+        with open(os.path.join(REPO, PMC_RECORD)) as f:
             return json.load(f)
     except (OSError, ValueError):
         return None
@@ -371,6 +527,8 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
            # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on
            # the same command (profiles/r02_pmc_k_layer_f32.json); null if that record is missing
            "traffic": (alg_bytes * pmc["bench_ratio"]) if pmc else None,
+           "traffic_is": "ESTIMATE = this run's algorithmic bytes x the counter/algorithmic ratio RECORDED in " + PMC_RECORD + " (not re-measured by this run: "
+                         "PMC passes need rocprofv3 around the process; tools/gpu_pmc_bench.sh re-records it)",
            "traffic_unit": "bytes/launch (average launch of this run)",
            "traffic_algorithmic": alg_bytes,
            "traffic_over_algorithmic": pmc["bench_ratio"] if pmc else None,

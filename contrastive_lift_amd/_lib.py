@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -52,6 +52,7 @@ class Gemm(C.Structure):
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 _SIGNATURES = {
     "clift_version": ([], C.c_int),
+    "clift_set_cu_reserve": ([_I], C.c_int),
     "clift_segment_loss": ([_P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _I, _P], C.c_int),
     "clift_gemm_workspace_bytes": ([_I, _I], C.c_long),
     "clift_out_layer_bwd": ([_P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),

@@ -10,6 +10,7 @@
 // ----------------------------------------------------------------------------- host-side error plumbing
 void clift_set_error(const char* fmt, ...);
 int clift_check_launch(const char* what);
+int clift_persistent_cus();      // blocks of a one-block-per-CU persistent launch: 256 - clift_set_cu_reserve()
 
 #define CLIFT_REQUIRE(cond, ...)              \
     do {                                      \

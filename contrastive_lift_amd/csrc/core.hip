@@ -20,7 +20,17 @@ int clift_check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int clift_version(void) { return 7; }
+extern "C" int clift_version(void) { return 8; }
+
+// Data-parallel runs: while an asynchronous RCCL all-reduce is in flight the persistent launches (one block per CU, held for the whole
+// launch) leave `k` CUs to the collective's kernels.  Host state of the calling process; takes effect at the next launch.
+static int g_cu_reserve = 0;
+int clift_persistent_cus() { return 256 - g_cu_reserve; }
+extern "C" int clift_set_cu_reserve(int k) {
+    if (k < 0 || k > 128) { clift_set_error("clift_set_cu_reserve: k must be in [0,128] (got %d)", k); return 1; }
+    g_cu_reserve = k;
+    return 0;
+}
 
 // per-translation-unit binders (CLIFT_ROWS_LIMIT_BINDER in each kernel file)
 void clift_bind_rows_limit_march(const int* p);

@@ -207,7 +207,7 @@ extern "C" int clift_xyz_head_bf16_fwd(const float* x4, const float* W0, int ldw
     HeadP p = {x4, W0, ldw0, b0, W1, ldw1, b1, W2, ldw2, b2, Wout, ldwo, bout, E, out, ldo,
                reinterpret_cast<unsigned short*>(h1), reinterpret_cast<unsigned short*>(h2), reinterpret_cast<unsigned short*>(h3), M};
     const int tiles = cdiv(M, HB_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), HB_ROWS) * HB_ROWS;
     k_head_bf16_fwd<<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb);
     return clift_check_launch("clift_xyz_head_bf16_fwd");

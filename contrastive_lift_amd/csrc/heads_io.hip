@@ -418,7 +418,7 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
         else if (2 * (slab + 8 * rec_bytes) <= 160 * 1024 - 1024) { wpb = 8; bpc = 2; }
         const long items = 3L * cdiv(M, useg);
         const int want = cdiv(items, wpb);
-        const int blocks = want < 256 * bpc ? want : 256 * bpc;
+        const int blocks = want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc;
         const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
         if (lds_l) {
             if (dyn > 48 * 1024)
@@ -431,7 +431,7 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     }
     const long total = (long)cdiv(M, seg) * 3 * h_app->comps;
     const int want = cdiv(total, threads);
-    const int blocks = want < 256 * per_cu ? want : 256 * per_cu;
+    const int blocks = want < clift_persistent_cus() * per_cu ? want : clift_persistent_cus() * per_cu;
     if (use_lds) {
         if (lds_bytes > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_blo
 // Eligibility is decided by the caller (gemm_bf16.hip): N = K = 256, plain A, bf16-stored A / C (/ mask), 16-byte-aligned rows.
 int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int tiles = cdiv(p.M, LY_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;                    // one persistent block per CU
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();                    // one persistent block per CU
     const int rpb = cdiv(cdiv(p.M, blocks), 32) * 32;
     if (b_trans) k_layer_bf16<true, 1><<<blocks, 512, 0, st>>>(p, rpb);
     else k_layer_bf16<false, 3><<<blocks, 512, 0, st>>>(p, rpb);
@@ -309,7 +309,7 @@ int clift_wgrad_bf16_stream2d_launch(const GemmP& p, hipStream_t st);
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st) {
     if (p.K >= 4096 && getenv("CLIFT_WGRAD_1D") == nullptr) return clift_wgrad_bf16_stream2d_launch(p, st);      // 64 row ranges x 4 column slices
     const int tiles = cdiv(p.K, LY_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(p.K, blocks), LY_ROWS) * LY_ROWS;
     k_wgrad_bf16_stream<<<cdiv(p.K, rpb), 512, 0, st>>>(p, rpb);
     return clift_check_launch("clift_gemm(bf16 wgrad stream)");

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
 // no mask; dgrad (b_trans): [k][n] weights, fp32 mask, no bias / activation.
 int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int tiles = cdiv(p.M, LF_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;                    // one persistent block per CU
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();                    // one persistent block per CU
     const int rpb = cdiv(cdiv(p.M, blocks), LF_ROWS) * LF_ROWS;
     const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
@@ -327,7 +327,7 @@ extern "C" int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W,
     GemmP p = {};
     p.M = M; p.N = 256; p.K = 256; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
     const int tiles = cdiv(M, LF_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
     const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     const OutP op = {Wout, ldwo, bout, E, out, ldo, hidden != nullptr ? 1 : 0};
@@ -347,7 +347,7 @@ extern "C" int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int l
     GemmP p = {};
     p.M = M; p.N = 256; p.K = 256; p.A = nullptr; p.lda = 256; p.B = W1; p.ldb = ldw1; p.C = h2; p.ldc = ldh2; p.bias = b1; p.act = 1;
     const int tiles = cdiv(M, LF_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
     const GenP gp = {x4, W0, ldw0, b0, h1, ldh1};
     const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
 // are zero), plain row-major A, 16-byte-aligned rows; forward: [n][k] weights; dgrad (b_trans): [k][n] weights, fp32 mask (required).
 int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int tiles = cdiv(p.M, LN_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(p.M, blocks), LN_ROWS) * LN_ROWS;
     const dim3 grid(cdiv(p.M, rpb));
     const OutN no_out = {nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1};
@@ -283,7 +283,7 @@ extern "C" int clift_app_head_last2_fwd(const float* A, int lda, const float* W,
     GemmP p = {};
     p.M = M; p.N = 128; p.K = 128; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
     const int tiles = cdiv(M, LN_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), LN_ROWS) * LN_ROWS;
     const OutN op = {Wout, ldwo, bout, E, pre, ldp, out, ldo, sigmoid, hidden != nullptr ? 1 : 0};
     k_layer_n128<32, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, op);

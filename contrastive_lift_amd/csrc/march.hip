@@ -514,7 +514,7 @@ extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_d
         if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 8; bpc = 3; }
         const long items = (long)N * cdiv(h_m->n_samples, DU_SEG);
         const long want = cdiv(items, wpb);
-        const int blocks = (int)(want < 256 * bpc ? want : 256 * bpc);
+        const int blocks = (int)(want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc);
         const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
         if (lds_l) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd_u<true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
@@ -530,7 +530,7 @@ extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_d
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
     const long want = cdiv(nseg << lg, (long)threads);
-    const int blocks = (int)(want < 256 * per_cu ? want : 256 * per_cu);
+    const int blocks = (int)(want < clift_persistent_cus() * per_cu ? want : clift_persistent_cus() * per_cu);
     if (use_lds) {
         if (lds_bytes > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_density_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
 int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const float* X, int ldx, int ni, int M, float* gW, int ldw, float* gb, int x_bf16,
                                      hipStream_t st) {
     const int tiles = cdiv(M, NS_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
     if (x_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr, 256);
     else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(dY, ldd, no, X, ldx, M, rpb, gW, (long)ldw, 1L, gb, -1, nullptr, ni);
@@ -157,7 +157,7 @@ int clift_wgrad_narrow_stream_launch(const float* dY, int ldd, int no, const flo
 // (x4 = (M, 4) positions, dH = (M, 256) hidden gradient, fp32 or bf16-stored).  Eligibility decided by the caller.
 int clift_k3_bwd_stream_launch(const float* x4, const float* dH, int ldh, int M, float* dW, int ldw, float* db, int dh_bf16, hipStream_t st) {
     const int tiles = cdiv(M, NS_ROWS);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), NS_ROWS) * NS_ROWS;
     if (dh_bf16) k_wgrad_narrow_stream<true><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db, 256);
     else k_wgrad_narrow_stream<false><<<cdiv(M, rpb), 512, 0, st>>>(x4, 4, 3, dH, ldh, M, rpb, dW, 1L, (long)ldw, nullptr, 3, db, 256);
@@ -359,7 +359,7 @@ extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const flo
     GemmP p = {};
     p.M = M; p.N = 256; p.K = no; p.A = dOut; p.lda = ldd; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx; p.mask = H; p.ldmask = ldh;
     const int tiles = cdiv(M, 32);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), 32) * 32;
     const dim3 grid(cdiv(M, rpb));
     hipStream_t st = as_stream(s);
@@ -376,7 +376,7 @@ extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const flo
 // N % 4 == 0.
 int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
     const int tiles = cdiv(p.M, 32);
-    const int blocks = tiles < 256 ? tiles : 256;
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(p.M, blocks), 32) * 32;
     const dim3 grid(cdiv(p.M, rpb));
     const int kj = cdiv(p.K, 8);

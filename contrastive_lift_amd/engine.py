@@ -430,6 +430,14 @@ def _density_march(model, renderer, rays, jitter, cap=None):
          ptr(n_active), st)
     ray_start = torch.empty((N + 1,), dtype=torch.int32, device=dev)
     if cap is None:
+        # a synchronising chunk inside a sync-free pass (a pass still learning its capacity, e.g. the segment term whose ray count
+        # changes every step): the library-wide row limit may still hold the PREVIOUS capped chunk's count, which would silently clamp
+        # every per-sample kernel of this chunk -- put "no limit" back first (stream-ordered)
+        global _limit_owner
+        lim_t = _rows_limit.get((dev.type, dev.index))
+        if lim_t is not None and _limit_owner is not None:
+            lim_t[0:1].fill_(INT_MAX)
+            _limit_owner = None
         call("clift_scan_counts", ptr(n_active), N, ptr(ray_start), st)
         M = int(ray_start[N].item())        # the one host sync of the chunk: sizes the active-sample buffers
         act_idx = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
@@ -448,7 +456,6 @@ def _density_march(model, renderer, rays, jitter, cap=None):
     ctx.ms, ctx.res, ctx.N, ctx.S, ctx.M = ms, res, N, S, M
     ctx.capped = cap is not None
     if ctx.capped:
-        global _limit_owner
         _limit_owner = ctx
     ctx.rays, ctx.jitter = rays, jitter
     ctx.alpha, ctx.T, ctx.w, ctx.ray_out, ctx.ray_start, ctx.act_idx = alpha, T, w, ray_out, ray_start, act_idx
@@ -599,11 +606,13 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
     N, S, M = ctx.N, ctx.S, ctx.M
     dev = ctx.rays.device
     st = stream()
+    global _limit_owner
     if getattr(ctx, "capped", False):
-        global _limit_owner
         if _limit_owner is not ctx:        # another chunk was marched since: put THIS chunk's row count back (device-to-device, 4 bytes)
             rows_limit(dev)[0:1].copy_(ctx.ray_start[N:N + 1])
             _limit_owner = ctx
+    elif _limit_owner is not None:         # a synchronising chunk's backward behind a sync-free chunk: its rows are not to be clamped
+        reset_rows_limit(dev)
     Ccls, D = ctx.C, ctx.D
     want_rgb, want_sem, want_inst = ctx.want
     g_rgb = g_rgb.contiguous() if (g_rgb is not None and want_rgb) else None

@@ -8,6 +8,7 @@ that the pass touched -- the reference's DDP does the same exchange bucket by bu
 (SURVEY 2a/2b).  The slow net is an EMA of synchronised fast weights, so it needs no exchange.
 """
 import math
+import time
 import types
 
 import torch
@@ -115,13 +116,23 @@ class HotPathTrainer:
         self.main_range = m.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")
         self.late_range = m.arena.range_of("grid_density")                       # final only after the density backward
         self.early_range = m.arena.range_of("grid_app", "net_app", "net_sem")     # final once the head chains are issued
-        self.overlap_allreduce = bool(getattr(c, "overlap_allreduce", True))
+        # data-parallel exchange of the main pass: True = early range all-reduced asynchronously under the density backward, False = one
+        # synchronous all-reduce after the backward, "auto" (default) = measure both over the first steps and keep the faster one.  The
+        # persistent kernels hold one block per CU for a whole launch, so while the asynchronous collective is in flight they leave
+        # ``allreduce_cu_reserve`` CUs to RCCL's kernels (clift_set_cu_reserve).
+        ov = getattr(c, "overlap_allreduce", "auto")
+        self.overlap_allreduce = ov if isinstance(ov, bool) else ("auto" if str(ov).lower() == "auto" else str(ov).lower() in ("1", "true", "yes"))
+        self.allreduce_cu_reserve = int(getattr(c, "allreduce_cu_reserve", 8))
+        self._cal = {"times": {True: [], False: []}, "decided": None}
         self.force_collectives = False          # tests: issue the collectives in a one-rank group too (RCCL path on a single-GPU box)
         # The slow MLP is listed in the reference's instance optimizer when not DINO-style (F:241-244), but its output is detached
         # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
         i0, i1 = m.arena.range_of("inst_fast")
         self.opt_inst = ArenaAdam(m, [("inst_fast", i0, i1, c.lr)], (0.9, 0.999), c.weight_decay)
         self.inst_range = (i0, i1)
+        # sync-free capacities were learnt for the previous grid / step size / bounding box: forget them (two synchronising steps again)
+        if hasattr(self, "_caps"):
+            self._caps = {}
 
     def on_train_epoch_start(self):
         """T:447: dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch))."""
@@ -136,12 +147,54 @@ class HotPathTrainer:
     def _allreduce_start(self, rng):
         """Asynchronous form: the collective is queued behind what the current stream holds now and runs beside what is launched next."""
         g = self.model.grad_flat[rng[0]:rng[1]]
-        return g, dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+        if self.allreduce_cu_reserve > 0 and self.device.type == "cuda":
+            _lib.call("clift_set_cu_reserve", self.allreduce_cu_reserve)     # the launches that follow leave CUs to the collective
+        return g, work
 
     def _allreduce_finish(self, started):
         g, work = started
         work.wait()
+        if self.allreduce_cu_reserve > 0 and self.device.type == "cuda":
+            _lib.call("clift_set_cu_reserve", 0)
         g.mul_(1.0 / self.world)
+
+    # ------------------------------------------------------------------ overlap on/off, decided by measurement
+    CAL_WARMUP, CAL_STEPS = 2, 4
+
+    def _overlap_now(self):
+        """Whether THIS main pass overlaps its exchange.  In "auto" mode the first CAL_WARMUP passes are not measured, the next
+        CAL_STEPS run overlapped, the CAL_STEPS after that synchronously (each bracketed by a device synchronisation and timed on the
+        host); the slower rank decides (MAX all-reduce of the medians), every rank takes the same branch afterwards."""
+        if self.overlap_allreduce != "auto":
+            return bool(self.overlap_allreduce)
+        c = self._cal
+        if c["decided"] is not None:
+            return c["decided"]
+        n = len(c["times"][True]) + len(c["times"][False]) + c.get("skipped", 0)
+        return (n - self.CAL_WARMUP) < self.CAL_STEPS
+
+    def _calibration_record(self, overlapped, seconds):
+        c = self._cal
+        if c["decided"] is not None or self.overlap_allreduce != "auto":
+            return
+        if c.get("skipped", 0) < self.CAL_WARMUP:
+            c["skipped"] = c.get("skipped", 0) + 1
+            return
+        c["times"][bool(overlapped)].append(seconds)
+        if len(c["times"][True]) >= self.CAL_STEPS and len(c["times"][False]) >= self.CAL_STEPS:
+            med = lambda v: sorted(v)[len(v) // 2]
+            t = torch.tensor([med(c["times"][True]), med(c["times"][False])], dtype=torch.float64,
+                             device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c["overlap_ms"], c["sync_ms"] = float(t[0]) * 1e3, float(t[1]) * 1e3
+            c["decided"] = bool(t[0] <= t[1])
+
+    @property
+    def overlap_decision(self):
+        """None while undecided / not in auto mode; else dict(overlap=bool, overlap_ms=..., sync_ms=...)."""
+        c = self._cal
+        return None if c["decided"] is None else dict(overlap=c["decided"], overlap_ms=c["overlap_ms"], sync_ms=c["sync_ms"])
 
     # ------------------------------------------------------------------ sync-free capacity bookkeeping
     NOSYNC_WARMUP, NOSYNC_HEADROOM = 2, 1.3
@@ -234,7 +287,12 @@ class HotPathTrainer:
         # Data-parallel runs: the TV term depends on the parameters only, so it goes FIRST (the scatter kernels accumulate on top of it),
         # and once the last chunk's head chains are issued everything but the density tables is final: that range (appearance tables +
         # both MLPs, ~3/4 of the bytes) is all-reduced under the density backward, the density tables after it.
-        early = (self.world > 1 or self.force_collectives) and self.overlap_allreduce and not seg_term
+        dp = self.world > 1 or self.force_collectives
+        calibrating = dp and self.overlap_allreduce == "auto" and self._cal["decided"] is None and self.world > 1 and not seg_term
+        early = dp and self._overlap_now() and not seg_term
+        if calibrating:
+            torch.cuda.synchronize(self.device)
+            t_cal = time.perf_counter()
         started = []
         if early:
             self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
@@ -257,6 +315,9 @@ class HotPathTrainer:
             self._allreduce_finish(started[0])
         else:
             self._allreduce(self.main_range)
+        if calibrating:
+            torch.cuda.synchronize(self.device)
+            self._calibration_record(early, time.perf_counter() - t_cal)
         self.opt_main.step(skip=() if sem_on else ("net_sem",))      # no semantic term yet: the head's grad is None in the reference
         self.last_outputs = (rgb, sem)
         return ctxs

@@ -29,6 +29,10 @@ typedef void* clift_stream_t; /* hipStream_t */
 
 /* ABI version (bumped on any signature change) and last error string of the calling process. */
 int clift_version(void);
+/* Data-parallel runs (reference: DDP buckets overlapped with backward, trainer/__init__.py:93-108): leave k of the 256 CUs to
+ * the collective's kernels while an asynchronous all-reduce is in flight -- the persistent launches (one block per CU, held for the
+ * whole launch) then use 256 - k blocks.  k = 0 restores the default.  Host state; takes effect at the next launch. */
+int clift_set_cu_reserve(int k);
 const char* clift_last_error(void);
 
 /* One VM-decomposed table set (3 planes + 3 lines, equal component count). */

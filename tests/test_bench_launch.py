@@ -1,0 +1,61 @@
+"""bench.py --gpus N must occupy N ranks by itself (the flag was parsed and ignored, so a driver-run
+`python bench.py --gpus 8` produced a 1-rank record).  CPU: the launcher path alone (`--launch-check`: process group over gloo,
+one all-reduce, the line's n_gpus).  GPU: the real bench with two ranks sharing the one device of the test box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_gpus_flag_self_launches_that_many_ranks():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=300, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["requested_gpus"] == 2
+    assert line["allreduce_of_ones"] == 2.0          # both ranks took part in the collective
+
+
+def test_single_rank_needs_no_launcher():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--launch-check"], capture_output=True, text=True, timeout=300,
+                       env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_reports_two():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "1024",
+                        "--inst-rays", "256", "--grid", "64", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                       env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["dist_backend"] in ("gloo", "nccl")
+    assert line["value"] > 0 and line["allreduce_overlap"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_inference_sharded_two_ranks():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--inference-sharded", "--steps", "1", "--warmup", "1",
+                        "--grid", "64"], capture_output=True, text=True, timeout=900, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["rays_per_frame"] == 1296 * 968
+    assert 0 < line["inference_roofline"]["frac"] < 1

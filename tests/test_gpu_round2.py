@@ -631,6 +631,48 @@ def test_sync_free_training_steps_match_synchronising_ones():
         assert float((got[1] - ref[1]).abs().max()) <= 0.5 * 1e-2
 
 
+def test_sync_free_pass_with_a_synchronising_segment_chunk_of_varying_size():
+    """the segment term runs inside the main pass, and its capacity key (pass, n_rays) changes whenever the segment
+    batch changes size -- such a chunk is marched WITHOUT a cap while the library-wide row limit still holds the previous capped chunk's
+    count.  Before the fix its per-sample kernels were silently clamped to that count.  Segment batches of 700 / 1500 / 900 / 1300 rays
+    behind capped main chunks: the segment loss and the semantic-head gradients must equal those of a synchronising trainer."""
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    g = torch.Generator().manual_seed(11)
+    sizes = [900, 1100, 700, 1500, 900, 1300]
+    jit = [torch.rand(512, generator=g).to(DEV) for _ in sizes]           # a SMALL main batch: its capped row count is far below the segment's
+    sjit = [torch.rand(n, generator=g).to(DEV) for n in sizes]
+    runs = {}
+    for nosync in (False, True):
+        model, renderer, pool = synthetic.make_scene(grid=64, num_classes=6, max_instances=3, seed=9, device=DEV, image=128, n_cams=2)
+        cfg = default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0, nosync=nosync, segment_optimization_epoch=0)
+        tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
+        gsel = torch.Generator().manual_seed(3)
+        hist = []
+        for step, n in enumerate(sizes):
+            b = synthetic.make_batches(pool, 512, 256, 6, 9, seed=60 + step, device=DEV)
+            idx = torch.randint(0, pool.shape[0], (n,), generator=gsel).to(DEV)
+            seg = dict(rays=pool[idx].contiguous(), group=torch.randint(0, 5, (n,), generator=gsel).to(DEV),
+                       confidences=torch.rand(n, generator=gsel).to(DEV), n_groups=5)
+            tr.main_pass(b[0], jitter=jit[step], white_bg=False, segments=seg, segment_jitter=sjit[step])
+            gm = {k: v.detach().clone() for k, v in model.named_grad_views().items() if k.startswith("render_semantic")}
+            hist.append((float(tr.loss_segment[0]), gm))
+            if nosync:
+                assert int(engine.rows_limit(torch.device(DEV, torch.cuda.current_device()))[0]) == engine.INT_MAX
+        if nosync:
+            assert tr.overflow_steps == 0
+            assert any(v["cap"] is not None for k, v in tr._caps.items() if k[0] == "main"), "the main chunk never went sync-free"
+        runs[nosync] = hist
+    for step in range(len(sizes)):
+        l0, g0 = runs[False][step]
+        l1, g1 = runs[True][step]
+        if step <= 3:      # later steps: the two runs' parameters differ by accumulation-order round-off of several Adam steps
+            rel_close(l1, l0, 5e-4, what=f"segment loss step {step}")
+        if step == 3:      # sync-free main chunk (capped at ~its own few thousand rows), 1500-ray segment chunk behind it
+            for k in g0:
+                grad_close(g1[k], g0[k], what=f"semantic-head grad {k} with a segment chunk behind a capped chunk", outlier_frac=2e-2, outlier_cap=1e-1)
+
+
 # ============================================================================ appearance table gradients: float4-lane walk vs scalar-lane walk
 @pytest.mark.parametrize("res,N", [((20, 28, 36), 700), ((64, 64, 64), 2048), ((128, 128, 128), 4096)])
 def test_appearance_scatter_four_channel_lanes_match_one_channel_lanes(res, N, monkeypatch):

@@ -63,7 +63,21 @@ def resume_from(path, cfg, tr, model, renderer, dev):
         if ckpt["optimizer_states"][0]["m"].numel() == tr.opt_main.m.numel():
             tr.opt_main.load_state_dict(ckpt["optimizer_states"][0])
             tr.opt_inst.load_state_dict(ckpt["optimizer_states"][1])
-    tr.load_rng_state(extra.get("rng"))
+    # Only rank 0 writes checkpoints, so the RNG record (CPU / device generators, pixel-batch generator) is ITS streams: restoring it on
+    # every rank would make all ranks draw the same pixel batches and jitter from here on (the all-reduced gradient would be that of one
+    # batch).  The other ranks re-seed from (seed, rank, global step): decorrelated from rank 0 and from each other, reproducible.
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0:
+        tr.load_rng_state(extra.get("rng"))
+    else:
+        seed = int(cfg.seed if cfg.seed is not None else 0)
+        mix = (seed * 9973 + rank) * 1000003 + int(ckpt.get("global_step", 0)) + 1
+        torch.manual_seed(mix)
+        if dev.type == "cuda":
+            torch.cuda.manual_seed(mix)
+        g = getattr(tr, "pixel_generator", None)
+        if g is not None:
+            g.manual_seed(mix)
     return first, int(ckpt.get("global_step", 0)), (not complete), int(extra.get("last_setup_epoch", max(done_ups) if done_ups else 0))
 
 
@@ -173,6 +187,7 @@ def main(argv):
                 print(f"epoch {epoch} it {it}/{steps_per_epoch} loss_rgb {l[0]:.5f} (psnr {-10 * math.log10(max(l[0], 1e-12)):.2f}) "
                       f"loss_sem {l[1]:.4f} tv {l[2]:.5f} clustering {l[3]:.4f}"
                       + (f" segment {float(tr.loss_segment[0]):.4f}" if 2 in batch else "")
+                      + (f" overflow_steps {tr.overflow_steps}" if tr.nosync else "")
                       + f" S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
         if rank == 0:
             tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep, epoch_complete=True)
