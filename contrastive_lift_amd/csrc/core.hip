@@ -39,6 +39,7 @@ void clift_bind_rows_limit_gemm(const int* p);
 void clift_bind_rows_limit_layer_f32(const int* p);
 void clift_bind_rows_limit_layer_n128(const int* p);
 void clift_bind_rows_limit_narrow_stream(const int* p);
+void clift_bind_rows_limit_layer_x6(const int* p);
 
 extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_march(dev_limit);
@@ -47,6 +48,7 @@ extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_layer_f32(dev_limit);
     clift_bind_rows_limit_layer_n128(dev_limit);
     clift_bind_rows_limit_narrow_stream(dev_limit);
+    clift_bind_rows_limit_layer_x6(dev_limit);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { clift_set_error("clift_bind_rows_limit: %s", hipGetErrorString(e)); return 2; }
     return 0;

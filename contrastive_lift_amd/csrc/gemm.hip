@@ -238,6 +238,12 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     hipStream_t st = as_stream(s);
     CLIFT_REQUIRE(h->precision >= 0 && h->precision <= 2, "clift_gemm: precision must be 0 (fp32), 1 (bf16 operands) or 2 (fp32x6 split), got %d", h->precision);
     if (h->precision == 1) return clift_gemm_bf16_launch(p, h->a_trans, h->b_trans, splits, st);
+    // fp32x6, the 256 x 256 hidden layers: persistent split kernels (layer_x6.hip), every M (a row's bits must not depend on its launch)
+    if (h->precision == 2 && !h->a_trans && h->N == 256 && h->K == 256 && splits == 1 && !h->accumulate && !h->c_trans && h->lda % 4 == 0 &&
+        h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_X6_TILED") == nullptr &&
+        ((!h->b_trans && !h->mask) ||
+         (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0)))
+        return clift_layer_x6_launch(p, h->b_trans, st);
     // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); everything else (wgrad: both operands streamed) stays exact fp32
     if (h->precision == 2 && !h->a_trans && !h->accumulate && splits == 1 && !h->c_trans && (long)h->N * h->K <= (1L << 22)) {
         const long need = clift_gemm_split_workspace_bytes(h->N, h->K);

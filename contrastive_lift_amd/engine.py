@@ -112,6 +112,11 @@ class _Precision:
         MLP_PRECISION = self.prev
 
 
+def exact_fp32():
+    """Context: matrix-core launches on the exact-fp32 kernels whatever mode is set or forced (tests of the exact kernels' fusions)."""
+    return _Precision(0)
+
+
 # bf16 mode: the 128-wide appearance MLP stays on the exact-fp32 persistent kernels (layer_n128.hip) -- they are FASTER than the tiled
 # bf16 kernels on these short-K layers (fp32 persistent ~0.76 ms vs bf16 tiled ~1.0 ms per step, profiles/r02_bf16_*), and it is the
 # more accurate choice.  The 256-wide xyz heads, where the bf16 streaming / fused kernels pay, run in bf16.
@@ -131,11 +136,21 @@ def act_dtype():
 BF16_STORAGE = os.environ.get("CLIFT_BF16_STORAGE", "1") == "1"
 
 
+# CLIFT_FORCE_MLP_DTYPE=fp32x6 (test switch): every request for the default "fp32" precision is served in that mode instead, so the whole
+# GPU suite can be run with the mode forced on at unchanged tolerances
+_FORCED = os.environ.get("CLIFT_FORCE_MLP_DTYPE", "").lower()
+if _FORCED:
+    MLP_PRECISION = _PRECISIONS[_FORCED]
+
+
 def set_mlp_precision(name):
     """'fp32', 'bf16' or 'fp32x6'; returns the previous setting's name."""
     global MLP_PRECISION
     prev = {0: "fp32", 1: "bf16", 2: "fp32x6"}[MLP_PRECISION]
-    MLP_PRECISION = _PRECISIONS[str(name).lower()]
+    want = _PRECISIONS[str(name).lower()]
+    if want == 0 and _FORCED:
+        want = _PRECISIONS[_FORCED]
+    MLP_PRECISION = want
     return prev
 
 
@@ -155,15 +170,24 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.accumulate, g.split_k = int(accumulate), int(split_k)
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
-    g.precision = MLP_PRECISION
+    # fp32x6 mode: the 256 x 256 hidden layers (forward / dgrad) run as persistent split kernels (csrc/layer_x6.hip); every other
+    # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, weight gradients -- stays on its exact-fp32 persistent kernel,
+    # which is faster than the tiled split kernel the library would pick for it
+    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or (N == 256 and K == 256 and not a_trans and not accumulate and not c_trans)) else 0
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
-    if MLP_PRECISION == 2 and not a_trans and not accumulate and not c_trans:
-        nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)          # split weight planes (stream-ordered scratch)
-        if _lib._launch_stream is not None:       # launched on a side stream (Branches): the allocator must not recycle it earlier
-            ws.record_stream(_lib._launch_stream)
-        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+    if g.precision == 2:
+        # the persistent split kernel takes 16-byte aligned rows; anything else (odd output pitch ...) goes to the library's tiled split
+        # kernel, which needs a workspace for the split weight planes
+        persistent = (int(lda) % 4 == 0 and int(ldc) % 4 == 0 and g.C % 16 == 0 and (mask is None or (int(ldmask) % 4 == 0 and g.mask % 16 == 0))
+                      and ((not b_trans and mask is None) or (b_trans and mask is not None and bias is None and not act))
+                      and not os.environ.get("CLIFT_X6_TILED"))
+        if not persistent:
+            nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)      # split weight planes (stream-ordered scratch)
+            if _lib._launch_stream is not None:   # launched on a side stream (Branches): the allocator must not recycle it earlier
+                ws.record_stream(_lib._launch_stream)
+            g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     call("clift_gemm", C.byref(g), stream())
 
 
@@ -364,7 +388,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         no, ni = W.shape
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
         if (FUSE_OUT_BWD and li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and
-                MLP_PRECISION == 0 and h.dtype == torch.float32 and d.dtype == torch.float32 and dn.dtype == torch.float32):
+                MLP_PRECISION in (0, 2) and h.dtype == torch.float32 and d.dtype == torch.float32 and dn.dtype == torch.float32):
             # output layer: weight gradient and masked input gradient in one pass over the hidden activation
             call("clift_out_layer_bwd", ptr(d), d.shape[1], no, ptr(W), _pitch(W), ptr(h), h.shape[1], M, ptr(dn), ni, ptr(gW), _pitch(gW),
                  ptr(gb), stream())
@@ -445,8 +469,8 @@ def _density_march(model, renderer, rays, jitter, cap=None):
     else:
         # sync-free: buffers and grids are sized by the capacity, the true count stays on the device (rows_limit()[0]) where every
         # per-sample kernel clamps to it; an overflow (count > cap: samples dropped) is recorded in rows_limit()[1] for the caller
-        if MLP_PRECISION != 0:
-            raise _lib.CliftError("sync-free steps (cap=...) are built for the exact-fp32 path only")
+        if MLP_PRECISION == 1:
+            raise _lib.CliftError("sync-free steps (cap=...) are built for the fp32 / fp32x6 paths only")
         lim = rows_limit(dev)
         M = max(int(cap), 1)
         call("clift_scan_counts_capped", ptr(n_active), N, ptr(ray_start), M, ptr(lim), C.c_void_p(lim.data_ptr() + 4), st)
@@ -523,7 +547,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             H1 = torch.empty((M, W1.shape[0]), dtype=hdt, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
-            if (FUSE_LAST2 and MLP_PRECISION == 0 and hdt == torch.float32 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4 and W3.shape[1] == 128
+            if (FUSE_LAST2 and MLP_PRECISION in (0, 2) and hdt == torch.float32 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4 and W3.shape[1] == 128
                     and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # second hidden layer + output layer + sigmoid in one launch; H2 is written only for a backward
                 H2 = torch.empty((M, 128), dtype=torch.float32, device=dev) if "app" in grad_heads else None

@@ -101,7 +101,7 @@ class HotPathTrainer:
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)   # rgb, sem, tv, clustering (last step)
         # sync-free mode: per pass a capacity for the compacted buffers, learnt from the first (synchronising) steps and followed
         # asynchronously afterwards; see _capacity / _follow
-        self.nosync = bool(getattr(config, "nosync", False)) and getattr(config, "mlp_dtype", "fp32") in ("fp32", "f32", None)
+        self.nosync = bool(getattr(config, "nosync", False)) and getattr(config, "mlp_dtype", "fp32") in ("fp32", "f32", "fp32x6", None)
         self._caps = {}
         self.overflow_steps = 0
 

@@ -381,7 +381,8 @@ def test_xyz_head_first_two_layers_fused_is_bit_identical(M):
     h1_ref = torch.empty((M, 256), device=DEV)
     call("clift_linear_k3_fwd", ptr(xa), ptr(W0), 4, ptr(b0), M, 256, 1, ptr(h1_ref), 256, 0, stream())
     h2_ref = torch.empty((M, 256), device=DEV)
-    engine.gemm(M, 256, 256, h1_ref, 256, W1, 256, h2_ref, 256, bias=b1, act=1)
+    with engine.exact_fp32():            # (the fused kernel is the exact-fp32 one: its reference is too, whatever mode is forced)
+        engine.gemm(M, 256, 256, h1_ref, 256, W1, 256, h2_ref, 256, bias=b1, act=1)
     for keep in (True, False):
         h1 = torch.full((M, 256), float("nan"), device=DEV) if keep else None
         h2 = torch.full((M, 256), float("nan"), device=DEV)
@@ -467,7 +468,8 @@ def test_xyz_head_last_two_layers_fused(M, E):
     bo = torch.randn(E, generator=g)
     Ad, Wd, bd, Wod, bod = (t.to(DEV) for t in (A, W, b, Wo, bo))
     h_ref = torch.empty((M, 256), device=DEV)
-    engine.gemm(M, 256, 256, Ad, 256, Wd, 256, h_ref, 256, bias=bd, act=1)
+    with engine.exact_fp32():            # (clift_xyz_head_last2_fwd is the exact-fp32 kernel: so is its reference)
+        engine.gemm(M, 256, 256, Ad, 256, Wd, 256, h_ref, 256, bias=bd, act=1)
     ref = h_ref.double().cpu() @ Wo.double().T + bo.double()
     scale = (h_ref.double().cpu().abs() @ Wo.double().abs().T + bo.double().abs())
     for keep in (True, False):

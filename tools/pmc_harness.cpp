@@ -2,7 +2,7 @@
 // A counter pass serialises every dispatch and re-runs nothing else, so the process under the profiler should do as little as
 // possible: this program allocates the operands of ONE 256x256 hidden-layer launch shape with hipMalloc, fills them with a
 // pseudo-random pattern, and issues `reps` launches of the chosen form through the C ABI.
-//   pmc_harness fwd|dgrad|wgrad|gen|outv M reps     (gen: clift_xyz_head_first2_fwd, activation kept; outv: clift_xyz_head_last2_fwd, E = 3, hidden dropped)
+//   pmc_harness fwd|dgrad|wgrad|gen|outv M reps [precision]     (gen: clift_xyz_head_first2_fwd, activation kept; outv: clift_xyz_head_last2_fwd, E = 3, hidden dropped)
 // Build: hipcc -O2 --offload-arch=gfx950 tools/pmc_harness.cpp -Iinclude -Lcontrastive_lift_amd -lclift -Wl,-rpath,'$ORIGIN/../contrastive_lift_amd' -o tools/pmc_harness.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
     if (!A || !X || !W || !b) { fprintf(stderr, "alloc failed\n"); return 2; }
     const bool gen = !strcmp(mode, "gen"), outv = !strcmp(mode, "outv");
     clift_gemm_t g; memset(&g, 0, sizeof g);
+    const int precision = argc > 4 ? atoi(argv[4]) : 0;          // 2 = fp32x6 (persistent split kernels for the 256 x 256 forward / dgrad)
     if (!strcmp(mode, "fwd")) {
         g.M = M; g.N = 256; g.K = 256; g.A = A; g.lda = 256; g.B = W; g.ldb = 256; g.C = Cc; g.ldc = 256; g.bias = b; g.act = 1; g.split_k = 1;
     } else if (!strcmp(mode, "dgrad")) {
@@ -49,6 +50,7 @@ int main(int argc, char** argv) {
         int sp = (512 + tiles - 1) / tiles; if (sp > (M + 255) / 256) sp = (M + 255) / 256; if (sp < 1) sp = 1;
         g.split_k = sp;
     }
+    g.precision = precision;
     float* x4 = dev_random((size_t)M * 4, 5, 1.0f);
     float* W0 = dev_random(256 * 4, 6, 0.7f);
     float* Wo = dev_random(4 * 256, 7, 0.1f);
