@@ -94,7 +94,7 @@ def appearance_feature(P, xn, explicit=False):
 
 def posenc(x, freqs):
     """tensoRF.py:413-418: [sin(x_0 f_0), sin(x_0 f_1), sin(x_1 f_0), ... , then all cos]."""
-    fb = 2.0 ** torch.arange(freqs, dtype=torch.float32)
+    fb = 2.0 ** torch.arange(freqs, dtype=x.dtype)
     pts = (x[..., None] * fb).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
     return torch.cat([torch.sin(pts), torch.cos(pts)], -1)
 

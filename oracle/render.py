@@ -96,7 +96,7 @@ def _density_weights(P, rays, cfg, jitter, explicit=False):
     pts, z, inbox = sample_along_rays(rays, cfg, jitter)
     dists, mid = _deltas_midpoints(z)
     xn = normalize(pts, cfg)
-    sigma = torch.zeros(pts.shape[:-1])
+    sigma = torch.zeros(pts.shape[:-1], dtype=pts.dtype)          # (dtype follows the inputs: the fp64 runs of tests/test_gpu_round3.py)
     if bool(inbox.any()):
         sigma = sigma.clone()
         sigma[inbox] = fld.density(P, xn[inbox], cfg.density_shift, explicit)
@@ -120,10 +120,10 @@ def render_forward(P, rays, cfg, jitter=None, white_bg=False, explicit=False, re
     dist_reg = dist_loss(w, mid, dists)
     S = z.shape[1]
     C = P[[k for k in P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".weight")][-1]].shape[0]
-    D = fld.instance_mlp(P, torch.zeros(1, 3)).shape[-1]
-    rgb = torch.zeros(N, S, 3)
-    sem = torch.zeros(N, S, C)
-    inst = torch.zeros(N, S, D)
+    D = fld.instance_mlp(P, torch.zeros(1, 3, dtype=z.dtype)).shape[-1]
+    rgb = torch.zeros(N, S, 3, dtype=z.dtype)
+    sem = torch.zeros(N, S, C, dtype=z.dtype)
+    inst = torch.zeros(N, S, D, dtype=z.dtype)
     act = w > cfg.weight_thres
     if bool(act.any()):
         viewdirs = rays[:, None, 3:6].expand(N, S, 3)
@@ -154,8 +154,8 @@ def render_instance_feature(P, rays, cfg, jitter=None, explicit=False):
     with torch.no_grad():
         xn, z, inbox, dists, mid, sigma, alpha, w, bg = _density_weights(P, rays, cfg, jitter, explicit)
     N, S = z.shape
-    D = fld.instance_mlp(P, torch.zeros(1, 3)).shape[-1]
-    inst = torch.zeros(N, S, D)
+    D = fld.instance_mlp(P, torch.zeros(1, 3, dtype=z.dtype)).shape[-1]
+    inst = torch.zeros(N, S, D, dtype=z.dtype)
     act = w > cfg.weight_thres
     if bool(act.any()):
         inst = inst.clone()
