@@ -284,6 +284,7 @@ def main():
             # that the driver-run record carries them: same step definition, 10 steps after 3 warm-up steps / one 262144-ray tile
             extra.update(inference_probe(cl, model, renderer, pool))
             extra.update(bf16_probe(a, dev, batches, S))
+            extra.update(x6_probe(a, dev, batches, S))
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
@@ -414,6 +415,7 @@ def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
             tr.training_step(batches[i % len(batches)], lean=a.lean)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
+        bf16_roof = bf16_roofline_pass(tr, batches, a.lean)
         # frame render in bf16 mode (the xyz heads run as one fused kernel each: csrc/head_bf16.hip)
         from contrastive_lift_amd import inference as inf
         ratio = renderer.step_ratio
@@ -430,7 +432,91 @@ def bf16_probe(a, dev, batches, S, steps=10, warmup=3):
             renderer.update_step_ratio(ratio)
     finally:
         engine.set_mlp_precision(prev)
-    return dict(bf16_ms_per_step=round(dt * 1e3, 3), bf16_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt, bf16_inference_rays_per_s=inf_rate)
+    return dict(bf16_ms_per_step=round(dt * 1e3, 3), bf16_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt, bf16_inference_rays_per_s=inf_rate,
+                bf16_roofline=bf16_roof)
+
+
+def x6_probe(a, dev, batches, S, steps=10, warmup=3):
+    """The same training_step with mlp_dtype "fp32x6": the 256 x 256 hidden layers (forward / dgrad) as fp32-FAITHFUL six-product bf16 splits on
+    the bf16 matrix cores (csrc/layer_x6.hip); every other launch on its exact-fp32 kernel.  Reported beside the exact-fp32 headline."""
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    prev = engine.set_mlp_precision("fp32x6")
+    try:
+        model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+        tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0,
+                                                            mlp_dtype="fp32x6"), current_epoch=4)
+        for i in range(warmup):
+            tr.training_step(batches[i % len(batches)], lean=a.lean)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(steps):
+            tr.training_step(batches[i % len(batches)], lean=a.lean)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+    finally:
+        engine.set_mlp_precision(prev)
+    return dict(fp32x6_ms_per_step=round(dt * 1e3, 3), fp32x6_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt,
+                fp32x6_note="fp32-faithful (6 bf16 products of exactly split operands, fp32 accumulate): outputs / gradients meet the exact path's "
+                            "test tolerances (tests/test_gpu_round3.py, CLIFT_FORCE_MLP_DTYPE=fp32x6 runs of the suite); not the headline")
+
+
+def bf16_roofline_pass(tr, batches, lean, steps=3):
+    """bf16 mode is HBM-bound (bf16 MFMAs run 16x the fp32 rate): per kernel family of the xyz heads, ALGORITHMIC bytes per launch / launch
+    time from HIP events around the launch sites (engine.head_bf16 = the fused whole-head forward, engine.gemm = per-layer forward / dgrad
+    / wgrad launches), over `steps` training steps after the timed ones.  The family with the largest time share is reported as the
+    dominant kernel, against the 8 TB/s peak and the ~6.3 TB/s a pure stream reaches on this chip (MI355X_MICROARCH.md)."""
+    from contrastive_lift_amd import engine
+    real_head, real_gemm = engine.head_bf16, engine.gemm
+    rec = []
+
+    def bracket(kind, nbytes, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        rec.append((kind, nbytes, flops, e0, e1))
+
+    def head(M, xa, l0, l1, l2, lout, h1, h2, h3, out, ldo, col_off):
+        kept = sum(x is not None for x in (h1, h2, h3))
+        nb = M * (16.0 + (4.0 * lout[0].shape[0] if lout is not None else 0.0) + kept * 512.0) + 3 * 256 * 256 * 4.0
+        fl = 2.0 * M * (3 * 256 + 2 * 256 * 256 + (256 * lout[0].shape[0] if lout is not None else 0))
+        return bracket("k_head_bf16_fwd (whole xyz head forward)", nb, fl, lambda: real_head(M, xa, l0, l1, l2, lout, h1, h2, h3, out, ldo, col_off))
+
+    def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, **kw):
+        es = lambda t: float(t.element_size())
+        if kw.get("a_trans"):       # wgrad: both operands streamed over K rows, result (M x N) accumulated
+            kind, nb = "wgrad", K * (M * es(A) + N * es(B)) + M * N * 4.0
+        else:
+            kind = "dgrad" if kw.get("b_trans") else "fwd"
+            nb = M * K * es(A) + M * N * es(Cm) + N * K * es(B) + (M * N * es(kw["mask"]) if kw.get("mask") is not None else 0.0)
+        kind = f"{kind} {N}x{K}" if not kw.get("a_trans") else f"wgrad {M}x{N}"
+        return bracket(kind, nb, 2.0 * M * N * K, lambda: real_gemm(M, N, K, A, lda, B, ldb, Cm, ldc, **kw))
+    engine.head_bf16, engine.gemm = head, gemm
+    try:
+        for i in range(steps):
+            tr.training_step(batches[i % len(batches)], lean=lean)
+        torch.cuda.synchronize()
+    finally:
+        engine.head_bf16, engine.gemm = real_head, real_gemm
+    fam = {}
+    for kind, nb, fl, e0, e1 in rec:
+        f = fam.setdefault(kind, [0.0, 0.0, 0, 0.0])
+        f[0] += nb; f[1] += e0.elapsed_time(e1); f[2] += 1; f[3] += fl
+    if not fam:
+        return None
+    table = {k: {"GBps": v[0] / (v[1] * 1e-3) / 1e9, "tflops": v[3] / (v[1] * 1e-3) / 1e12, "ms_per_step": v[1] / steps,
+                 "launches_per_step": v[2] / steps} for k, v in fam.items() if v[1] > 0}
+    dom = max(table, key=lambda k: table[k]["ms_per_step"])
+    g, tfl = table[dom]["GBps"], table[dom]["tflops"]
+    hbm_frac, mfma_frac = g / PEAK_HBM_GBS, tfl / 2500.0
+    # The fused head forward moves 16 B in / 4 E B out per row (+ 512 B per kept activation): it is NOT a stream -- its ceiling is the bf16
+    # matrix pipe / LDS (every wave re-reads the 64-row tile from LDS); the per-layer launches (activations through HBM) are streams.
+    return {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", "kernel": dom,
+            "achieved": g if hbm_frac >= mfma_frac else tfl, "peak": PEAK_HBM_GBS if hbm_frac >= mfma_frac else 2500.0,
+            "unit": "GB/s" if hbm_frac >= mfma_frac else "TFLOP/s (dense bf16 MFMA)", "frac": max(hbm_frac, mfma_frac),
+            "hbm_GBps": g, "hbm_frac": hbm_frac, "hbm_frac_of_achievable_stream_6300": g / 6300.0, "mfma_tflops": tfl, "mfma_frac": mfma_frac,
+            "families": table,
+            "note": "algorithmic bytes per launch (operands + results as stored: bf16 activations, fp32 weights / narrow tensors) / HIP-event time "
+                    "(events make the step host-bound, so per-launch times are upper bounds)"}
 
 
 def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):

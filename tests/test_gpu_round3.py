@@ -169,7 +169,10 @@ def test_fp32x6_persistent_layers_against_fp64(M):
 
 
 def test_fp32x6_mode_full_forward_backward_vs_oracle():
-    """mlp_dtype fp32x6 through the renderer: outputs 1e-3 relative and every gradient in the band of the exact path's test, C = 22 mid-size."""
+    """mlp_dtype fp32x6 through the renderer, C = 22 mid-size, against the oracle in FLOAT64, next to the exact-fp32 path on the same inputs:
+    outputs 1e-3 relative; per gradient tensor the number of entries outside the band (2e-3 relative + 1e-4 of the scale: these are samples
+    whose hidden unit lands on the other side of a ReLU kink, the kernels' own errors are ~1e-6) is of the exact path's order -- at most
+    2x its count + 0.1 % of the tensor -- and the worst entry within 1e-3 of the scale."""
     cl, op, orender, ofld, olosses, orays = _import()
     from contrastive_lift_amd import engine
     res, C_, E, N = (40, 48, 56), 22, 3, 900
@@ -178,17 +181,101 @@ def test_fp32x6_mode_full_forward_backward_vs_oracle():
     jitter = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
     cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
     o, gref = _oracle_run(op, orender, P, rays, jitter, cots, aabb, res, "softmax", False, dtype=torch.float64)
-    m = build_model(cl, P, res, C_, E, -3.0, "softmax")
-    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
-    prev = engine.set_mlp_precision("fp32x6")
-    try:
-        outs, grads = _run_forward_backward(cl, m, r, rays, jitter, False, cots + [3.0])
-    finally:
-        engine.set_mlp_precision(prev)
+    res_mode = {}
+    for mode in ("fp32", "fp32x6"):
+        m = build_model(cl, P, res, C_, E, -3.0, "softmax")
+        r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+        with engine._Precision(engine._PRECISIONS[mode]):
+            res_mode[mode] = _run_forward_backward(cl, m, r, rays, jitter, False, cots + [3.0])
+    outs, grads = res_mode["fp32x6"]
     for a, b, nm in zip(outs[:4], o[:4], ("rgb", "sem", "inst", "depth")):
         rel_close(a, b.detach(), 1e-3, what=f"fp32x6 {nm}")
+    tot = {"fp32": 0, "fp32x6": 0}
     for k, gr in grads.items():
         got = torch.zeros_like(gref[k]) if gr is None else gr.detach().cpu()
-        grad_close(got, gref[k], what=f"fp32x6 grad {k}", rtol=2e-3, scale_atol=1e-4,
-                   outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-2 if k.startswith("appearance_basis") else 1e-3),
-                   outlier_cap=1e-3)
+        g0 = res_mode["fp32"][1][k]
+        exact = torch.zeros_like(gref[k]) if g0 is None else g0.detach().cpu()
+        n6, w6 = _outliers(got, gref[k])
+        n0, w0 = _outliers(exact, gref[k])
+        tot["fp32"] += n0; tot["fp32x6"] += n6
+        # one hidden unit on the other side of its kink for ONE sample moves one row of the next layer's weight gradient (up to 256 entries):
+        # count the rows the out-of-band entries sit in
+        allow = max(1, int(1e-3 * gref[k].numel()))
+        if n6 > 2 * n0 + allow and gref[k].dim() == 2 and gref[k].shape[1] >= 128:
+            ref = gref[k].double()
+            bad = ((got.double() - ref).abs() > 2e-3 * ref.abs() + 1e-4 * float(ref.abs().max()) + 1e-12)
+            rows_hit = int(bad.any(1).sum())
+            print(f"{k}: {n6} entries outside the band in {rows_hit} row(s) (exact path: {n0})")
+            assert rows_hit <= 2, f"{k}: fp32x6 {n6} entries outside the band spread over {rows_hit} rows (exact {n0})"
+        else:
+            assert n6 <= 2 * n0 + allow, f"{k}: fp32x6 {n6} vs exact {n0} entries outside the band"
+        assert w6 <= max(1e-3, 3 * w0), f"{k}: worst fp32x6 error {w6:.2e} of the scale (exact {w0:.2e})"
+    print("entries outside the band vs the fp64 oracle, all gradients: exact fp32", tot["fp32"], " fp32x6", tot["fp32x6"])
+    assert tot["fp32x6"] <= 2 * tot["fp32"] + 600
+
+
+# ============================================================================ bf16 mode (configs[2]) against the ORACLE at the Messy-Rooms shape
+def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
+    """BASELINE configs[2]: Messy-Rooms class count (C = 2: background / foreground, dataset/many_object_scenes.py:135-141), 25 instance
+    ids, slow-fast contrastive head, bf16 MLP operands.  Sixty full training steps (main pass + instance pass, both optimizers, EMA) from
+    identical weights / batches / jitter through the HIP trainer in bf16 mode and through the fp32 CPU oracle:
+      * rendered rgb / semantics / instance features of the first step within 2e-2 of each tensor's scale (bf16 has 8 significant bits:
+        the 1e-3 of the fp32 path is not expected, SURVEY 7 'bf16 tolerance'),
+      * PSNR on the training rays within 0.1 dB of the oracle's at every checkpoint (north_star), semantic loss within 5 %,
+      * the slow-fast loss within 10 % + 5e-3."""
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from oracle.train_step import CpuTrainer
+    res, C_, E, B, Bi, steps = (32, 32, 32), 2, 3, 768, 512, 60
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    P, rays, rng = scene(op, orays, 73, res, C_, E, B + Bi, amp=2.6, sg=0.4)
+    rays_main, rays_inst = rays[:B].contiguous(), rays[B:].contiguous()
+    d = rays_main[:, 3:6]
+    rgbs = (0.5 + 0.5 * torch.sin(3.0 * d + torch.tensor([0.0, 1.0, 2.0]))).contiguous()
+    fg = torch.sigmoid(6.0 * torch.sin(2.0 * d[:, 0]) * torch.cos(3.0 * d[:, 1]))
+    probs = torch.stack([1 - fg, fg], -1).contiguous()
+    conf = torch.from_numpy(rng.uniform(0.5, 1, B).astype(np.float32))
+    # 25 instance ids laid out on a 5 x 5 grid of ray directions
+    di = rays_inst[:, 3:6]
+    gx = ((di[:, 0] - di[:, 0].min()) / (di[:, 0].max() - di[:, 0].min() + 1e-9) * 4.999).long()
+    gy = ((di[:, 1] - di[:, 1].min()) / (di[:, 1].max() - di[:, 1].min() + 1e-9) * 4.999).long()
+    labels = (1 + gx * 5 + gy).contiguous()
+    assert len(torch.unique(labels)) >= 20
+    iconf = torch.from_numpy(rng.uniform(0.5, 1, Bi).astype(np.float32))
+    m = build_model(cl, P, res, C_, E, -3.0)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    try:
+        tr = HotPathTrainer(m, r, default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype="bf16"), current_epoch=4)
+        assert engine.MLP_PRECISION == 1
+        ct = CpuTrainer(P, orender.RenderCfg(aabb, res, density_shift=-3.0), chunk=4096, epoch=4)
+        batch0 = dict(rays=rays_main.to(DEV), rgbs=rgbs.to(DEV), probabilities=probs.to(DEV), confidences=conf.to(DEV), mask=None)
+        ibatch = [dict(rays=rays_inst.to(DEV), instances=labels.to(DEV), confidences=iconf.to(DEV))]
+        psnr = lambda a, b: float(-10.0 * torch.log10(((a - b) ** 2).mean()))
+        # element-wise agreement of one forward (before any update) with the oracle
+        jit0 = torch.from_numpy(rng.uniform(0, 1, B).astype(np.float32))
+        o = orender.render_forward(op.clone_params(P), rays_main, orender.RenderCfg(aabb, res, density_shift=-3.0), jit0, False)
+        with torch.no_grad():
+            og, _ = engine.render_forward(m, r, rays_main.to(DEV), jit0.to(DEV), False)
+        for nm, a, b in (("rgb", og["rgb"], o[0]), ("semantics", og["semantics"], o[1]), ("instances", og["instances"], o[2])):
+            err = float((a.cpu() - b.detach()).abs().max()) / max(1e-6, float(b.abs().max()))
+            assert err < 2e-2, (nm, err)
+        worst = 0.0
+        for step in range(steps):
+            jit = torch.from_numpy(rng.uniform(0, 1, B).astype(np.float32))
+            jit_i = torch.from_numpy(rng.uniform(0, 1, Bi).astype(np.float32))
+            white = bool(step % 3 == 0)
+            oc = ct.main_pass(rays_main, rgbs, probs, conf, jit, [white])
+            oi = ct.instance_pass(rays_inst, labels, iconf, jit_i)
+            tr.main_pass(batch0, jitter=jit.to(DEV), white_bg=white)
+            tr.instance_pass(ibatch, jitter=jit_i.to(DEV))
+            if step % 10 == 9 or step == steps - 1:
+                p_cpu, p_gpu = psnr(oc["rgb"], rgbs), psnr(tr.last_outputs[0].cpu(), rgbs)
+                worst = max(worst, abs(p_cpu - p_gpu))
+                assert abs(p_cpu - p_gpu) < 0.1, (step, p_cpu, p_gpu)
+                rel_close(tr.losses[1], oc["loss_sem"], 5e-2, what=f"bf16 step {step} loss_sem")
+                rel_close(tr.losses[3], oi["loss"], 1e-1, atol=5e-3, what=f"bf16 step {step} slow-fast loss")
+        assert p_cpu > psnr(torch.full_like(rgbs, 0.5), rgbs) + 1.0
+        print(f"bf16 vs oracle, C = 2 / 25 ids: PSNR after {steps} steps oracle {p_cpu:.3f} dB, HIP bf16 {p_gpu:.3f} dB; worst |delta| {worst:.4f} dB")
+    finally:
+        engine.set_mlp_precision("fp32")
