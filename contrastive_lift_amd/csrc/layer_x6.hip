@@ -86,10 +86,44 @@ static __device__ __forceinline__ void x6_wait_piece(int i) {       // (i is a c
 // range are CLAMPED to its last row on the way in (DMA, mask), so their results are copies of that row's and the store simply writes
 // them to that row again; the first tile "stores" zeros to its own rows, which its real results overwrite later (same wave, same
 // addresses, program order).
-// ABL (timing probes only, results are garbage): 1 = no split / DMA / store work in the loop, 2 = additionally no fragment reads (bare MFMAs)
-template <bool DGRAD, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range, int nranges) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X6_STAGE + X6_ROWS * 1024];     // 128 KB, the only LDS object
+// OUTV (forward only): the layer is the LAST hidden layer of a head with a narrow output (E <= 4: the instance heads, tensoRF.py:480-481) and
+// the output layer out[m][c] = sum_k h[m][k] Wout[c][k] + bout[c] is applied to the tile while it is in registers: 4 x 16 FMAs per lane
+// against register-resident output weights (spread over the MFMA gaps of the following tile), half-waves folded with a permlane swap, the four
+// waves' shares meet in LDS and are summed in a fixed order after the next barrier.  A block owns only 128 of the 256 hidden columns, so
+// its sum is HALF a dot product: the two blocks of a pair add theirs to `out` with one float atomic each -- two addends on a zero-filled
+// target commute, so the result does not depend on their order (the caller zero-fills `out`; bias comes with column half 0).
+// OUTV = 2: the hidden activation itself is not written (no backward through the head) -- the kernel then has no output stream at all,
+// which is worth more than the fused layer: the 255 MB of HBM writes of a plain launch cost ~55 us of its 190 (profiles/r03_x6_notes.txt).
+struct X6Out {
+    const float* Wout;    // (E, 256), row pitch ldwo
+    int ldwo;
+    const float* bout;    // (E), nullable
+    int E;
+    float* out;           // (M, ldo), column offset already applied, zero-filled by the caller
+    int ldo;
+};
+constexpr int X6_PART = X6_RAW + X6_ROWS * 1024;    // OUTV: [tile parity][wave][64] float4 partial sums, 2 x 4 KB
+// vmcnt before the read-back of staged row i with the output layer's atomic (X) at the top of every tile: X D0 D1 D2 D3 D4 S0 D5 S1 D6 S2 D7 S3
+// and, without the hidden stores, X D0 .. D7
+constexpr int X6_VM_OUTV1[8] = {12, 11, 11, 11, 11, 10, 10, 10};
+constexpr int X6_VM_OUTV2[8] = {8, 7, 7, 7, 7, 7, 7, 7};
+
+template <bool DGRAD, int OUTV>
+static __device__ __forceinline__ void x6_wait_piece_v(int i) {
+    if (OUTV == 0) { x6_wait_piece<DGRAD>(i); return; }
+    if (i == 0) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[0]>();
+    if (i == 1) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[1]>();
+    if (i == 2) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[2]>();
+    if (i == 3) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[3]>();
+    if (i == 4) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[4]>();
+    if (i == 5) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[5]>();
+    if (i == 6) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[6]>();
+    if (i == 7) x6_wait_vm<(OUTV == 1 ? X6_VM_OUTV1 : X6_VM_OUTV2)[7]>();
+}
+
+template <bool DGRAD, int OUTV = 0>
+__global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Out op) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * X6_STAGE + X6_ROWS * 1024 + (OUTV ? 8192 : 0)];     // 128 (136) KB, the only LDS object
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: row numbers, DMA bases and the clamps derived from it stay on the SALU
     const int b = blockIdx.x, half = (b >> 3) & 1, range = (b & 7) + 8 * (b >> 4);
@@ -209,9 +243,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
     // The accumulators of a tile are turned into results at the TOP of the next iteration, between the issue of that tile's first fragment
     // reads (behind the barrier) and their use: the ~32 VALU instructions cover the LDS latency that nothing else can (the reads cannot be
     // issued before the barrier), and the last MFMAs of the tile drain meanwhile.  Iteration 0 "finishes" zero accumulators (prev = 0).
-    f32x16 acc0, acc1, accx, accy;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; accx[r] = 0.f; accy[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     f32x4 mk[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     auto finish = [&]() {
         // lane (li, lh) holds row li of the tile, columns ncol + 8 q + 4 lh + (0..3) for q = 0..3: kept for the next tile's loop
@@ -229,6 +263,58 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
         }
     };
     int m_done = prev_m;                                                         // row of the accumulators waiting to be finished
+    // ---- OUTV state: output weights of this lane's 16 columns, its running share of the E dot products, row bookkeeping two tiles deep
+    float wo[4][16];
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+    const unsigned part0 = lds0 + (unsigned)X6_PART;
+    int t_fin = -1;                          // tile whose results are in `prev` (their shares are being summed during the current tile)
+    float bo_c = 0.f;                        // bias of output lane & 3, added by column half 0 only
+    if (OUTV) {
+        if (half == 0 && op.bout && (lane & 3) < op.E) bo_c = op.bout[lane & 3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wo[c][r] = c < op.E ? op.Wout[(size_t)c * op.ldwo + ncol + 8 * (r >> 2) + 4 * lh + (r & 3)] : 0.f;
+    }
+    // two registers of `prev` per call (part p = 0..7 <-> prev[p >> 1] components 2 (p & 1), +1) against the four output rows: 8 FMAs
+    auto outv_fma = [&](int p_) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = 2 * p_ + u;
+            const float h = prev[r >> 2][r & 3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pv[c] = fmaf(h, wo[c][r], pv[c]);
+        }
+    };
+    // fold the two half-waves and park the wave's share in LDS (both halves write: no branch beside the hand-issued memory instructions)
+    auto outv_park = [&](int par) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned u = __float_as_uint(pv[c]);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            pv[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        asm volatile("ds_write_b128 %0, %1" : : "v"(part0 + (unsigned)(par * 4096 + wave * 1024 + lane * 16)), "v"(pv) : "memory");
+        pv = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // lanes (r = (lane >> 2) & 7, c = lane & 3) of wave w: the four waves' shares of row 8 w + r, output c, of tile `tile` (parked with parity par)
+    f32x4 sh;
+    auto outv_fetch = [&](int par) {
+        const unsigned a = part0 + (unsigned)(par * 4096 + (8 * wave + ((lane >> 2) & 7)) * 16 + (lane & 3) * 4);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(sh[0]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(sh[1]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:2048" : "=v"(sh[2]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:3072" : "=v"(sh[3]) : "v"(a) : "memory");
+    };
+    auto outv_add = [&](int tile) {          // fixed order; ONE atomic per (row, output) and block; lanes 32..63 and invalid rows add 0 to a valid address
+        const int c = lane & 3, row = rbeg + tile * X6_ROWS + 8 * wave + ((lane >> 2) & 7);
+        const bool live = tile >= 0 && lane < 32 && c < op.E && row < rend;
+        float v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        v += bo_c;
+        v = live ? v : 0.f;
+        const int rr = min(max(row, rbeg), rend - 1), cc = min(c, op.E - 1);
+        unsafeAtomicAdd(op.out + (size_t)rr * op.ldo + cc, v);
+    };
 
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's plane writes of tile t are done ...
@@ -243,10 +329,16 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
             asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(f[1]) : "v"(a) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(f[2]) : "v"(a) : "memory");
         };
+        if (OUTV) outv_fetch((t + 1) & 1);                                      // parked during tile t - 1: the shares of tile t - 2's rows
         rd(0, fa[0]);
+        if (OUTV) {
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sh) : : "memory");        // (the three fragment reads stay in flight)
+            outv_add(t - 2);
+        }
         finish();                        // the previous tile's results (prev), while the reads are in flight
         prev_m = m_done;
         m_done = m;
+        t_fin = t - 1;
         acc0 = bv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
@@ -259,16 +351,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
             // this step's fragments were issued in gap 0 of the previous step; LDS instructions issued since (tools/x6_vmcnt_model.py):
             // j = 0: none (they were issued just now, behind the barrier); other even steps: one plane write; odd steps: the staging read and two
             // plane writes (step 1: the staging read only)
-            if (j == 0 || ABL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
+            if (j == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
             else if (even || j == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
             else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 0: next step's fragments.  Even: the staged fp32 piece i (DMA'd during tile t - 1) starts its way into registers.
             //      Odd: that piece has had six MFMAs to arrive: wait for it (younger: two plane writes + the three reads just issued), first split
-            if (j + 1 < 16 && ABL < 2) rd(j + 1, fa[(j + 1) & 1]);   // (ABL >= 2: the fragments of step 0 are reused)
-            if (ABL) {
-            } else if (even) {
-                x6_wait_piece<DGRAD>(i);
+            if (j + 1 < 16) rd(j + 1, fa[(j + 1) & 1]);
+            if (even) {
+                x6_wait_piece_v<DGRAD, OUTV>(i);
                 raw_read(i);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");
@@ -276,23 +367,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
                 else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(sp_x) : : "memory");
                 split_a();
             }
-            if (ABL == 3) {      // probe: four independent accumulator chains, bare MFMAs
-                acc0 = x6_mfma(wh[j], f[0], acc0); acc1 = x6_mfma(wh[j], f[1], acc1); accx = x6_mfma(wm[j], f[1], accx); accy = x6_mfma(wm[j], f[0], accy);
-                acc0 = x6_mfma(wh[j], f[2], acc0); acc1 = x6_mfma(wl[j], f[0], acc1);
-                accx = x6_mfma(wl[j], f[1], accx); accy = x6_mfma(wl[j], f[2], accy);      // (8 per step here: 4/3 of the work)
-                continue;
-            }
             acc0 = x6_mfma(wh[j], f[0], acc0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 1
-            if (ABL) {
-            } else if (even) { if (i > 0) split_e(nxt, i - 1); }                        // planes 1 and 2 of the previous piece
+            if (even) { if (i > 0) split_e(nxt, i - 1); }                        // planes 1 and 2 of the previous piece
             else split_b0();
             acc1 = x6_mfma(wh[j], f[1], acc1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 2
-            if (ABL) {
-            } else if (even) {
+            if (even) {
                 if (DGRAD && i < 4) {                                            // the ReLU mask of this tile's rows: four loads, steps 0, 2, 4, 6
                     const float* mp = g.mask + (size_t)m * g.ldmask + ncol + 8 * i + 4 * lh;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[i]) : "v"(mp) : "memory");
@@ -301,15 +384,13 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
             acc0 = x6_mfma(wm[j], f[1], acc0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 3
-            if (ABL) {
-            } else if (even) { if (i > 0) dma_piece(t + 2, i - 1); }                    // the slot consumed one step ago is refilled with tile t + 2's row
+            if (even) { if (i > 0) dma_piece(t + 2, i - 1); }                    // the slot consumed one step ago is refilled with tile t + 2's row
             else split_c(nxt, i);
             acc1 = x6_mfma(wm[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 4
-            if (ABL) {
-            } else if (even) {
-                if (i >= 5) {                                                    // the previous tile's results leave: steps 10, 12, 14 (and 15)
+            if (even) {
+                if (i >= 5 && OUTV != 2) {                                                    // the previous tile's results leave: steps 10, 12, 14 (and 15)
                     const int q = i - 5;
                     *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
                 }
@@ -317,23 +398,50 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
             acc0 = x6_mfma(wh[j], f[2], acc0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 5
-            if (!even && !ABL) {
+            if (even) { if (OUTV) outv_fma(i); }
+            else {
                 if (j < 15) split_d1();
                 else {                                                           // last piece of the tile: everything of it has to be out before the barrier
                     split_e(nxt, 7);
                     dma_piece(t + 2, 7);
-                    *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + ncol + 8 * 3 + 4 * lh) = prev[3];
+                    if (OUTV != 2) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + ncol + 8 * 3 + 4 * lh) = prev[3];
+                    if (OUTV) outv_park(t & 1);                                  // the shares of the rows finished at the top of this tile
                 }
             }
             acc1 = x6_mfma(wl[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (DGRAD && !ABL) asm volatile("s_waitcnt vmcnt(10)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
+        if (DGRAD) asm volatile("s_waitcnt vmcnt(10)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
     }
-    if (ABL == 3) { acc0 += accx; acc1 += accy; }
-    finish();
+    if (!OUTV) {
+        finish();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+        return;
+    }
+    // OUTV drain: the shares of tile ntiles - 2 are parked (parity (ntiles - 1) & 1); the last tile still sits in the accumulators
+    x6_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    outv_fetch((ntiles + 1) & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh) : : "memory");
+    outv_add(ntiles - 2);
+    finish();
+    if (OUTV != 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+    }
+#pragma unroll
+    for (int p_ = 0; p_ < 8; ++p_) outv_fma(p_);
+    outv_park(ntiles & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    outv_fetch(ntiles & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sh) : : "memory");
+    outv_add(ntiles - 1);
+    (void)t_fin;
 }
 
 // Eligibility is decided by the caller (gemm.hip): N = K = 256, plain row-major fp32 A, 16-byte-aligned rows; forward: [n][k] weights,
@@ -345,14 +453,39 @@ int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int rpr = cdiv(cdiv(p.M, nranges), X6_ROWS) * X6_ROWS;
     const int nr = cdiv(p.M, rpr);
     const int grid = 16 * cdiv(nr, 8);                               // block b: half (b >> 3) & 1 of range (b & 7) + 8 (b >> 4)
-    const char* abl = getenv("CLIFT_X6_ABLATE");                       // timing probes (tools/x6_probe.py): wrong results by construction
-    if (abl && !b_trans) {
-        if (abl[0] == '2') k_layer_x6<false, 2><<<grid, 256, 0, st>>>(p, rpr, nr);
-        else if (abl[0] == '3') k_layer_x6<false, 3><<<grid, 256, 0, st>>>(p, rpr, nr);
-        else k_layer_x6<false, 1><<<grid, 256, 0, st>>>(p, rpr, nr);
-        return clift_check_launch("clift_gemm(fp32x6 layer, ablated)");
-    }
-    if (b_trans) k_layer_x6<true><<<grid, 256, 0, st>>>(p, rpr, nr);
-    else k_layer_x6<false><<<grid, 256, 0, st>>>(p, rpr, nr);
+    const X6Out none = {nullptr, 0, nullptr, 0, nullptr, 0};
+    if (b_trans) k_layer_x6<true, 0><<<grid, 256, 0, st>>>(p, rpr, nr, none);
+    else k_layer_x6<false, 0><<<grid, 256, 0, st>>>(p, rpr, nr, none);
     return clift_check_launch("clift_gemm(fp32x6 layer)");
+}
+
+// LAST hidden layer of an xyz head together with its narrow output layer, fp32x6 form of clift_xyz_head_last2_fwd (tensoRF.py:478-481):
+//   h = relu(A W^T + b) (written to `hidden` only if it is non-null), out[:, 0:E] = h Wout^T + bout.
+// `out` columns 0..E-1 of rows 0..M-1 are zero-filled here (stream-ordered) and then receive one atomic add from each of the two blocks that
+// share a row (two addends: order-independent).
+extern "C" int clift_xyz_head_last2_x6_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                           const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(E >= 1 && E <= 4, "clift_xyz_head_last2_x6_fwd: E must be in [1,4] (got %d)", E);
+    CLIFT_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= 256 && ldw >= 256,
+                  "clift_xyz_head_last2_x6_fwd: A / W must be 16-byte aligned with pitches >= 256 that are multiples of 4");
+    CLIFT_REQUIRE(hidden == nullptr || ((((uintptr_t)hidden) & 15) == 0 && ldh % 4 == 0 && ldh >= 256), "clift_xyz_head_last2_x6_fwd: hidden must be 16-byte aligned, pitch >= 256");
+    CLIFT_REQUIRE(ldo >= E, "clift_xyz_head_last2_x6_fwd: ldo < E");
+    hipStream_t st = as_stream(s);
+    if (hipMemset2DAsync(out, (size_t)ldo * sizeof(float), 0, (size_t)E * sizeof(float), (size_t)M, st) != hipSuccess) {
+        clift_set_error("clift_xyz_head_last2_x6_fwd: zero-fill of the output failed");
+        return 2;
+    }
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
+    const int tiles = cdiv(M, X6_ROWS);
+    const int pairs = clift_persistent_cus() / 2;
+    const int nranges = tiles < pairs ? tiles : pairs;
+    const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
+    const int nr = cdiv(M, rpr);
+    const int grid = 16 * cdiv(nr, 8);
+    const X6Out op = {Wout, ldwo, bout, E, out, ldo};
+    if (hidden) k_layer_x6<false, 1><<<grid, 256, 0, st>>>(p, rpr, nr, op);
+    else k_layer_x6<false, 2><<<grid, 256, 0, st>>>(p, rpr, nr, op);
+    return clift_check_launch("clift_xyz_head_last2_x6_fwd");
 }

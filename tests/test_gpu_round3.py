@@ -236,12 +236,18 @@ def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
     fg = torch.sigmoid(6.0 * torch.sin(2.0 * d[:, 0]) * torch.cos(3.0 * d[:, 1]))
     probs = torch.stack([1 - fg, fg], -1).contiguous()
     conf = torch.from_numpy(rng.uniform(0.5, 1, B).astype(np.float32))
-    # 25 instance ids laid out on a 5 x 5 grid of ray directions
+    # 25 instance ids: five equally populated bands along x, each cut into five equally populated bands along y (rank-based, so every id occurs)
     di = rays_inst[:, 3:6]
-    gx = ((di[:, 0] - di[:, 0].min()) / (di[:, 0].max() - di[:, 0].min() + 1e-9) * 4.999).long()
-    gy = ((di[:, 1] - di[:, 1].min()) / (di[:, 1].max() - di[:, 1].min() + 1e-9) * 4.999).long()
-    labels = (1 + gx * 5 + gy).contiguous()
-    assert len(torch.unique(labels)) >= 20
+    order_x = torch.argsort(di[:, 0])
+    band = torch.empty(Bi, dtype=torch.long)
+    band[order_x] = torch.arange(Bi) * 5 // Bi
+    labels = torch.empty(Bi, dtype=torch.long)
+    for bnd in range(5):
+        idx = torch.nonzero(band == bnd).reshape(-1)
+        oy = idx[torch.argsort(di[idx, 1])]
+        labels[oy] = 1 + bnd * 5 + torch.arange(oy.numel()) * 5 // max(1, oy.numel())
+    labels = labels.contiguous()
+    assert len(torch.unique(labels)) == 25
     iconf = torch.from_numpy(rng.uniform(0.5, 1, Bi).astype(np.float32))
     m = build_model(cl, P, res, C_, E, -3.0)
     r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
@@ -279,3 +285,41 @@ def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
         print(f"bf16 vs oracle, C = 2 / 25 ids: PSNR after {steps} steps oracle {p_cpu:.3f} dB, HIP bf16 {p_gpu:.3f} dB; worst |delta| {worst:.4f} dB")
     finally:
         engine.set_mlp_precision("fp32")
+
+
+@pytest.mark.parametrize("M", [1, 31, 33, 65, 4097, 70001])
+@pytest.mark.parametrize("E", [3, 4, 1])
+def test_fp32x6_last_two_layers_fused(M, E):
+    """clift_xyz_head_last2_x6_fwd (csrc/layer_x6.hip, OUTV): last hidden layer on the bf16 matrix cores (six-product split) with the narrow
+    output layer applied to the tile in registers; the two workgroups of a row pair add their halves of the dot products atomically onto
+    the zero-filled output.  Hidden activation bit-identical to the plain fp32x6 launch (same kernel body); outputs against fp64 (2e-6 of
+    sum |h||W| + |b|), with and without writing the hidden activation, strided output with a column offset, neighbours untouched;
+    deterministic (two runs bit-identical: two addends commute)."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M * 7 + E)
+    A = torch.relu(torch.randn((M, 256), generator=g))
+    W = (torch.randn((256, 256), generator=g) / 16).contiguous()
+    b = torch.randn(256, generator=g) * 0.2
+    Wo = (torch.randn((E, 256), generator=g) / 10).contiguous()
+    bo = torch.randn(E, generator=g)
+    Ad, Wd, bd, Wod, bod = (t.to(DEV) for t in (A, W, b, Wo, bo))
+    h_ref = torch.empty((M, 256), device=DEV)
+    with engine._Precision(2):
+        engine.gemm(M, 256, 256, Ad, 256, Wd, 256, h_ref, 256, bias=bd, act=1)
+    h64 = torch.relu(A.double() @ W.double().T + b.double())
+    assert float(((h_ref.double().cpu() - h64).abs() / h64.abs().amax(1, keepdim=True).clamp_min(1e-30)).max()) <= 2e-6
+    ref = h_ref.double().cpu() @ Wo.double().T + bo.double()
+    scale = (h_ref.double().cpu().abs() @ Wo.double().abs().T + bo.double().abs())
+    outs = []
+    for keep in (True, False, False):
+        hid = torch.full((M, 256), float("nan"), device=DEV) if keep else None
+        out = torch.full((M + 1, 6), -7.0, device=DEV)
+        engine.last2_x6(M, Ad, Wd, bd, Wod, bod, hid, out, 6, 1)
+        if keep:
+            assert torch.equal(hid, h_ref)
+        got = out[:M, 1:1 + E].double().cpu()
+        assert float(((got - ref).abs() / scale).max()) <= 2e-6, (M, E, keep)
+        assert bool((out[M:] == -7.0).all()) and bool((out[:, 0] == -7.0).all()) and bool((out[:, 1 + E:] == -7.0).all())
+        outs.append(out.clone())
+    assert torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[0][:M, 1:1 + E], outs[1][:M, 1:1 + E])
