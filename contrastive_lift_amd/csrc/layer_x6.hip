@@ -54,6 +54,12 @@ static __device__ __forceinline__ f32x16 x6_mfma(const u32x4& w, const u32x4& a,
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// (non-temporal output stores, -DX6_NT_STORES: measured SLOWER -- forward 190 -> 217 us, dgrad 200 -> 258 us at 249 k rows; off)
+#ifdef X6_NT_STORES
+#define X6_STORE(ptr, val) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&(val)), reinterpret_cast<f32x4*>(ptr))
+#else
+#define X6_STORE(ptr, val) (*reinterpret_cast<float4*>(ptr) = (val))
+#endif
 constexpr int X6_RAW = 2 * X6_STAGE;                // fp32 staging: wave w owns rows w + 4 i as 1 KB slots (w * 8 + i), 32 KB
 
 // vmcnt before the read-back of staged row i (tools/x6_vmcnt_model.py replays the instruction stream and prints these)
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
             if (even) {
                 if (i >= 5 && OUTV != 2) {                                                    // the previous tile's results leave: steps 10, 12, 14 (and 15)
                     const int q = i - 5;
-                    *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+                    X6_STORE(g.C + (size_t)prev_m * g.ldc + ncol + 8 * q + 4 * lh, prev[q]);
                 }
             } else { split_d0(); if (j == 15) split_d1(); }
             acc0 = x6_mfma(wh[j], f[2], acc0);
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
                 else {                                                           // last piece of the tile: everything of it has to be out before the barrier
                     split_e(nxt, 7);
                     dma_piece(t + 2, 7);
-                    if (OUTV != 2) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + ncol + 8 * 3 + 4 * lh) = prev[3];
+                    if (OUTV != 2) X6_STORE(g.C + (size_t)prev_m * g.ldc + ncol + 8 * 3 + 4 * lh, prev[3]);
                     if (OUTV) outv_park(t & 1);                                  // the shares of the rows finished at the top of this tile
                 }
             }
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
     if (!OUTV) {
         finish();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+        for (int q = 0; q < 4; ++q) X6_STORE(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh, prev[q]);
         return;
     }
     // OUTV drain: the shares of tile ntiles - 2 are parked (parity (ntiles - 1) & 1); the last tile still sits in the accumulators
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_x6(GemmP g, int rows_per_range
     finish();
     if (OUTV != 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh) = prev[q];
+        for (int q = 0; q < 4; ++q) X6_STORE(g.C + (size_t)m_done * g.ldc + ncol + 8 * q + 4 * lh, prev[q]);
     }
 #pragma unroll
     for (int p_ = 0; p_ < 8; ++p_) outv_fma(p_);
