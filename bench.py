@@ -24,7 +24,7 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PMC_RECORD = "profiles/r02_pmc_k_layer_f32.json"
+PMC_RECORD = "profiles/r03_pmc_k_layer_f32.json"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
@@ -581,7 +581,7 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
 
 
 def measured_traffic_ratio():
-    """HBM bytes of the dominant kernel from counters, as a ratio to its algorithmic bytes: profiles/r02_pmc_k_layer_f32.json holds
+    """HBM bytes of the dominant kernel from counters, as a ratio to its algorithmic bytes: profiles/r03_pmc_k_layer_f32.json holds
     the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-byte-per-lane streaming reads on gfx950) over this very command and over the torch-free single-kernel harness."""
     try:
@@ -663,7 +663,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
            # HBM bytes per (average) launch of the dominant kernel: algorithmic bytes of THIS run's average launch (A read once + C
            # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on
-           # the same command (profiles/r02_pmc_k_layer_f32.json); null if that record is missing
+           # the same command (profiles/r03_pmc_k_layer_f32.json); null if that record is missing
            "traffic": (alg_bytes * pmc["bench_ratio"]) if pmc else None,
            "traffic_is": "ESTIMATE = this run's algorithmic bytes x the counter/algorithmic ratio RECORDED in " + PMC_RECORD + " (not re-measured by this run: "
                          "PMC passes need rocprofv3 around the process; tools/gpu_pmc_bench.sh re-records it)",
@@ -671,7 +671,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
            "traffic_algorithmic": alg_bytes,
            "traffic_over_algorithmic": pmc["bench_ratio"] if pmc else None,
            "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE x2, gfx950 correction of MI355X_MICROARCH.md) "
-                              "over `python bench.py --steps 3 --warmup 1`: profiles/r02_pmc_k_layer_f32.json") if pmc else None,
+                              "over `python bench.py --steps 3 --warmup 1`: profiles/r03_pmc_k_layer_f32.json") if pmc else None,
            "mfma_busy_frac_counters": pmc.get("mfma_busy_frac") if pmc else None,
            "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
            "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
