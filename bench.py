@@ -185,7 +185,6 @@ def main():
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
     real_gemm, real_first2, real_last2, real_app_last2 = engine.gemm, engine.first2, engine.last2, engine.app_last2
-    real_last2_x6 = engine.last2_x6
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -223,17 +222,13 @@ def main():
             return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2(M, h, W, b, Wo, *args))
         def recorded_app_last2(M, H1, W2, b2, W3, *args):  # appearance: last hidden layer + output layer + sigmoid (clift_app_head_last2_fwd)
             return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], lambda: real_app_last2(M, H1, W2, b2, W3, *args))
-        def recorded_last2_x6(M, h, W, b, Wo, *args):     # fp32x6 form (clift_xyz_head_last2_x6_fwd)
-            return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2_x6(M, h, W, b, Wo, *args))
         engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
-        engine.last2_x6 = recorded_last2_x6
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
             engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
-            engine.last2_x6 = real_last2_x6
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays
@@ -638,7 +633,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
         gbs = bytes_plain / (plain[1] * 1e-3) / 1e9 if plain[1] > 0 else 0.0
         return {"bound": "mfma", "kernel": "k_layer_x6<false, *> (persistent fp32-faithful split kernel: pair of workgroups per row range, the weights' three "
                                            "bf16 planes in registers, cooperative activation split through LDS-DMA staging, v_mfma_f32_32x32x16_bf16; "
-                                           "plain launches and the form with the narrow output layer applied in-kernel)",
+                                           "eight waves = 4 column groups x 2 k-halves meeting through LDS)",
                 "achieved": bf16_tf, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent 2MNK)", "frac": bf16_tf / 2500.0,
                 "fp32_equivalent_tflops": ach, "fp32_equivalent_vs_exact_fp32_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                 "hbm_GBps_plain_launches": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "traffic": None,

@@ -173,7 +173,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     # fp32x6 mode: the 256 x 256 hidden layers (forward / dgrad) run as persistent split kernels (csrc/layer_x6.hip); every other
     # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, weight gradients -- stays on its exact-fp32 persistent kernel,
     # which is faster than the tiled split kernel the library would pick for it
-    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or (N == 256 and K == 256 and not a_trans and not accumulate and not c_trans)) else 0
+    x6 = N == 256 and K == 256 and not a_trans and not accumulate and not c_trans
+    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6) else 0
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
     if g.precision == 2:
@@ -281,12 +282,6 @@ def last2(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
          C.c_void_p(out.data_ptr() + 4 * col_off), ldo, stream())
 
 
-def last2_x6(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
-    """One clift_xyz_head_last2_x6_fwd launch (fp32x6 mode): as ``last2`` with the hidden layer on the bf16 matrix cores."""
-    call("clift_xyz_head_last2_x6_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), ptr(Wo), _pitch(Wo), ptr(bo), Wo.shape[0], M, ptr(hidden), 256,
-         C.c_void_p(out.data_ptr() + 4 * col_off), ldo, stream())
-
-
 def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
     """One clift_app_head_last2_fwd launch: H2 = relu(H1 W2^T + b2) (written if not None), rgb = sigmoid(H2 W3^T + b3)."""
     call("clift_app_head_last2_fwd", ptr(H1), H1.shape[1], ptr(W2), _pitch(W2), ptr(b2), ptr(W3), _pitch(W3), ptr(b3), W3.shape[0], M,
@@ -357,13 +352,13 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
         acts.append(h)
     Wo, bo = layers[-1]
-    fuse_out = (FUSE_LAST2 and MLP_PRECISION in (0, 2) and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
+    fuse_out = (FUSE_LAST2 and MLP_PRECISION == 0 and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
                 and h.dtype == torch.float32 and out.dtype == torch.float32 and os.environ.get("CLIFT_NO_PERSISTENT") is None)
     for li_, (W, b) in enumerate(rest):
         if fuse_out and li_ == len(rest) - 1:
             # last hidden layer + the narrow output layer in one launch; the hidden activation is written only for a backward
             hn = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
-            (last2_x6 if MLP_PRECISION == 2 else last2)(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
+            last2(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
             acts.append(hn)
             return acts if keep_first else [None]
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)

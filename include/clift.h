@@ -224,11 +224,7 @@ int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const 
  * summation order only. */
 int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
                              const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s);
-/* fp32x6 form of the same fused pair of layers (csrc/layer_x6.hip): the hidden layer as an fp32-faithful six-product bf16 split on the
- * bf16 matrix cores.  out[:, 0:E] of rows 0..M-1 is zero-filled by the call and then receives one float atomic from each of the two
- * workgroups that share a row (two addends: the result does not depend on their order). */
-int clift_xyz_head_last2_x6_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
-                                const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, clift_stream_t s);
+
 /* Last hidden layer of the appearance MLP + its output layer + sigmoid in one launch (tensoRF.py:395-397,410; 128-wide, fp32):
  * h = relu(A W^T + b) (written to `hidden` if non-null), pre = h Wout^T + bout (written if `pre` non-null), out = sigmoid ?
  * 1/(1+exp(-pre)) : pre.  E <= 4.  Deterministic; differs from clift_gemm + clift_rows_act_fwd by summation order only. */

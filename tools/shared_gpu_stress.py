@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Two-processes-on-one-GPU stress: every kernel family of the fp32x6 mode next to an unrelated elementwise kernel (clift_linear_k3_fwd),
+each repeated `iters` times on fixed inputs and compared bit-for-bit with its first result.  Run two instances AT ONCE on one device
+(tests/test_gpu_round3.py does): with the first (four-wave) form of the fp32x6 layer kernel, and with an fp32x6 weight-gradient kernel, the elementwise kernel running
+beside them came back with corrupted lanes 48..63; the kernels that ship pass (profiles/r03_x6_notes.txt).
+usage: tools/shared_gpu_stress.py M tag iters [kernel,kernel,...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from contrastive_lift_amd import engine
+from contrastive_lift_amd._lib import call, ptr, stream
+
+dev = "cuda"
+M, tag, iters = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+g = torch.Generator().manual_seed(1)
+A = torch.relu(torch.randn(M, 256, generator=g)).to(dev)
+W = (torch.randn(256, 256, generator=g) / 16).to(dev)
+b = torch.randn(256, generator=g).to(dev)
+mk = torch.randn(M, 256, generator=g).to(dev)
+dY = torch.randn(M, 256, generator=g).to(dev)
+xa = torch.zeros(M, 4); xa[:, :3] = torch.rand(M, 3, generator=g) * 2 - 1; xa = xa.to(dev)
+W0 = torch.zeros(256, 4); W0[:, :3] = torch.randn(256, 3, generator=g); W0 = W0.to(dev)
+
+
+def k3():
+    h = torch.empty(M, 256, device=dev)
+    call("clift_linear_k3_fwd", ptr(xa), ptr(W0), 4, ptr(b), M, 256, 1, ptr(h), 256, 0, stream())
+    return h
+
+
+def layer(prec, dgrad):
+    with engine._Precision(prec):
+        f = torch.empty(M, 256, device=dev)
+        if dgrad:
+            engine.gemm(M, 256, 256, dY, 256, W, 256, f, 256, b_trans=1, mask=mk, ldmask=256)
+        else:
+            engine.gemm(M, 256, 256, A, 256, W, 256, f, 256, bias=b, act=1)
+    return f
+
+
+A16 = A.to(torch.bfloat16)
+
+
+def bf16_layer():
+    with engine._Precision(1):
+        f = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+        engine.gemm(M, 256, 256, A16, 256, W, 256, f, 256, bias=b, act=1)
+    return f
+
+
+def n128_layer():
+    with engine._Precision(0):
+        f = torch.empty(M, 128, device=dev)
+        engine.gemm(M, 128, 128, A, 256, W, 256, f, 128, bias=b, act=1)
+    return f
+
+
+fns = {"bf16_fwd": bf16_layer, "n128_fwd": n128_layer, "k3": k3, "x6_fwd": lambda: layer(2, False), "x6_dgrad": lambda: layer(2, True), "exact_fwd": lambda: layer(0, False)}
+only = sys.argv[4].split(",") if len(sys.argv) > 4 else list(fns)
+fns = {k: v for k, v in fns.items() if k in only}
+ref = {k: f() for k, f in fns.items()}
+torch.cuda.synchronize()
+bad = {k: 0 for k in fns}
+t0 = time.time()
+for it in range(iters):
+    for k, f in fns.items():
+        r = f()
+        ok = torch.equal(r, ref[k])
+        bad[k] += 0 if ok else 1
+print(f"{tag} {time.time() - t0:.1f}s mismatches of {iters}: {bad}", flush=True)
+sys.exit(1 if any(bad.values()) else 0)
