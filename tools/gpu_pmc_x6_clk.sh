@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Round-3 record: CLIFT_X6_ABLATE selected timing-probe variants of the four-wave kernel that are no longer in the tree; results in
+#  profiles/r03_pmc_x6_clock_with_without_stores.txt.)
 # Cycles vs wall time of the fp32x6 forward kernel with and without its HBM writes (timing probes CLIFT_X6_ABLATE = 6 / 8): is the cost of the
 # output stores cycles (stalls) or clock (power)?
 cd "$GRAFT_REPO_ROOT" || exit 1

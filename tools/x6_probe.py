@@ -57,12 +57,5 @@ for M in [int(x) for x in sys.argv[1:]] or [249000, 62000]:
         os.environ["CLIFT_X6_TILED"] = "1"
         txt = run("fp32x6", lambda: timeit(f))
         del os.environ["CLIFT_X6_TILED"]
-        if name == "fwd":
-            for ab in ("1", "2", "3"):
-                os.environ["CLIFT_X6_ABLATE"] = ab
-                ta = run("fp32x6", lambda: timeit(f))
-                del os.environ["CLIFT_X6_ABLATE"]
-                what = {"1": "MFMAs + fragment reads + barrier", "2": "bare MFMAs + barrier", "3": "bare MFMAs, FOUR chains, 8 per step (4/3 of the MFMAs)"}[ab]
-                print(f"   ablation {ab} ({what}): {ta:7.1f} us")
         print(f"{name} 256x256 M={M}: exact persistent {t32:7.1f} us ({fl/t32/1e6:6.1f} TF)   x6 persistent {tx6:7.1f} us ({fl/tx6/1e6:6.1f} TF-equiv, "
               f"{2*4*M*256/tx6/1e3:5.0f} GB/s)   x6 tiled {txt:7.1f} us")
