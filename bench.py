@@ -184,7 +184,7 @@ def main():
     # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
-    real_gemm, real_first2, real_last2, real_app_last2 = engine.gemm, engine.first2, engine.last2, engine.app_last2
+    real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd = engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -222,13 +222,15 @@ def main():
             return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2(M, h, W, b, Wo, *args))
         def recorded_app_last2(M, H1, W2, b2, W3, *args):  # appearance: last hidden layer + output layer + sigmoid (clift_app_head_last2_fwd)
             return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], lambda: real_app_last2(M, H1, W2, b2, W3, *args))
-        engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
+        def recorded_first2_bwd(M, *args):                 # second layer's masked dgrad + the K = 3 layer's weight gradient (clift_xyz_head_first2_bwd)
+            return bracket("dgrad", M, 256, 256, 2.0 * M * 256 * 4, lambda: real_first2_bwd(M, *args))
+        engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2, recorded_first2_bwd
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
-            engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
+            engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd = real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays
@@ -241,14 +243,17 @@ def main():
         return [(kind, M, N, K, e0.elapsed_time(e1), xf) for kind, M, N, K, e0, e1, xf in recs]
     dom_sel = lambda kind, N: kind in ("fwd", "fwd_gen", "fwd_out") and N > 128
     rec, rec_b = resolve(replay(dom_sel)), resolve(replay(dom_sel))
-    if len(rec) == len(rec_b) and all(x[:4] == y[:4] for x, y in zip(rec, rec_b)):
+    # (same launch = same kind and shape at the same position; the row count may differ by a few samples between replays -- the gradient
+    # atomics are not order-deterministic, so a later step's active-sample count can move by one or two)
+    same = lambda x, y: x[0] == y[0] and x[2:4] == y[2:4] and abs(x[1] - y[1]) <= 0.01 * max(x[1], y[1])
+    if len(rec) == len(rec_b) and all(same(x, y) for x, y in zip(rec, rec_b)):
         rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, rec_b)]
     rec_all = resolve(replay(lambda kind, N: True))
     # every bracket is an UPPER bound of its kernel's time (it also contains any moment the GPU idled between the two records), and the third
     # replay bracketed the same launches once more: keep the shortest of the three per launch (seen once: all OUTV brackets of both dominant
     # passes 3x too long in a run right behind a 20-minute test session -- 0.45 instead of 0.77 -- while the all-launch pass read 111 TFLOP/s)
     sub = [x for x in rec_all if dom_sel(x[0], x[2])]
-    if len(sub) == len(rec) and all(x[:4] == y[:4] for x, y in zip(rec, sub)):
+    if len(sub) == len(rec) and all(same(x, y) for x, y in zip(rec, sub)):
         rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, sub)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
