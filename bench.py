@@ -184,7 +184,8 @@ def main():
     # any other step would see a different launch mix), every clift_gemm launch bracketed by two HIP events on its launch
     # stream (torch's current stream; the side-stream mode is off by default).  Kept out of the timed region because creating
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
-    real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd = engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd
+    real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd, real_first2_wgrad = (engine.gemm, engine.first2, engine.last2, engine.app_last2,
+                                                                                              engine.first2_bwd, engine.first2_wgrad)
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -224,13 +225,17 @@ def main():
             return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], lambda: real_app_last2(M, H1, W2, b2, W3, *args))
         def recorded_first2_bwd(M, *args):                 # second layer's masked dgrad + the K = 3 layer's weight gradient (clift_xyz_head_first2_bwd)
             return bracket("dgrad", M, 256, 256, 2.0 * M * 256 * 4, lambda: real_first2_bwd(M, *args))
-        engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2, recorded_first2_bwd
+        def recorded_first2_wgrad(M, *args):               # second layer's weight gradient over the regenerated first activation (clift_xyz_head_first2_wgrad)
+            return bracket("wgrad", 256, 256, M, 2.0 * M * 256 * 3, lambda: real_first2_wgrad(M, *args))
+        engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
+        engine.first2_bwd, engine.first2_wgrad = recorded_first2_bwd, recorded_first2_wgrad
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
-            engine.gemm, engine.first2, engine.last2, engine.app_last2, engine.first2_bwd = real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd
+            engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
+            engine.first2_bwd, engine.first2_wgrad = real_first2_bwd, real_first2_wgrad
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays

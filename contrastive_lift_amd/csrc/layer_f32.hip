@@ -65,11 +65,33 @@ struct OutP {
 };
 constexpr int LF_OUTV_F4 = 256 + 2 * 8 * 32;  // float4: Wout rows padded to 4 x 256 floats + two buffers of 8 waves x 32 rows of partial sums
 
+// K3W (dgrad only): the layer is the SECOND layer of an xyz head, so its input gradient dH1 = mask . (dH2 W1) has one consumer, the K = 3
+// first layer's weight / bias gradient dW0[n][c] = sum_m dH1[m][n] x[m][c], db0[n] = sum_m dH1[m][n] (tensoRF.py:475,576).  Instead of
+// writing dH1 (1 KB per row) for a second launch to re-read, a finished tile goes into LDS (two 32 KB images, same swizzle as the row
+// stages) and is summed DOWN ITS COLUMNS during the next tile's MFMA loop: thread (n = column, half) reads 16 elements of its column
+// (consecutive lanes = consecutive words: conflict-free) and the 16 positions (broadcast reads; DMA'd per tile into a ring of four 1 KB
+// slots) -- 4 FMAs per element on the VALU, which idles under the MFMAs.  dH1 is never stored.
+// The ReLU mask is not read either: the tile goes into LDS UNmasked, and the thread that sums column n re-derives "h1[m][n] > 0" from the
+// position it is holding anyway -- W0[n] . x_m + b0[n] in the forward's operation order (3 FMAs, the same bits as the activation the
+// forward generated) -- so this form of the kernel has no mask loads, no registers for them, and reads 1 KB per row instead of 2.
+struct K3P {
+    const float* x4;      // (M, 4) normalised sample positions
+    const float* W0;      // (256, 3) first-layer weights, row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+    float* gW0;           // (256, 3) gradient, row pitch ldgw0 (accumulated into)
+    int ldgw0;
+    float* gb0;           // (256) (accumulated into)
+};
+
 // DGRAD = false: weights stored [n][k], bias + optional ReLU.  DGRAD = true: weights stored [k][n], fp32 ReLU mask.
-template <bool DGRAD, bool GEN, bool OUTV>
-__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block, GenP gp, OutP op) {
-    __shared__ __attribute__((aligned(1024))) float4 lds[2 * LF_TILE + (GEN ? LF_XROWS : 0) + (OUTV ? LF_OUTV_F4 : 0)];   // the only LDS object
+template <bool DGRAD, bool GEN, bool OUTV, bool K3W = false>
+__global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_block, GenP gp, OutP op, K3P kp) {
+    static_assert(!K3W || (DGRAD && !GEN && !OUTV), "K3W is a dgrad form");
+    __shared__ __attribute__((aligned(1024))) float4 lds[2 * LF_TILE + (GEN ? LF_XROWS : 0) + (OUTV ? LF_OUTV_F4 : 0) + (K3W ? 2 * LF_TILE + 4 * 64 : 0)];   // the only LDS object
     float4* const xs = lds + 2 * LF_TILE;
+    float4* const kd = lds + 2 * LF_TILE;                                    // K3W: two dH1 tile images ...
+    float4* const kx = kd + 2 * LF_TILE;                                     // ... and four position slots of 64 float4
     float4* const wl4 = lds + 2 * LF_TILE + (GEN ? LF_XROWS : 0);            // OUTV: wl4[c * 64 + k / 4]
     float4* const part = wl4 + 256;                                          // OUTV: part[(tile & 1) * 256 + wave * 32 + row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -162,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         const int q = p_ >> 2, c = p_ & 3;
         const f32x4 wq = wv[p_ & 1];
         pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
+        asm volatile("" : "+v"(pv));               // (pins the arithmetic to its k-step; otherwise it is sunk to the end of the tile and the reads pile up in registers: spills)
     };
     // step 3 (k-step 24): fold the half-waves, park the wave's share of tile `tile` in LDS
     auto outv_park = [&](int tile) {
@@ -193,13 +216,53 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             if (tile >= 0 && c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
         }
     };
+    // ---- K3W state: thread (kn, khalf) sums column kn of a finished dH1 tile over rows 16 khalf .. +15
+    const int kn = (wave & 3) * 64 + lane, khalf = wave >> 2;
+    const unsigned kd0 = (unsigned)(uintptr_t)(lds_ptr_t)kd, kx0 = (unsigned)(uintptr_t)(lds_ptr_t)kx;
+    const unsigned kcol = kd0 + (unsigned)(khalf * 16 * 1024 + ((kn >> 2) << 4) + (kn & 3) * 4);    // row 16 khalf, UNswizzled slot of column kn
+    const unsigned kpos = kx0 + (unsigned)(khalf * 16 * 16);
+    float k3w0 = 0.f, k3w1 = 0.f, k3w2 = 0.f, k3b = 0.f;
+    float kc0 = 0.f, kc1 = 0.f, kc2 = 0.f, kcb = 0.f;                        // first-layer coefficients of column kn
+    if (K3W) { const float* wr0 = kp.W0 + (size_t)kn * kp.ldw0; kc0 = wr0[0]; kc1 = wr0[1]; kc2 = wr0[2]; kcb = kp.b0[kn]; }
+    float kv;             // (one set: the FMAs of element r are issued before the reads of element r + 1 overwrite it)
+    f32x4 kq;
+    auto k3_pos_dma = [&](int t) {                    // positions of tile t -> slot t & 3 (lanes 32..63 repeat rows 0..31 into the slot's second half)
+        if (wave == 0) {
+            const int gr = min(rbeg + t * LF_ROWS + li, rend - 1);
+            __builtin_amdgcn_global_load_lds(kp.x4 + (size_t)gr * 4, (lds_ptr_t)(kx + (t & 3) * 64), 16, 0, 0);
+        }
+    };
+    auto k3_issue = [&](int tile, int r) {            // element (row 16 khalf + r, column kn) of tile `tile` and that row's position
+        unsigned cb = kcol + (unsigned)((tile & 1) * LF_TILE * 16), pb = kpos + (unsigned)((tile & 3) * 1024);
+        asm volatile("" : "+v"(cb), "+v"(pb));       // (opaque: keeps the compiler from hoisting sixteen precomputed address pairs into registers)
+        const unsigned a = (cb ^ (unsigned)(r << 4)) + (unsigned)(r * 1024);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(kv) : "v"(a) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kq) : "v"(pb + (unsigned)(r * 16)) : "memory");
+    };
+    auto k3_fma = [&](int r) {
+        asm volatile("" : "+v"(kv), "+v"(kq) : : "memory");         // (placed after the step's lgkmcnt(0): the values are there)
+        const f32x4 x = kq;
+        const float pre = fmaf(kc2, x.z, fmaf(kc1, x.y, fmaf(kc0, x.x, kcb)));      // same order as the forward (k_linear_k3_fwd / GEN): the sign test sees the forward's bits
+        const float v = pre > 0.f ? kv : 0.f;
+        k3w0 = fmaf(v, x.x, k3w0); k3w1 = fmaf(v, x.y, k3w1); k3w2 = fmaf(v, x.z, k3w2); k3b += v;
+        asm volatile("" : "+v"(k3w0), "+v"(k3w1), "+v"(k3w2), "+v"(k3b));          // (pins the four operations HERE: left alone, the compiler sinks all
+                                                                                // sixteen elements' arithmetic to the end of the tile and keeps 80 registers of reads alive)
+    };
+    if (K3W) {
+        // tile 0's loop sums "tile -1": image 1 and slot 3 start as zeros
+        for (int e = tid; e < LF_TILE; e += 512) kd[LF_TILE + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 256) kx[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        k3_pos_dma(0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_row(0, i);
     for (int t = 0; t < ntiles; ++t) {
+        if (K3W) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's dH1 image writes of tile t-1
         if (!GEN) {
             // DMA of tile t: issued during tile t-1; younger than it: the 4 stores of tile t-2 (forward; the dgrad drained everything at the
             // end of tile t-1 for its mask)
-            if (t >= 2) wait_vmf<4>(); else wait_vmf<0>();
+            if (t >= 2 && !K3W) wait_vmf<4>(); else wait_vmf<0>();           // (K3W: no stores, no mask loads -- the tile's DMAs are all there is)
             __builtin_amdgcn_s_barrier();                                    // everyone's rows have landed; everyone is done with the other stage
             asm volatile("" ::: "memory");
         } else {
@@ -237,7 +300,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0) : : "memory");
             if (j + 1 < 32) rd(j + 1, fa[(j + 1) & 1]);
             if (j < 8 && (j & 1) == 0) { if (more) dma_row(t + 1, j >> 1); }
-            if (j >= 8 && j < 16 && (j & 1) == 0 && (!OUTV || op.store_hidden)) {
+            if (K3W) {
+                // column sums of tile t-1 (image (t-1) & 1, slot (t-1) & 3; zeros for t = 0): element r is read at k-step r, used at r + 1 -- done
+                // before the mask loads of this tile take their registers
+                if (j == 7 && more) k3_pos_dma(t + 1);
+                if (j >= 1 && j < 17) k3_fma(j - 1);
+                if (j < 16) k3_issue(t + 3, j);
+            }
+            if (!K3W && j >= 8 && j < 16 && (j & 1) == 0 && (!OUTV || op.store_hidden)) {
                 const int q = (j - 8) >> 1;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
             }
@@ -251,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
                 if (j == 26) outv_fetch(t - 2);
                 if (j == 28) outv_store(t - 2);
             }
-            if (DGRAD && j >= 16 && j < 24 && (j & 1) == 0) {
+            if (DGRAD && !K3W && j >= 16 && j < 24 && (j & 1) == 0) {
                 const int q = (j - 16) >> 1;
                 const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh + 8 * q;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[q]) : "v"(mp) : "memory");
@@ -263,21 +333,50 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, c0.w, acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);          // ... and this step's MFMAs ahead of the next step's wait
         }
-        if (DGRAD) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
+        if (DGRAD && !K3W) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
         // lane (li, lh) holds row li of the tile, columns 32 wave + 8 q + 4 lh + (0..3) for q = 0..3: kept for the next tile's loop
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 o = make_float4(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1],
                                    acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]);
-            if (DGRAD) {
+            if (DGRAD && !K3W) {
                 o.x = mk[q].x > 0.f ? o.x : 0.f; o.y = mk[q].y > 0.f ? o.y : 0.f;
                 o.z = mk[q].z > 0.f ? o.z : 0.f; o.w = mk[q].w > 0.f ? o.w : 0.f;
             } else if (g.act == 1) {
                 o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
             }
-            prev[q] = o;
+            if (K3W) {                               // into the tile's LDS image instead of memory; rows past the range count for nothing
+                if (m >= rend) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                const f32x4 ov = {o.x, o.y, o.z, o.w};
+                asm volatile("ds_write_b128 %0, %1" : : "v"(kd0 + (unsigned)((t & 1) * LF_TILE * 16 + li * 1024 + (((8 * wave + 2 * q + lh) ^ (li & 15)) << 4))), "v"(ov) : "memory");
+            } else {
+                prev[q] = o;
+            }
         }
         prev_m = m;
+    }
+    if (K3W) {
+        // the last tile's column sums, the two row halves of a column folded through LDS, one atomic per gradient entry and block
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            k3_issue(ntiles - 1, r);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            k3_fma(r);
+        }
+        if (khalf == 1) lds[kn] = make_float4(k3w0, k3w1, k3w2, k3b);        // (the row stages are idle: every wave is past its last MFMA loop)
+        __syncthreads();
+        if (khalf == 0) {
+            const float4 o = lds[kn];
+            float* gw = kp.gW0 + (size_t)kn * kp.ldgw0;
+            unsafeAtomicAdd(gw + 0, k3w0 + o.x);
+            unsafeAtomicAdd(gw + 1, k3w1 + o.y);
+            unsafeAtomicAdd(gw + 2, k3w2 + o.z);
+            unsafeAtomicAdd(kp.gb0 + kn, k3b + o.w);
+        }
+        return;
     }
     if (prev_m < rend && (!OUTV || op.store_hidden)) {
 #pragma unroll
@@ -310,8 +409,8 @@ int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int rpb = cdiv(cdiv(p.M, blocks), LF_ROWS) * LF_ROWS;
     const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
-    if (b_trans) k_layer_f32<true, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out);
-    else k_layer_f32<false, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out);
+    if (b_trans) k_layer_f32<true, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out, K3P{nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr});
+    else k_layer_f32<false, false, false><<<cdiv(p.M, rpb), 512, 0, st>>>(p, rpb, none, no_out, K3P{nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_gemm(fp32 layer)");
 }
 
@@ -331,7 +430,7 @@ extern "C" int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W,
     const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
     const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
     const OutP op = {Wout, ldwo, bout, E, out, ldo, hidden != nullptr ? 1 : 0};
-    k_layer_f32<false, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, none, op);
+    k_layer_f32<false, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, none, op, K3P{nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_xyz_head_last2_fwd");
 }
 
@@ -351,8 +450,31 @@ extern "C" int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int l
     const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
     const GenP gp = {x4, W0, ldw0, b0, h1, ldh1};
     const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
-    k_layer_f32<false, true, false><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, gp, no_out);
+    k_layer_f32<false, true, false><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, gp, no_out, K3P{nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_xyz_head_first2_fwd");
+}
+
+// Backward of the first TWO layers of an xyz head in one launch (the forward is clift_xyz_head_first2_fwd): with dH2 (M, ldd) the gradient
+// at the second layer's output (already masked by its ReLU), dH1 = (W0 x + b0 > 0) . (dH2 W1) is formed tile by tile and consumed on the spot:
+//   gW0[n][0..2] += sum_m dH1[m][n] x4[m][0..2],   gb0[n] += sum_m dH1[m][n]          (tensoRF.py:475-476, 576-577)
+// dH1 is never written and the first layer's activation is not read (its sign is re-derived from the positions).  (The second layer's own
+// weight gradient, dH2^T h1, stays a clift_gemm call.)
+extern "C" int clift_xyz_head_first2_bwd(const float* dH2, int ldd, const float* W1, int ldw1, const float* W0, int ldw0, const float* b0, const float* x4,
+                                         int M, float* gW0, int ldgw0, float* gb0, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)dH2) & 15) == 0 && (((uintptr_t)x4) & 15) == 0 && ldd % 4 == 0 && ldd >= 256 && ldw1 >= 256,
+                  "clift_xyz_head_first2_bwd: dH2 / x4 must be 16-byte aligned, dH2's pitch >= 256 and a multiple of 4, W1's pitch >= 256");
+    CLIFT_REQUIRE(W0 != nullptr && b0 != nullptr && ldw0 >= 3 && gW0 != nullptr && gb0 != nullptr && ldgw0 >= 3,
+                  "clift_xyz_head_first2_bwd: W0 / gW0 (256 x 3, pitch >= 3) and b0 / gb0 (256) are required");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = dH2; p.lda = ldd; p.B = W1; p.ldb = ldw1; p.C = nullptr; p.ldc = 256;
+    const int tiles = cdiv(M, LF_ROWS);
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
+    const int rpb = cdiv(cdiv(M, blocks), LF_ROWS) * LF_ROWS;
+    const GenP none = {nullptr, nullptr, 0, nullptr, nullptr, 0};
+    const OutP no_out = {nullptr, 0, nullptr, 0, nullptr, 0, 1};
+    k_layer_f32<true, false, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, none, no_out, K3P{x4, W0, ldw0, b0, gW0, ldgw0, gb0});
+    return clift_check_launch("clift_xyz_head_first2_bwd");
 }
 
 // ============================================================================ weight gradient of the same layers, persistent

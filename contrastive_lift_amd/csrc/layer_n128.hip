@@ -298,13 +298,27 @@ extern "C" int clift_app_head_last2_fwd(const float* A, int lda, const float* W,
 // MFMAs per wave between barriers; per step a lane reads one dY and one X element per tile (row-contiguous ds_read_b32, conflict-free
 // in a lane-linear image).  The block ends with ONE 128 x K partial added to gW (20 k atomics per block instead of the 64 k of a
 // split-K tile launch).  The tiled split-K launch it replaces ran at ~50 TFLOP/s on these shapes.
-template <int KXC>
-__global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_per_range, int quads) {
+// GENX (256 x 256 quadrant form only): X is the FIRST layer's activation of an xyz head, X[m][k] = relu(W0[k] . x_m + b0[k]) with K = 3
+// (tensoRF.py:475,576) -- the weight gradient of the head's second layer.  Instead of streaming it (1 KB per row, written by the forward for
+// this purpose alone) a wave GENERATES the four 1 KB pieces of the X tile it would have DMA'd: a lane owns four columns of its quadrant
+// (12 weights + 4 biases in registers) and two rows per piece, whose positions come from a ring of four 1 KB slots filled by LDS-DMA two
+// tiles ahead; 13 VALU instructions + one ds_write_b128 per piece, placed where the DMA instructions were.  Same operation order as the
+// forward, so the generated values are the forward's bits.
+struct GenX {
+    const float* x4;      // (rows, 4) normalised sample positions
+    const float* W0;      // (256, 3), row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+};
+
+template <int KXC, bool GENX = false>
+__global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_per_range, int quads, GenX gx) {
+    static_assert(!GENX || KXC == 32, "GENX is the 256 x 256 quadrant form");
     constexpr int ROWS = 64;
     constexpr int YB = ROWS * 512, XB = ROWS * KXC * 16, STAGE = YB + XB;     // bytes
     constexpr int NT = (KXC == 40) ? 3 : 2;                                   // accumulator tiles per wave (KXC = 40: 3 + 2 over the two wk)
     constexpr int NDX = KXC / 8;                                              // X DMA instructions per wave per tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE + (GENX ? 4 * 1024 : 0)];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wn = wave & 3, wk = wave >> 2;
     const int tile0 = (KXC == 40) ? 3 * wk : 2 * wk;                          // first X column tile of this wave
@@ -341,7 +355,41 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     };
     auto dma = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 4 + NDX; ++i) dma_piece(t, i);
+        for (int i = 0; i < (GENX ? 4 : 4 + NDX); ++i) dma_piece(t, i);
+    };
+    // ---- GENX: this lane's first-layer coefficients (columns 128 (quad & 1) + 4 (lane & 31) .. +3) and the position ring
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    float gw0[4] = {0.f, 0.f, 0.f, 0.f}, gw1[4] = {0.f, 0.f, 0.f, 0.f}, gw2[4] = {0.f, 0.f, 0.f, 0.f}, gbb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (GENX) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = 128 * (quad & 1) + 4 * (lane & 31) + e;
+            const float* wr0 = gx.W0 + (size_t)col * gx.ldw0;
+            gw0[e] = wr0[0]; gw1[e] = wr0[1]; gw2[e] = wr0[2]; gbb[e] = gx.b0[col];
+        }
+    }
+    const unsigned gpos0 = (unsigned)(uintptr_t)(lds_ptr_t)(lds + 2 * STAGE);
+    auto pos_dma = [&](int t) {                       // positions of the 64 rows of tile t -> slot t & 3 (one wave instruction)
+        if (wave == 0) {
+            const int gr = min(rbeg + t * ROWS + lane, rend - 1);
+            __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)gr * 4, (lds_ptr_t)(lds + 2 * STAGE + (t & 3) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 gpv;                                        // position of the row this lane generates next
+    auto gen_read = [&](int t, int j) {               // piece j of tile t covers rows 2 (4 wave + j) + lh
+        unsigned a = gpos0 + (unsigned)((t & 3) * 1024 + (2 * (4 * wave + j) + lh) * 16);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(gpv) : "v"(a) : "memory");
+    };
+    auto gen_write = [&](int t, int j) {              // (after an lgkmcnt(0) that covers gen_read)
+        asm volatile("" : "+v"(gpv) : : "memory");
+        const f32x4 x = gpv;
+        f32x4 o;
+        o.x = fmaxf(fmaf(gw2[0], x.z, fmaf(gw1[0], x.y, fmaf(gw0[0], x.x, gbb[0]))), 0.f);      // same order as k_linear_k3_fwd
+        o.y = fmaxf(fmaf(gw2[1], x.z, fmaf(gw1[1], x.y, fmaf(gw0[1], x.x, gbb[1]))), 0.f);
+        o.z = fmaxf(fmaf(gw2[2], x.z, fmaf(gw1[2], x.y, fmaf(gw0[2], x.x, gbb[2]))), 0.f);
+        o.w = fmaxf(fmaf(gw2[3], x.z, fmaf(gw1[3], x.y, fmaf(gw0[3], x.x, gbb[3]))), 0.f);
+        const unsigned a = gpos0 - (unsigned)(2 * STAGE) + (unsigned)((t & 1) * STAGE + YB + 1024 * (4 * wave + j) + lane * 16);
+        asm volatile("ds_write_b128 %0, %1" : : "v"(a), "v"(o) : "memory");
     };
     f32x16 acc[NT];
 #pragma unroll
@@ -354,8 +402,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     const unsigned yoff = (unsigned)(lh * 512 + (32 * wn + li) * 4);                           // dY element (row lh, column 32 wn + li)
     const unsigned xoff = (unsigned)(YB + lh * KXC * 16 + (32 * tile0 + li) * 4);              // X element (row lh, column 32 tile0 + li)
 
+    if (GENX) {                                      // positions of tiles 0 and 1, then X of tile 0
+        pos_dma(0);
+        if (ntiles > 1) pos_dma(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gen_read(0, j);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gen_write(0, j);
+        }
+    }
     dma(0);
     for (int t = 0; t < ntiles; ++t) {
+        if (GENX) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's generated pieces of tile t are written
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile t has landed (issued a whole tile ago)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -391,9 +453,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
             if (grp + 1 < ROWS / 8) rd(grp + 1, set ^ 1);
             // the next tile's DMA pieces are spread over the groups of this tile (eight waves issuing 8-9 of them at the same moment right
             // after the barrier stall the vector-memory issue path with the MFMA pipe idle -- the effect measured in layer_f32.hip)
-            if (more) {
+            if (more && !GENX) {
                 if (grp < 4 + NDX) dma_piece(t + 1, grp);
                 if (grp == 0 && 4 + NDX > ROWS / 8) dma_piece(t + 1, ROWS / 8);
+            }
+            if (more && GENX) {
+                // dY pieces at groups 0..3; X of tile t+1 generated at groups 4..7 (its positions landed a tile ago: read at group j + 3, behind
+                // this group's lgkmcnt(0) at group j + 4); the positions of tile t+2 leave at group 0 (a whole tile to land)
+                if (grp < 4) dma_piece(t + 1, grp);
+                if (grp >= 4) gen_write(t + 1, grp - 4);
+                if (grp >= 3 && grp < 7) gen_read(t + 1, grp - 3);
+                if (grp == 0 && t + 2 < ntiles) pos_dma(t + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -430,8 +500,23 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
 // The 256 x 256 weight gradient as four 128 x 128 quadrants of the same kernel (64 row ranges x 4 quadrant-blocks = 256 blocks).
 int clift_wgrad_f32_quads_launch(const GemmP& p, hipStream_t st) {
     const int rpr = cdiv(cdiv(p.K, 64), 64) * 64;
-    k_wgrad_n128_stream<32><<<256, 512, 0, st>>>(p, rpr, 4);
+    k_wgrad_n128_stream<32><<<256, 512, 0, st>>>(p, rpr, 4, GenX{nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_gemm(fp32 wgrad quadrants)");
+}
+
+// Weight / bias gradient of the SECOND layer of an xyz head with the first layer's activation generated in-kernel (GENX above):
+//   gW1[n][k] += sum_m dH2[m][n] relu(W0[k] . x4[m] + b0[k]),   gb1[n] += sum_m dH2[m][n]        (tensoRF.py:476-478, 577-579)
+extern "C" int clift_xyz_head_first2_wgrad(const float* dH2, int ldd, const float* W0, int ldw0, const float* b0, const float* x4, int M,
+                                           float* gW1, int ldgw1, float* gb1, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)dH2) & 15) == 0 && (((uintptr_t)x4) & 15) == 0 && ldd % 4 == 0 && ldd >= 256 && ldgw1 >= 256 && ldw0 >= 3,
+                  "clift_xyz_head_first2_wgrad: dH2 / x4 must be 16-byte aligned, dH2's pitch >= 256 and a multiple of 4, gW1's pitch >= 256");
+    CLIFT_REQUIRE(W0 != nullptr && b0 != nullptr && gW1 != nullptr, "clift_xyz_head_first2_wgrad: W0, b0 and gW1 are required");
+    GemmP p = {};
+    p.M = 256; p.N = 256; p.K = M; p.A = dH2; p.lda = ldd; p.B = nullptr; p.ldb = 256; p.C = gW1; p.ldc = ldgw1; p.accumulate = 1; p.colsum = gb1;
+    const int rpr = cdiv(cdiv(M, 64), 64) * 64;
+    k_wgrad_n128_stream<32, true><<<256, 512, 0, as_stream(s)>>>(p, rpr, 4, GenX{x4, W0, ldw0, b0});
+    return clift_check_launch("clift_xyz_head_first2_wgrad");
 }
 
 // Eligibility decided by the caller (gemm.hip): wgrad form (a_trans, b_trans, accumulate) with a 128 x N result, N in {128, 160} (N <= ldb:
@@ -439,7 +524,7 @@ int clift_wgrad_f32_quads_launch(const GemmP& p, hipStream_t st) {
 int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st) {
     const int rpr = cdiv(cdiv(p.K, 256), 64) * 64;
     const dim3 grid(cdiv(p.K, rpr));
-    if (p.N > 128) k_wgrad_n128_stream<40><<<grid, 512, 0, st>>>(p, rpr, 1);
-    else k_wgrad_n128_stream<32><<<grid, 512, 0, st>>>(p, rpr, 1);
+    if (p.N > 128) k_wgrad_n128_stream<40><<<grid, 512, 0, st>>>(p, rpr, 1, GenX{nullptr, nullptr, 0, nullptr});
+    else k_wgrad_n128_stream<32><<<grid, 512, 0, st>>>(p, rpr, 1, GenX{nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_gemm(fp32 128-wide wgrad stream)");
 }

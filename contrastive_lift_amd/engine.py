@@ -314,6 +314,25 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
     call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h1), 256, ptr(h2), 256, stream())
 
 
+# backward: the second layer's input gradient is consumed inside its kernel by the K = 3 first layer's weight / bias gradient (never written)
+FUSE_FIRST2_BWD = os.environ.get("CLIFT_FUSE_FIRST2_BWD", "1") != "0"
+# ... and the forward then does not write the first layer's activation at all: the second layer's weight gradient regenerates it as well
+# ("0": the forward keeps it and that weight gradient streams it -- 14 us faster per 249 k-row launch, 255 MB more per head)
+DROP_FIRST_ACT = os.environ.get("CLIFT_DROP_FIRST_ACT", "1") != "0"
+
+
+def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
+    """One clift_xyz_head_first2_bwd launch: gW0 += ((W0 x + b0 > 0) . (d W1))^T xa[:, :3], gb0 += column sums of the same masked gradient.
+    (Module-level for the same reason as first2.)"""
+    call("clift_xyz_head_first2_bwd", ptr(d), d.shape[1], ptr(W1), _pitch(W1), ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW0), _pitch(gW0), ptr(gb0),
+         stream())
+
+
+def first2_wgrad(M, d, W0, b0, xa, gW1, gb1):
+    """One clift_xyz_head_first2_wgrad launch: gW1 += d^T relu(xa[:, :3] W0^T + b0), gb1 += column sums of d."""
+    call("clift_xyz_head_first2_wgrad", ptr(d), d.shape[1], ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW1), _pitch(gW1), ptr(gb1), stream())
+
+
 def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
     """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
     activation) into out[:, col_off:col_off+n_out] with row pitch ldo.
@@ -342,7 +361,9 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
     elif (FUSE_FIRST2 and MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
             and os.environ.get("CLIFT_NO_PERSISTENT") is None):
         W1, b1 = layers[1]
-        h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
+        # (with the fused backward the first layer's activation has no reader: both of its uses -- the ReLU mask of the second layer's input
+        # gradient and the second layer's weight gradient -- re-derive it from the positions, so it is never written)
+        h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if (keep_first and not (FUSE_FIRST2_BWD and DROP_FIRST_ACT)) else None
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
         first2(M, xa, W0, b0, W1, b1, h1, h)
         acts += [h1, h]
@@ -378,7 +399,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
     dev = xa.device
     d = dpre
     n = len(layers)
-    if acts[0] is None:
+    if acts[0] is None and len(acts) != n - 1:
         raise _lib.CliftError("backward through an xyz head whose forward ran with keep_first=False (head not named in grad_heads)")
     keep = keep if keep is not None else []
     keep.append(d)
@@ -387,6 +408,17 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         gW, gb = glayers[li]
         h = acts[li - 1]
         no, ni = W.shape
+        if li == 1 and (h is None or (FUSE_FIRST2_BWD and MLP_PRECISION == 0 and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and
+                                      d.dtype == torch.float32 and h.dtype == torch.float32 and d.shape[1] % 4 == 0 and
+                                      os.environ.get("CLIFT_NO_PERSISTENT") is None)):
+            # second layer: its weight gradient (over the first layer's activation -- regenerated from the positions when the forward did not keep
+            # it), then its input gradient formed and consumed by the first layer's weight gradient in one launch
+            if h is None:
+                first2_wgrad(M, d, layers[0][0], layers[0][1], xa, gW, gb)
+            else:
+                wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
+            first2_bwd(M, d, W, layers[0][0], layers[0][1], xa, *glayers[0])
+            return
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
         if (FUSE_OUT_BWD and li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and
                 MLP_PRECISION in (0, 2) and h.dtype == torch.float32 and d.dtype == torch.float32 and dn.dtype == torch.float32):

@@ -217,6 +217,23 @@ int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b
  * activation when a backward pass will need it.  Results are bit-identical to clift_linear_k3_fwd followed by clift_gemm. */
 int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
                               const float* b1, int M, float* h1, int ldh1, float* h2, int ldh2, clift_stream_t s);
+/* Backward of the first TWO layers of an xyz head in one launch (tensoRF.py:475-478, 576-579; fp32, ABI 11).  dH2 (M, ldd) is the
+ * gradient at the second layer's output, already masked by that layer's ReLU; W0 (256, 3) / b0 the first layer; x4 (M, 4) the sample
+ * positions.  The second layer's input gradient dH1 = (W0 x + b0 > 0) . (dH2 W1) is formed tile by tile and consumed in place:
+ *   gW0[n][0..2] += sum_m dH1[m][n] x4[m][0..2],   gb0[n] += sum_m dH1[m][n]
+ * -- dH1 (1 KB per row) is never written, and the first layer's activation is not read: its sign is re-derived from the positions in the
+ * forward's operation order (the same bits clift_linear_k3_fwd / clift_xyz_head_first2_fwd produced).  Replaces clift_gemm(b_trans, mask)
+ * + clift_linear_k3_bwd; results differ from that pair by summation order only (both accumulate per-block partial sums with fp32
+ * atomics).  The second layer's own weight gradient stays a clift_gemm call. */
+int clift_xyz_head_first2_bwd(const float* dH2, int ldd, const float* W1, int ldw1, const float* W0, int ldw0, const float* b0,
+                              const float* x4, int M, float* gW0, int ldgw0, float* gb0, clift_stream_t s);
+/* Weight / bias gradient of the SECOND layer of an xyz head with its input -- the first layer's activation -- generated in-kernel from
+ * the positions (ABI 11):  gW1[n][k] += sum_m dH2[m][n] relu(W0[k] . x4[m] + b0[k]),  gb1[n] += sum_m dH2[m][n]  (gb1 nullable).
+ * With clift_xyz_head_first2_bwd this makes the first layer's activation (1 KB per sample) unnecessary for the backward: the forward
+ * (clift_xyz_head_first2_fwd with h1 = NULL) never writes it.  Same bits as clift_gemm's weight gradient over the stored activation up
+ * to the summation order of the per-block partial sums. */
+int clift_xyz_head_first2_wgrad(const float* dH2, int ldd, const float* W0, int ldw0, const float* b0, const float* x4, int M,
+                                float* gW1, int ldgw1, float* gb1, clift_stream_t s);
 /* LAST hidden layer of an xyz head together with its narrow output layer (E <= 4 outputs: the instance heads,
  * tensoRF.py:478-481): h = relu(A W^T + b), out[:, 0:E] = h Wout^T + bout, in one launch -- the output layer is applied to the
  * tile while it is in registers instead of re-reading the 1 KB-per-row activation.  `hidden` (nullable, (M, ldh)) receives h when

@@ -11,6 +11,23 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota).  On the GPU boxes the affinity mask (and
+    torch's default thread count) is the whole host while the container's quota is a fraction of it: the CPU oracle runs with hundreds
+    of threads on a dozen cores crawl (the round-3 suite went from minutes to a timeout that way)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+torch.set_num_threads(usable_cores())
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

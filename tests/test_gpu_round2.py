@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import grad_close, rel_close, load_golden, T
+from conftest import grad_close, rel_close, usable_cores, load_golden, T
 from test_gpu_parity import _import, build_model, scene, _run_forward_backward
 
 pytestmark = pytest.mark.gpu
@@ -168,7 +168,7 @@ def test_full_size_backward_vs_oracle():
     cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
     Pg = op.clone_params(P, requires_grad=True)
     cfg = orender.RenderCfg(aabb, res, density_shift=-3.0, semantic_weight_mode="softmax")
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(usable_cores())
     o = orender.render_forward(Pg, rays, cfg, jitter, False)
     L = (o[0] * cots[0]).sum() + (o[1] * cots[1]).sum() + (o[2] * cots[2]).sum() + 3.0 * o[5]
     L.backward()

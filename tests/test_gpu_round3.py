@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import grad_close, rel_close
+from conftest import grad_close, rel_close, usable_cores
 from test_gpu_parity import DEV, _import, _run_forward_backward, build_model, scene
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +48,7 @@ def test_forward_backward_vs_oracle_two_classes(shape, mode):
     P, rays, rng = scene(op, orays, 57, res, C_, E, N, **kw)
     jitter = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
     cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(usable_cores())
     o, gref = _oracle_run(op, orender, P, rays, jitter, cots, aabb, res, mode, False)
     m = build_model(cl, P, res, C_, E, -3.0, mode)
     r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode=mode).to(DEV)
@@ -92,7 +92,7 @@ def test_full_size_gradients_hip_and_fp32_oracle_against_fp64_oracle():
     P, rays, rng = scene(op, orays, 41, res, C_, E, N, img=64, amp=3.0, sg=0.35)
     jitter = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32))
     cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((N, 3), (N, C_), (N, 2 * E))]
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(usable_cores())
     o64, g64 = _oracle_run(op, orender, P, rays, jitter, cots, aabb, res, "softmax", False, dtype=torch.float64)
     o32, g32 = _oracle_run(op, orender, P, rays, jitter, cots, aabb, res, "softmax", False, dtype=torch.float32)
     m = build_model(cl, P, res, C_, E, -3.0, "softmax")
@@ -166,6 +166,131 @@ def test_fp32x6_persistent_layers_against_fp64(M):
     for i in range(2):
         assert e["fp32x6"][i] <= 2e-6 and e["fp32x6"][i] <= 4 * e["fp32"][i] + 2e-7, e
     assert torch.equal(out["fp32x6"][2][:M], out["fp32x6"][0][:, :256])             # a row's bits do not depend on the launch it is in
+
+
+# ============================================================================ first two layers' backward in one launch
+def _first2_case(M, seed, cap=None):
+    from contrastive_lift_amd._lib import call, ptr, stream
+    R = cap or M
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(R, 256, generator=g) * (torch.rand(R, 256, generator=g) > 0.4)
+    W1 = torch.randn(256, 256, generator=g) / 16
+    W0, b0 = torch.randn(256, 3, generator=g), 0.5 * torch.randn(256, generator=g)
+    x4 = torch.cat([torch.rand(R, 3, generator=g) * 2 - 1, torch.zeros(R, 1)], 1).contiguous()
+    dev = {k: v.to(DEV) for k, v in dict(d=d, W1=W1, W0=W0, b0=b0, x4=x4).items()}
+    h1 = torch.empty(R, 256, device=DEV)          # the forward's first-layer activation (its sign is what the fused kernel has to reproduce)
+    call("clift_linear_k3_fwd", ptr(dev["x4"]), ptr(dev["W0"]), 3, ptr(dev["b0"]), R, 256, 1, ptr(h1), 256, 0, stream())
+    dH1 = (d[:M].double() @ W1.double()) * (h1[:M].cpu() > 0)
+    return dev, h1, dH1.t() @ x4[:M, :3].double(), dH1.sum(0)
+
+
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 64, 4097, 66001, 249000])
+def test_first2_bwd_against_fp64_and_the_unfused_pair(M):
+    """clift_xyz_head_first2_bwd (ABI 11): gW0 / gb0 of the K = 3 layer from dH2, W1, (W0, b0) and the positions, without writing
+    dH1 = (h1 > 0) . (dH2 W1) and without reading h1, against the same sums in float64 (mask = sign of the activation the forward kernel
+    produced) and against the unfused pair (clift_gemm masked dgrad + clift_linear_k3_bwd).  Ragged row counts (single row, one short of /
+    one past a 32-row tile, one past a block boundary) and the bench size; the gradients are ACCUMULATED into (a second call doubles them).
+    Band: 2e-5 of each tensor's largest entry (fp32 sums over M rows)."""
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    t, h1, gW_ref, gb_ref = _first2_case(M, 1000 + M)
+    gW, gb = torch.zeros(256, 3, device=DEV), torch.zeros(256, device=DEV)
+    engine.first2_bwd(M, t["d"], t["W1"], t["W0"], t["b0"], t["x4"], gW, gb)
+    torch.cuda.synchronize()
+    for got, ref, nm in ((gW, gW_ref, "gW0"), (gb, gb_ref, "gb0")):
+        err = float((got.double().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err < 2e-5, (M, nm, err)
+    dn = torch.empty(M, 256, device=DEV)                                              # the unfused pair on the same inputs
+    with engine.exact_fp32():
+        engine.gemm(M, 256, 256, t["d"], 256, t["W1"], 256, dn, 256, b_trans=1, mask=h1, ldmask=256)
+    gW2, gb2 = torch.zeros(256, 3, device=DEV), torch.zeros(256, device=DEV)
+    call("clift_linear_k3_bwd", ptr(t["x4"]), ptr(dn), 256, M, 256, ptr(gW2), 3, ptr(gb2), 0, stream())
+    for got, ref, nm in ((gW, gW2, "gW0"), (gb, gb2, "gb0")):
+        err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err < 2e-5, (M, nm, "fused vs unfused", err)
+    engine.first2_bwd(M, t["d"], t["W1"], t["W0"], t["b0"], t["x4"], gW, gb)          # accumulation
+    err = float((gW.double().cpu() - 2 * gW_ref).abs().max()) / max(float(gW_ref.abs().max()), 1e-30)
+    assert err < 4e-5, (M, "accumulate", err)
+
+
+def test_first2_bwd_under_a_device_side_row_limit():
+    """Sync-free step: the launch is sized by a capacity and the kernels read the true row count from device memory -- rows past it
+    (NaN here) must not reach the sums."""
+    from contrastive_lift_amd import engine
+    cap, M = 9000, 5003
+    t, h1, gW_ref, gb_ref = _first2_case(M, 5, cap=cap)
+    t["d"][M:] = float("nan"); t["x4"][M:] = float("nan")
+    gW, gb = torch.zeros(256, 3, device=DEV), torch.zeros(256, device=DEV)
+    lim = engine.rows_limit(gW.device)
+    lim[0:1].fill_(M)
+    try:
+        engine.first2_bwd(cap, t["d"], t["W1"], t["W0"], t["b0"], t["x4"], gW, gb)
+        torch.cuda.synchronize()
+    finally:
+        engine.reset_rows_limit(gW.device)
+    assert bool(torch.isfinite(gW).all()) and bool(torch.isfinite(gb).all())
+    err = float((gW.double().cpu() - gW_ref).abs().max()) / float(gW_ref.abs().max())
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 4097, 66001, 249000])
+def test_first2_wgrad_against_fp64_and_the_streamed_form(M):
+    """clift_xyz_head_first2_wgrad (ABI 11): the second layer's weight / bias gradient with its input, relu(W0 x + b0), generated in-kernel,
+    against float64 sums over the activation the forward kernel produced and against clift_gemm's weight gradient streaming that stored
+    activation.  Ragged row counts around the 64-row tile and the block boundary, and the bench size; accumulating.  Band 2e-5 of the largest entry."""
+    from contrastive_lift_amd import engine
+    t, h1, _, _ = _first2_case(M, 2000 + M)
+    ref = t["d"][:M].double().cpu().t() @ h1[:M].double().cpu()
+    gb_ref = t["d"][:M].double().cpu().sum(0)
+    gW, gb = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+    engine.first2_wgrad(M, t["d"], t["W0"], t["b0"], t["x4"], gW, gb)
+    torch.cuda.synchronize()
+    for got, r, nm in ((gW, ref, "gW1"), (gb, gb_ref, "gb1")):
+        err = float((got.double().cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-30)
+        assert err < 2e-5, (M, nm, err)
+    gW2, gb2 = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+    with engine.exact_fp32():
+        engine.wgrad(256, 256, M, t["d"], 256, h1, 256, gW2, gb2)
+    err = float((gW - gW2).abs().max()) / max(float(gW2.abs().max()), 1e-30)
+    assert err < 2e-5, (M, "generated vs streamed", err)
+    engine.first2_wgrad(M, t["d"], t["W0"], t["b0"], t["x4"], gW, gb)
+    err = float((gW.double().cpu() - 2 * ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+    assert err < 4e-5, (M, "accumulate", err)
+
+
+def test_head_backward_without_the_first_activation_matches_the_stored_form():
+    """xyz_mlp_fwd / xyz_mlp_bwd of a 5-layer head (3 -> 256 -> 256 -> 256 -> 256 -> 22) with the fused first-two-layers backward (the forward
+    keeps no first-layer activation) against the same head with CLIFT_FUSE_FIRST2_BWD off (activation stored, masked dgrad + K = 3 weight
+    gradient as separate launches): every parameter gradient within 2e-5 of its scale; the forward outputs bit-identical."""
+    from contrastive_lift_amd import engine
+    M, C_ = 20011, 22
+    g = torch.Generator().manual_seed(77)
+    dims = [(256, 3), (256, 256), (256, 256), (256, 256), (C_, 256)]
+    layers = [((torch.randn(o, i, generator=g) / (i ** 0.5)).to(DEV), (0.1 * torch.randn(o, generator=g)).to(DEV)) for o, i in dims]
+    xa = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, torch.zeros(M, 1)], 1).contiguous().to(DEV)
+    dpre = torch.zeros(M, 24)
+    dpre[:, :C_] = torch.randn(M, C_, generator=g)
+    dpre = dpre.to(DEV)
+    res = {}
+    prev = engine.FUSE_FIRST2_BWD
+    try:
+        for flag in (True, False):
+            engine.FUSE_FIRST2_BWD = flag
+            out = torch.zeros(M, 24, device=DEV)
+            gl = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in layers]
+            with engine.exact_fp32():
+                acts = engine.xyz_mlp_fwd(layers, xa, M, out, 24)
+                assert (acts[0] is None) == flag
+                engine.xyz_mlp_bwd(layers, gl, xa, acts, dpre.clone(), M)
+            torch.cuda.synchronize()
+            res[flag] = (out, gl)
+    finally:
+        engine.FUSE_FIRST2_BWD = prev
+    assert torch.equal(res[True][0], res[False][0])
+    for (a, ab), (b, bb) in zip(res[True][1], res[False][1]):
+        for x, y in ((a, b), (ab, bb)):
+            err = float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
+            assert err < 2e-5, (tuple(x.shape), err)
 
 
 def test_fp32x6_mode_full_forward_backward_vs_oracle():
