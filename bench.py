@@ -659,8 +659,8 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
     plain = inst.get("fwd", [dom_f, dom_ms, dom_n])
     alg_bytes = (plain[0] / max(1, plain[2])) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
     pmc = measured_traffic_ratio()
-    names = {"fwd": "k_layer_f32<false, false, false>", "fwd_gen": "k_layer_f32<false, true, false>", "fwd_out": "k_layer_f32<false, false, true>"}
-    out = {"bound": "mfma", "kernel": "k_layer_f32<false, *, *> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel: the 256x256 forward MLP layers of the xyz heads, "
+    names = {"fwd": "k_layer_f32<false, false, false, false>", "fwd_gen": "k_layer_f32<false, true, false, false>", "fwd_out": "k_layer_f32<false, false, true, false>"}
+    out = {"bound": "mfma", "kernel": "k_layer_f32<false, *, *, false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel: the 256x256 forward MLP layers of the xyz heads, "
                                       "11 launches per step in three instantiations -- input streamed from memory / K = 3 input layer generated in-kernel / narrow "
                                       "output layer applied in-kernel; rocprofv3 lists them separately: see `instantiations`)",
            "instantiations": {names[k]: {"tflops": tf(v[0], v[1]), "frac": tf(v[0], v[1]) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": v[2] // nb,
