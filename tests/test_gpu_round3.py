@@ -252,6 +252,31 @@ def test_first2_bwd_under_a_device_side_row_limit():
     assert err < 2e-5, err
 
 
+def test_first2_backward_kernels_with_padded_pitches():
+    """The two fused kernels through the C ABI with every pitch larger than its row (dH2 260, W1 264, W0 / gW0 4, gW1 272): pad columns are
+    neither read into the sums nor written."""
+    from contrastive_lift_amd._lib import call, ptr, stream
+    M = 7001
+    t, h1, gW0_ref, gb0_ref = _first2_case(M, 31)
+    dp = torch.full((M, 260), float("nan"), device=DEV); dp[:, :256] = t["d"]
+    W1p = torch.full((256, 264), float("nan"), device=DEV); W1p[:, :256] = t["W1"]
+    W0p = torch.full((256, 4), float("nan"), device=DEV); W0p[:, :3] = t["W0"]
+    gW0 = torch.full((256, 4), -7.0, device=DEV); gW0[:, :3] = 0
+    gb0 = torch.zeros(256, device=DEV)
+    call("clift_xyz_head_first2_bwd", ptr(dp), 260, ptr(W1p), 264, ptr(W0p), 4, ptr(t["b0"]), ptr(t["x4"]), M, ptr(gW0), 4, ptr(gb0), stream())
+    gW1 = torch.full((256, 272), -7.0, device=DEV); gW1[:, :256] = 0
+    gb1 = torch.zeros(256, device=DEV)
+    call("clift_xyz_head_first2_wgrad", ptr(dp), 260, ptr(W0p), 4, ptr(t["b0"]), ptr(t["x4"]), M, ptr(gW1), 272, ptr(gb1), stream())
+    torch.cuda.synchronize()
+    assert bool((gW0[:, 3] == -7.0).all()) and bool((gW1[:, 256:] == -7.0).all())
+    err = float((gW0[:, :3].double().cpu() - gW0_ref).abs().max()) / float(gW0_ref.abs().max())
+    assert err < 2e-5, err
+    ref1 = t["d"][:M].double().cpu().t() @ h1[:M].double().cpu()
+    err = float((gW1[:, :256].double().cpu() - ref1).abs().max()) / float(ref1.abs().max())
+    assert err < 2e-5, err
+    assert float((gb1.double().cpu() - t["d"].double().cpu().sum(0)).abs().max()) / float(t["d"].double().cpu().sum(0).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("M", [1, 63, 64, 65, 4097, 66001, 249000])
 def test_first2_wgrad_against_fp64_and_the_streamed_form(M):
     """clift_xyz_head_first2_wgrad (ABI 11): the second layer's weight / bias gradient with its input, relu(W0 x + b0), generated in-kernel,
