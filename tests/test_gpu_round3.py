@@ -233,8 +233,8 @@ def test_first2_bwd_against_fp64_and_the_unfused_pair(M):
 
 
 def test_first2_bwd_under_a_device_side_row_limit():
-    """Sync-free step: the launch is sized by a capacity and the kernels read the true row count from device memory -- rows past it
-    (NaN here) must not reach the sums."""
+    """Sync-free step: the launch is sized by a capacity and the kernels (both fused backward kernels) read the true row count from device
+    memory -- rows past it (NaN here) must not reach the sums."""
     from contrastive_lift_amd import engine
     cap, M = 9000, 5003
     t, h1, gW_ref, gb_ref = _first2_case(M, 5, cap=cap)
@@ -249,6 +249,18 @@ def test_first2_bwd_under_a_device_side_row_limit():
         engine.reset_rows_limit(gW.device)
     assert bool(torch.isfinite(gW).all()) and bool(torch.isfinite(gb).all())
     err = float((gW.double().cpu() - gW_ref).abs().max()) / float(gW_ref.abs().max())
+    assert err < 2e-5, err
+    # the generating weight gradient under the same limit
+    gW1, gb1 = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+    lim[0:1].fill_(M)
+    try:
+        engine.first2_wgrad(cap, t["d"], t["W0"], t["b0"], t["x4"], gW1, gb1)
+        torch.cuda.synchronize()
+    finally:
+        engine.reset_rows_limit(gW.device)
+    ref1 = t["d"][:M].double().cpu().t() @ h1[:M].double().cpu()
+    assert bool(torch.isfinite(gW1).all()) and bool(torch.isfinite(gb1).all())
+    err = float((gW1.double().cpu() - ref1).abs().max()) / float(ref1.abs().max())
     assert err < 2e-5, err
 
 
