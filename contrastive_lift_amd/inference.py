@@ -116,11 +116,46 @@ def assign_clusters(all_thing_features, all_points_semantics, all_centroids, dev
     return _one_hot(labels, num_images, device)
 
 
-def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000, use_silverman=False):
-    """RP:196-263 (MeanShift branch; HDBSCAN is not installed in this image): 3-sigma outlier filter, per-axis rescale to the
+def _hdbscan_fit(pts, cluster_size):
+    """RP:236-241 / 321-326: HDBSCAN(min_cluster_size, min_samples=1, allow_single_cluster=True) on the rescaled subsample; returns
+    (labels, centroids (K, d) or None when every point is noise).  centroid k = the membership-probability-weighted mean of cluster k's
+    points -- the ``weighted_cluster_centroid`` of the hdbscan package the reference imports.  That package is not in this image: the fit
+    comes from the package when it is importable and otherwise from ``sklearn.cluster.HDBSCAN`` (scikit-learn >= 1.3: the same algorithm,
+    adopted from that package -- mutual-reachability MST, condensed tree, excess-of-mass selection; PARITY UNPINNED against the package
+    itself)."""
+    try:
+        import hdbscan as _pkg                                     # the reference's dependency (requirements.txt)
+        cl = _pkg.HDBSCAN(min_cluster_size=cluster_size, min_samples=1, prediction_data=True, allow_single_cluster=True).fit(pts)
+        labels, prob = cl.labels_, cl.probabilities_
+    except ImportError:
+        from sklearn.cluster import HDBSCAN
+        cl = HDBSCAN(min_cluster_size=cluster_size, min_samples=1, allow_single_cluster=True, copy=True).fit(pts)
+        labels, prob = cl.labels_, cl.probabilities_
+    ids = [k for k in np.unique(labels) if k != -1]
+    if not ids:
+        return labels, None
+    return labels, np.stack([np.average(pts[labels == k], weights=prob[labels == k], axis=0) for k in ids])
+
+
+def _nearest_centroid(points, centroids, device):
+    """RP:244-254: every point to its nearest centroid (squared distances through clift_nearest_centroid on the device; ties -> lowest index,
+    as torch.argmin over cdist)."""
+    f = torch.as_tensor(np.ascontiguousarray(points), dtype=torch.float32, device=device).contiguous()
+    c = torch.as_tensor(np.ascontiguousarray(centroids), dtype=torch.float32, device=device).contiguous()
+    if f.device.type != "cuda":
+        return torch.argmin(torch.cdist(f, c), dim=-1).cpu().numpy()
+    valid = torch.ones((f.shape[0],), dtype=torch.uint8, device=device)
+    lab = torch.empty((f.shape[0],), dtype=torch.int32, device=device)
+    _lib.call("clift_nearest_centroid", _lib.ptr(f), f.shape[1], f.shape[1], _lib.ptr(c), c.shape[0], _lib.ptr(valid), f.shape[0], _lib.ptr(lab),
+              _lib.stream())
+    return lab.cpu().numpy().astype(np.int64)
+
+
+def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000, use_silverman=False, use_dbscan=False, cluster_size=500):
+    """RP:196-263: 3-sigma outlier filter, per-axis rescale to the
     unit box, a 50000-point subsample drawn with ``np.random.choice`` from numpy's GLOBAL generator exactly as the reference
-    does (seed it with ``np.random.seed`` for reproducible runs), sklearn MeanShift (optionally with Silverman's bandwidth),
-    then every pixel is assigned to its nearest cluster.  Returns (one-hot (num_images, P, K+1) float64, centroids in feature
+    does (seed it with ``np.random.seed`` for reproducible runs), sklearn MeanShift (optionally with Silverman's bandwidth) or, with
+    ``use_dbscan``, HDBSCAN (``_hdbscan_fit``), then every pixel is assigned to its nearest cluster.  Returns (one-hot (num_images, P, K+1) float64, centroids in feature
     units).  Scenes with fewer thing pixels than ``num_points`` use all of them (the reference raises there)."""
     from sklearn.cluster import MeanShift
     feats = np.asarray(all_thing_features)
@@ -138,18 +173,26 @@ def cluster(all_thing_features, bandwidth, device, num_images, num_points=50000,
     if use_silverman:
         from scipy.stats import gaussian_kde
         bandwidth = gaussian_kde(pts.T, bw_method="silverman").covariance_factor()
-    ms = MeanShift(bandwidth=bandwidth, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(pts)
-    all_labels = ms.predict((f_all.reshape(-1, f_all.shape[-1]) - bias) * factor)
+    if use_dbscan:                                                # RP:236-255: HDBSCAN on the subsample, then EVERY point to its nearest centroid
+        _, centers = _hdbscan_fit(pts, cluster_size)
+        if centers is None:
+            raise _lib.CliftError("HDBSCAN found no cluster (every sampled point is noise); the reference fails here too (np.stack of an empty list)")
+        all_labels = _nearest_centroid((f_all.reshape(-1, f_all.shape[-1]) - bias) * factor, centers, device)
+    else:
+        ms = MeanShift(bandwidth=bandwidth, cluster_all=False, bin_seeding=True, min_bin_freq=10).fit(pts)
+        all_labels = ms.predict((f_all.reshape(-1, f_all.shape[-1]) - bias) * factor)
+        centers = ms.cluster_centers_
     all_labels[~thing] = -1
     all_labels = all_labels + 1                                   # -1,0,..,K-1 -> 0,1,..,K
-    K1 = ms.cluster_centers_.shape[0] + 1                          # width = number of centroids + 1 (not max label + 1)
+    K1 = centers.shape[0] + 1                                      # width = number of centroids + 1 (not max label + 1)
     onehot = torch.zeros((all_labels.shape[0], K1), dtype=torch.float64, device=device)
     onehot[torch.arange(all_labels.shape[0], device=device), torch.as_tensor(all_labels, dtype=torch.int64, device=device)] = 1
-    return onehot.view(num_images, -1, K1), ms.cluster_centers_ / factor + bias
+    return onehot.view(num_images, -1, K1), centers / factor + bias
 
 
-def cluster_segmentwise(all_thing_features, all_points_semantics, bandwidth, device, num_images, num_points=50000, use_silverman=False):
-    """RP:265-368 (MeanShift branch): the clustering of ``cluster`` run separately inside every predicted thing class, labels of
+def cluster_segmentwise(all_thing_features, all_points_semantics, bandwidth, device, num_images, num_points=50000, use_silverman=False,
+                        use_dbscan=False, cluster_size=500):
+    """RP:265-368: the clustering of ``cluster`` (MeanShift, or HDBSCAN with ``use_dbscan``) run separately inside every predicted thing class, labels of
     successive classes offset so they stay disjoint; classes with fewer than 100 (filtered) points get no instances (-1).
     Returns (one-hot (num_images, P, max label + 2) float64, concatenated centroids in feature units).  Like the reference,
     a class that is skipped for having too few points still appends the previous class's centroids (rescaled with its own
@@ -178,7 +221,14 @@ def cluster_segmentwise(all_thing_features, all_points_semantics, bandwidth, dev
         cr = (cf - bias) * factor
         idx = np.arange(cr.shape[0]) if cr.shape[0] < num_points else np.random.choice(cr.shape[0], num_points, replace=False)
         pts = cr[idx]
-        if pts.shape[0] < 100:                                      # too few points for MeanShift
+        if use_dbscan:                                              # RP:320-342
+            _, cents = _hdbscan_fit(pts, cluster_size)
+            if cents is not None:
+                centroids = cents
+                lab = _nearest_centroid((fc.reshape(-1, fc.shape[-1]) - bias) * factor, cents, device).astype(np.int32)
+            else:
+                lab = -1 * np.ones(fc.shape[0], dtype=np.int32)
+        elif pts.shape[0] < 100:                                    # too few points for MeanShift
             lab = -1 * np.ones(fc.shape[0], dtype=np.int32)
         else:
             bw = bandwidth

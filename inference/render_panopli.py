@@ -80,10 +80,7 @@ def glasbey(n):
 
 
 def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth=0.15, use_dbscan=False, segmentwise=False,
-                              cached_centroids_path=None, device="cuda:0", use_silverman=False):
-    if use_dbscan:
-        raise NotImplementedError("--use_dbscan needs the hdbscan package, which is not installed in this image; use MeanShift "
-                                  "(default, optionally --segmentwise / --use_silverman) or --cached_centroids_path")
+                              cached_centroids_path=None, device="cuda:0", use_silverman=False, cluster_size=500):
     out = output_dirname(config, trajectory_name, test_only, use_dbscan, segmentwise)
     out.mkdir(exist_ok=True, parents=True)
     # launched under torch.distributed.run: one process per GPU, every frame rendered as row-tiles (one per rank) and
@@ -137,9 +134,11 @@ def render_panopli_checkpoint(config, trajectory_name, test_only=True, bandwidth
         insts = inf.assign_clusters(all_thing, sems, cents, device, num_images=len(rgbs))
     else:
         if not segmentwise:
-            insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
+            insts, _ = inf.cluster(all_thing, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman, use_dbscan=use_dbscan,
+                                   cluster_size=cluster_size)
         else:
-            insts, _ = inf.cluster_segmentwise(all_thing, sems, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman)
+            insts, _ = inf.cluster_segmentwise(all_thing, sems, bandwidth, device, num_images=len(rgbs), use_silverman=use_silverman,
+                                               use_dbscan=use_dbscan, cluster_size=cluster_size)
     for d in ("vis_semantics_and_surrogate", "pred_semantics", "pred_surrogateid"):
         (out / d).mkdir(exist_ok=True)
     for j, frame_name in enumerate(names):
@@ -163,9 +162,8 @@ if __name__ == "__main__":
     ap.add_argument("--bandwidth", type=float, default=0.15, required=False)
     ap.add_argument("--cluster_size", type=int, default=500, required=False, help="min_cluster_size for HDBSCAN")
     ap.add_argument("--use_dbscan", action="store_true",
-                    help="HDBSCAN clustering (reference RP:236-255) -- NOT available here: the hdbscan package is not installed in this "
-                         "image; the flag fails immediately, before anything is rendered.  Use MeanShift (default), --use_silverman or "
-                         "--cached_centroids_path")
+                    help="HDBSCAN clustering (reference RP:236-255): the hdbscan package when it is installed, otherwise "
+                         "sklearn.cluster.HDBSCAN (the same algorithm; scikit-learn >= 1.3)")
     ap.add_argument("--segmentwise", action="store_true")
     ap.add_argument("--subsample", type=int, default=1, required=False)
     ap.add_argument("--use_silverman", action="store_true")
@@ -178,4 +176,5 @@ if __name__ == "__main__":
     cfg.image_dim = list(args.image_dim)
     print(render_panopli_checkpoint(cfg, "trajectory_blender", test_only=not args.render_trajectory, bandwidth=args.bandwidth,
                                     use_dbscan=args.use_dbscan, segmentwise=args.segmentwise,
-                                    cached_centroids_path=args.cached_centroids_path, use_silverman=args.use_silverman))
+                                    cached_centroids_path=args.cached_centroids_path, use_silverman=args.use_silverman,
+                                    cluster_size=args.cluster_size))

@@ -188,6 +188,61 @@ def test_g17_segmentwise_clustering_vs_reference():
     np.testing.assert_allclose(cents, g["seg.centroids"], rtol=1e-6, atol=1e-7)
 
 
+def test_hdbscan_clustering_branch():
+    """--use_dbscan (RP:236-255, 320-342).  The hdbscan package the reference imports is not in this image (PARITY UNPINNED against it): the fit
+    comes from sklearn.cluster.HDBSCAN, the same algorithm.  Checked here on five well-separated 3-D blobs + stuff rows: every blob becomes
+    exactly one cluster, every thing pixel gets its blob's label (nearest probability-weighted centroid), stuff pixels get label 0, the one-hot
+    width is clusters + 1, the centroids (scaled back to feature units) sit on the blob means; segment-wise: the same inside every class with
+    disjoint label ranges; a class of 30 scattered points (fewer than min_cluster_size) comes out as ONE cluster (allow_single_cluster: the root
+    of a tree without a split is selected), as the algorithm prescribes."""
+    import numpy as np
+    import torch
+    from contrastive_lift_amd.inference import cluster, cluster_segmentwise, _hdbscan_fit
+    rng = np.random.default_rng(5)
+    n_img, per_img, n_blob = 4, 3000, 5
+    means = np.array([[0.0, 0.0, 0.0], [1.0, 0.2, -0.3], [-0.8, 0.9, 0.4], [0.3, -1.1, 0.8], [-0.5, -0.6, -1.0]])
+    N = n_img * per_img
+    blob = rng.integers(0, n_blob, N)
+    feats = means[blob] + 0.03 * rng.standard_normal((N, 3))
+    thing = rng.uniform(size=N) < 0.7
+    all_thing = np.concatenate([np.where(thing, -np.inf, 0.0)[:, None], feats], 1).astype(np.float32)
+    np.random.seed(1)
+    onehot, cents = cluster(all_thing.copy(), 0.15, torch.device("cpu"), num_images=n_img, use_dbscan=True, cluster_size=50)
+    lab = onehot.argmax(-1).reshape(-1).numpy()
+    assert onehot.shape == (n_img, per_img, n_blob + 1) and cents.shape == (n_blob, 3)
+    assert np.all(lab[~thing] == 0) and np.all(lab[thing] >= 1)
+    for b in range(n_blob):                                           # one label per blob, and the labels of different blobs differ
+        assert len(np.unique(lab[thing & (blob == b)])) == 1
+    assert len({int(lab[thing & (blob == b)][0]) for b in range(n_blob)}) == n_blob
+    for b in range(n_blob):
+        k = int(lab[thing & (blob == b)][0]) - 1
+        assert np.abs(cents[k] - means[b]).max() < 0.02
+    # the centroid is the membership-probability-weighted mean of the cluster's points (hdbscan's weighted_cluster_centroid)
+    pts = rng.standard_normal((400, 2)) * 0.05 + np.repeat(np.array([[0.0, 0.0], [1.0, 1.0]]), 200, 0)
+    labels, c = _hdbscan_fit(pts, 20)
+    from sklearn.cluster import HDBSCAN
+    ref = HDBSCAN(min_cluster_size=20, min_samples=1, allow_single_cluster=True).fit(pts)
+    assert np.array_equal(labels, ref.labels_) and c.shape == (2, 2)
+    for k in range(2):
+        m = ref.labels_ == k
+        np.testing.assert_allclose(c[k], np.average(pts[m], weights=ref.probabilities_[m], axis=0), rtol=1e-12)
+    # segment-wise: two thing classes holding blobs {0, 1, 2} and {3, 4}; a third class of 30 scattered points
+    sem_cls = np.where(blob <= 2, 1, 2)
+    scat = rng.choice(np.nonzero(thing)[0], 30, replace=False)
+    sem_cls[scat] = 3
+    all_thing[scat, 1:] = rng.uniform(-3, 3, (30, 3)).astype(np.float32)
+    sems = [torch.nn.functional.one_hot(torch.from_numpy(sem_cls[i * per_img:(i + 1) * per_img]), 4).float() for i in range(n_img)]
+    np.random.seed(2)
+    onehot_s, cents_s = cluster_segmentwise(all_thing.copy(), sems, 0.15, torch.device("cpu"), num_images=n_img, use_dbscan=True, cluster_size=50)
+    lab_s = onehot_s.argmax(-1).reshape(-1).numpy()
+    keep = thing & (sem_cls != 3)
+    assert cents_s.shape == (n_blob + 1, 3) and onehot_s.shape[-1] == n_blob + 2
+    assert np.all(lab_s[~thing] == 0) and np.all(lab_s[scat] == n_blob + 1)
+    ids = [np.unique(lab_s[keep & (blob == b)]) for b in range(n_blob)]
+    assert all(len(i) == 1 for i in ids) and len({int(i[0]) for i in ids}) == n_blob
+    assert {int(ids[b][0]) for b in (0, 1, 2)} == {1, 2, 3} and {int(ids[b][0]) for b in (3, 4)} == {4, 5}
+
+
 def test_trainer_rejects_unbuilt_config_variants():
     """Options of the reference's config tree that the hot-path trainer does not implement raise instead of being ignored."""
     import pytest

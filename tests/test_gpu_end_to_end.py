@@ -62,6 +62,13 @@ def test_train_checkpoint_render(tmp_path, monkeypatch):
     assert sorted(os.listdir(out_t / "pred_semantics")) == ["0000.png", "0001.png", "0002.png"] and "trajectory_blender" in str(out_t)
     thing = np.load(out / "thing_features.npy")
     assert thing.shape == (4 * 64 * 64, 4) and set(np.unique(np.isinf(thing[:, 0]))) == {True}
+    # --use_dbscan (RP:236-255): HDBSCAN over the rendered instance features, every pixel to its nearest centroid on the device
+    np.random.seed(0)
+    out_d = rp.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, use_dbscan=True, cluster_size=200)
+    assert str(out_d).endswith("_dbscan") and sorted(os.listdir(out_d / "pred_surrogateid")) == names
+    from PIL import Image as _Image
+    sur_d = np.stack([np.array(_Image.open(out_d / "pred_surrogateid" / n)) for n in names])
+    assert sur_d.dtype == np.uint16 and sur_d.max() >= 1 and 2 <= len(np.unique(sur_d)) <= 64      # 0 = pixels of stuff classes
     from PIL import Image
     sem = np.array(Image.open(out / "pred_semantics" / names[0]))
     sur = np.array(Image.open(out / "pred_surrogateid" / names[0]))
