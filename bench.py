@@ -471,9 +471,23 @@ def x6_probe(a, dev, batches, S, steps=10, warmup=3):
             tr.training_step(batches[i % len(batches)], lean=a.lean)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
+        # frame render in fp32x6 mode (same rays / chunking as the bf16 probe's and the exact path's `inference_rays_per_s`)
+        from contrastive_lift_amd import inference as inf
+        ratio = renderer.step_ratio
+        renderer.update_step_ratio(ratio * 0.5)
+        try:
+            rays = pool[:262144].contiguous()
+            inf.render_rays(model, renderer, rays[:32768], 32768)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            inf.render_rays(model, renderer, rays, 32768)
+            torch.cuda.synchronize()
+            inf_rate = rays.shape[0] / (time.perf_counter() - t)
+        finally:
+            renderer.update_step_ratio(ratio)
     finally:
         engine.set_mlp_precision(prev)
-    return dict(fp32x6_ms_per_step=round(dt * 1e3, 3), fp32x6_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt,
+    return dict(fp32x6_ms_per_step=round(dt * 1e3, 3), fp32x6_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt, fp32x6_inference_rays_per_s=inf_rate,
                 fp32x6_note="fp32-faithful (6 bf16 products of exactly split operands, fp32 accumulate): outputs / gradients meet the exact path's "
                             "test tolerances (tests/test_gpu_round3.py, CLIFT_FORCE_MLP_DTYPE=fp32x6 runs of the suite); not the headline")
 
