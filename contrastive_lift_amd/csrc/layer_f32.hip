@@ -17,6 +17,9 @@
 // Dgrad: the ReLU mask of a tile (the layer's fp32 input activation, as large as the tile) does not fit in LDS next to the rows, so
 // each lane fetches the 4 x 16 bytes it needs straight into registers at the START of the tile and waits for them at the epilogue,
 // ~8 k MFMA cycles later.
+// Three fused forms share the skeleton (template flags): GEN (forward: the K = 3 input layer generated in-kernel), OUTV (forward: a narrow
+// output layer applied to the tile in registers) and K3W (dgrad: the result consumed in-kernel by the K = 3 layer's weight gradient, mask
+// re-derived from the positions) -- described at their parameter structs below.
 // All LDS reads and the mask loads are inline asm: beside an in-flight LDS-DMA the compiler guards ordinary reads of the array /
 // ordinary global loads with s_waitcnt vmcnt(0), which would drain the prefetched tile and the output stores; each asm wait is
 // tied to the registers it guards as a data dependency, and sched_barriers pin the read-ahead order.

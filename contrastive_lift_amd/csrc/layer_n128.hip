@@ -7,6 +7,8 @@
 // The tiled kernel (gemm.hip, k_gemm<128,128>) ran these layers at ~36 % of the fp32-MFMA rate: a K = 128 launch is 8 k-tiles, so
 // its prologue, barriers and un-overlapped epilogue are most of a tile's life.
 //   forward: C = relu(A W^T + b), weights [n][k];  dgrad: C = mask . (A W), weights [k][n], fp32 ReLU mask.
+// Also here: every persistent WEIGHT GRADIENT (k_wgrad_n128_stream: the 128-wide layers, and the 256 x 256 layers as four quadrants --
+// optionally with the X operand generated from the sample positions, GENX: the second layer of an xyz head).
 // LDS image: lane-linear (DMA); 16-byte chunk c of row r sits in slot c ^ (r & 7) of its row (low three bits only, so that a
 // 40-chunk row keeps the permutation inside its 8-chunk groups); a ds_read_b128 pass of 16 lanes (rows r .. r+15, one chunk index)
 // then touches every bank exactly twice -- the minimum for 256 bytes.
