@@ -182,7 +182,7 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // (4 ds_write_b128, 16 ds_read_b32 per lane) so that rows become the MFMA reduction index, reads dOut column-wise from the tile that is
 // already in LDS, and adds 16 MFMAs per tile into one accumulator kept for the whole row range (flushed once, like k_wgrad_narrow_stream).
 constexpr int DN_TPITCH = 36;            // floats per row of the transposition buffer (16-byte rows, conflict-free both ways)
-template <int KJ, bool HB, bool MASK, bool WG = false>
+template <int KJ, bool HB, bool MASK, bool WG = false, bool PF = WG>
 __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block, float* __restrict__ gW = nullptr, int ldgw = 0,
                                                                 float* __restrict__ gb = nullptr, int no = 0) {
     static_assert(!WG || (MASK && !HB), "the fused weight gradient exists for the fp32 masked form");
@@ -229,15 +229,59 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     for (int r = 0; r < 16; ++r) accw[r] = 0.f;
     float bsum = 0.f;
     const unsigned tb0 = lds0 + (unsigned)(2 * TILEB + wave * ROWS * DN_TPITCH * 4);      // this wave's transposition buffer
+    // WG form: the mask of a tile is fetched ONE TILE AHEAD (into `nk` / `nh`, copied to `mk` / `mh` at the top of its tile): fetched at the start of
+    // its own tile and awaited before the epilogue, the kernel kept only 32 KB of reads in flight per CU and a tile lasted one HBM round trip
+    // (140.6 -> 110.3 us at 249 k rows x 22 classes).  Always issued -- for the tile past the last one on clamped rows -- so that no run-time
+    // branch separates the asm loads from the asm wait that publishes their registers.  The plain masked form keeps the same-tile fetch: its
+    // tiles are a handful of MFMAs long, one tile of distance hides nothing and moves the wait in front of the barrier (102 -> 116 us).
+    f32x4 nk[4];
+    u32x2v nh[4];
+    // (masked form: N is a multiple of 32; a wave past N only helps with the DMA.  Its mask loads stay in the instruction stream --
+    // pointed at columns that exist -- for the same reason)
+    const bool wave_on = 32 * wave < g.N;
+    const int mcol = wave_on ? 32 * wave : 0;
+    auto mask_fetch = [&](int t) {
+        const int mrow = min(rbeg + t * ROWS + li, rend - 1);
+        if (!MASK) {
+        } else if (!HB) {
+            const float* mp = g.mask + (size_t)mrow * g.ldmask + mcol + 4 * lh;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                         : "=&v"(nk[0]), "=&v"(nk[1]), "=&v"(nk[2]), "=&v"(nk[3]) : "v"(mp) : "memory");
+        } else {
+            const unsigned short* mp = reinterpret_cast<const unsigned short*>(g.mask) + (size_t)mrow * g.ldmask + mcol + 4 * lh;
+            asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx2 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48"
+                         : "=&v"(nh[0]), "=&v"(nh[1]), "=&v"(nh[2]), "=&v"(nh[3]) : "v"(mp) : "memory");
+        }
+    };
     dma(0);
+    if (PF) mask_fetch(0);
     for (int t = 0; t < ntiles; ++t) {
-        // MASK: the previous epilogue waited for everything older than its stores, the DMA of this tile included.  !MASK: the DMA of this tile
-        // is older than the previous tile's stores -- four of them in a wave that stores all its column groups, otherwise drain
-        if (t > 0 && ((MASK && 32 * wave < g.N) || (!MASK && full_wave))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Issue order of a wave per tile: DMA(t+1), mask(t+1) [4], ..., stores(t) [4].  At the top of tile t everything older than the four
+        // stores of tile t-1 must have landed -- the DMA of this tile and (MASK) this tile's mask, both issued before them; a wave that does not
+        // store all four column groups drains
+        if (t > 0 && ((MASK && 32 * wave < g.N) || (!MASK && full_wave))) {
+            if (!MASK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (!HB) asm volatile("s_waitcnt vmcnt(4)" : "+v"(nk[0]), "+v"(nk[1]), "+v"(nk[2]), "+v"(nk[3]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" : "+v"(nh[0]), "+v"(nh[1]), "+v"(nh[2]), "+v"(nh[3]) : : "memory");
+        } else {
+            if (!MASK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk[0]), "+v"(nk[1]), "+v"(nk[2]), "+v"(nk[3]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nh[0]), "+v"(nh[1]), "+v"(nh[2]), "+v"(nh[3]) : : "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 1 < ntiles) dma(t + 1);
+        f32x4 mk[4];
+        u32x2v mh[4];
+        if (PF) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mk[q] = nk[q]; mh[q] = nh[q]; }
+            mask_fetch(t + 1);
+        } else {
+            mask_fetch(t);
+        }
         if (WG) {
             const int valid = rend - (rbeg + t * ROWS);
             if (valid < ROWS) {                                              // last tile of the range: rows past its end add nothing to gW
@@ -247,25 +291,6 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             }
         }
         const int m = rbeg + t * ROWS + li;
-        f32x4 mk[4];
-        u32x2v mh[4];
-        // (masked form: N is a multiple of 32; a wave past N only helps with the DMA.  Its mask loads stay in the instruction stream --
-        // pointed at columns that exist -- because a run-time branch between an asm load and the asm wait that publishes its registers
-        // lets the compiler copy those registers before the data has arrived)
-        const bool wave_on = 32 * wave < g.N;
-        const int mcol = wave_on ? 32 * wave : 0;
-        if (!MASK) {
-        } else if (!HB) {
-            const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + mcol + 4 * lh;
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                         : "=&v"(mk[0]), "=&v"(mk[1]), "=&v"(mk[2]), "=&v"(mk[3]) : "v"(mp) : "memory");
-        } else {
-            const unsigned short* mp = reinterpret_cast<const unsigned short*>(g.mask) + (size_t)min(m, rend - 1) * g.ldmask + mcol + 4 * lh;
-            asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:16\n\t"
-                         "global_load_dwordx2 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48"
-                         : "=&v"(mh[0]), "=&v"(mh[1]), "=&v"(mh[2]), "=&v"(mh[3]) : "v"(mp) : "memory");
-        }
         f32x4 fa[KJ];
         const unsigned sb = lds0 + (unsigned)((t & 1) * TILEB);
 #pragma unroll
@@ -281,9 +306,12 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].z, fa[j].z, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j].w, fa[j].w, acc1, 0, 0, 0);
         }
-        if (!MASK) {
-        } else if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mh[0]), "+v"(mh[1]), "+v"(mh[2]), "+v"(mh[3]) : : "memory");
+        if (!PF && MASK) {                   // same-tile fetch: the mask is needed from here on
+            if (!HB) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk[0]), "+v"(nk[1]), "+v"(nk[2]), "+v"(nk[3]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nh[0]), "+v"(nh[1]), "+v"(nh[2]), "+v"(nh[3]) : : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mk[q] = nk[q]; mh[q] = nh[q]; }
+        }
         if (WG) {
             // the wave's 32 x 32 block of h: row-per-lane registers -> LDS [row][36] -> column-per-lane registers (rows 2 s + lh)
 #pragma unroll
@@ -364,6 +392,14 @@ extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const flo
     const dim3 grid(cdiv(M, rpb));
     hipStream_t st = as_stream(s);
     const int kj = cdiv(no, 8);
+    const char* pf = getenv("CLIFT_NARROW_PREFETCH");          // A/B switch: "0" = fetch a tile's mask inside the tile (the round-2 form)
+    if (pf && pf[0] == '0') {
+        if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else k_dgrad_narrow_stream<4, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        return clift_check_launch("clift_out_layer_bwd");
+    }
     if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
