@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -67,6 +67,9 @@ _SIGNATURES = {
     "clift_app_head_last2_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P], C.c_int),
     "clift_xyz_head_bf16_fwd": ([_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P], C.c_int),
     "clift_bind_rows_limit": ([_P], C.c_int),
+    "clift_bind_grad_shards": ([_P], C.c_int),
+    "clift_grad_shards_begin": ([_P, _P, _P, C.c_long, _P], C.c_int),
+    "clift_grad_shards_fold": ([_P, C.c_long, C.c_long, _I, _P], C.c_int),
     "clift_scan_counts_capped": ([_P, _I, _P, _I, _P, _P, _P], C.c_int),
     "clift_compact_fill_capped": ([_P, _P, _I, _I, _F, _P, _I, _P], C.c_int),
     "clift_alpha_bbox": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P], C.c_int),

@@ -77,8 +77,35 @@ __device__ __forceinline__ bool rows_cut(long row) {          // is this row pas
     const int* p = g_rows_limit;
     return p && row >= (long)*p;
 }
+// ----------------------------------------------------------------------------- XCD-private gradient shards
+// The kernels that END by adding a per-block partial of a small gradient tensor to memory (weight gradients, the K = 3 / output layers'
+// gradients) pay for contention, not for bandwidth: 256 blocks of all eight XCDs add to the same few cache lines at the same moment, and a
+// line that is read-modify-written from several XCDs' L2s bounces between them -- 8 - 20 us per launch at every size (tools/fixed_cost_probe.py,
+// DESIGN.md 5c).  With shards, a block adds into the copy of the gradient range that belongs to ITS XCD (block id & 7: block ids 8 apart share
+// an XCD), so a line is only ever touched from one L2; clift_grad_shards_fold adds the eight copies into the real gradients once per pass.
+// The range and the shards are described by a 40-byte record in device memory (clift_bind_grad_shards publishes its address once, like the
+// row limit); `enabled` is set by clift_grad_shards_begin and cleared by the fold, both stream-ordered, so a backward pass outside such a
+// bracket (the autograd path, tests) adds straight into the gradients as before.
+struct GradShardDesc {
+    long lo;          // address of the first gradient float of the sharded range
+    long bytes;       // length of the range
+    long shard0;      // address of shard 0; shard x at shard0 + x * stride
+    long stride;      // bytes between shards
+    int enabled;
+    int pad;
+};
+static __device__ const GradShardDesc* g_grad_shard_desc = nullptr;
+// block-uniform: where this block adds its partial of the gradient tensor at `p`
+__device__ __forceinline__ float* grad_target(float* p) {
+    const GradShardDesc* d = g_grad_shard_desc;
+    if (d == nullptr || p == nullptr) return p;
+    const long off = (long)(uintptr_t)p - d->lo;
+    if (!d->enabled || off < 0 || off >= d->bytes) return p;
+    return reinterpret_cast<float*>((uintptr_t)(d->shard0 + (long)(blockIdx.x & 7) * d->stride + off));
+}
 #define CLIFT_ROWS_LIMIT_BINDER(tu) \
-    void clift_bind_rows_limit_##tu(const int* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_limit), &p, sizeof(p)); }
+    void clift_bind_rows_limit_##tu(const int* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_limit), &p, sizeof(p)); } \
+    void clift_bind_grad_shards_##tu(const void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_grad_shard_desc), &p, sizeof(p)); }
 
 // ----------------------------------------------------------------------------- wave primitives (64 lanes)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -373,11 +373,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         __syncthreads();
         if (khalf == 0) {
             const float4 o = lds[kn];
-            float* gw = kp.gW0 + (size_t)kn * kp.ldgw0;
+            float* gw = grad_target(kp.gW0) + (size_t)kn * kp.ldgw0;
             unsafeAtomicAdd(gw + 0, k3w0 + o.x);
             unsafeAtomicAdd(gw + 1, k3w1 + o.y);
             unsafeAtomicAdd(gw + 2, k3w2 + o.z);
-            unsafeAtomicAdd(kp.gb0 + kn, k3b + o.w);
+            unsafeAtomicAdd(grad_target(kp.gb0) + kn, k3b + o.w);
         }
         return;
     }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_f32_stream(GemmP g, int rows_p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = 32 * wave + 8 * (r >> 2) + 4 * lh + (r & 3);
-        float* dst = g.C + (size_t)n * g.ldc + 64 * slice + li;
+        float* dst = grad_target(g.C) + (size_t)n * g.ldc + 64 * slice + li;
         unsafeAtomicAdd(dst, acc0[r]);
         unsafeAtomicAdd(dst + 32, acc1[r]);
     }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_f32_stream(GemmP g, int rows_p
         const unsigned u = __float_as_uint(bsum);
         const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (lh == 0) unsafeAtomicAdd(g.colsum + 32 * wave + li, tot);
+        if (lh == 0) unsafeAtomicAdd(grad_target(g.colsum) + 32 * wave + li, tot);
     }
 }
 

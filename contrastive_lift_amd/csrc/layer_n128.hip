@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
     const int ntiles = (rend - rbeg + ROWS - 1) / ROWS;
     const float* __restrict__ Y = g.A + 128 * (quad >> 1);            // dY (rows, 128 of lda)
     const float* __restrict__ X = g.B + 128 * (quad & 1);             // X (rows, 4 KXC of ldb)
-    float* __restrict__ Cq = g.C + (size_t)(128 * (quad >> 1)) * g.ldc + 128 * (quad & 1);
+    float* __restrict__ Cq = grad_target(g.C) + (size_t)(128 * (quad >> 1)) * g.ldc + 128 * (quad & 1);     // (this XCD's shard when a pass has them on)
     const int ncols = quads == 4 ? 128 : g.N;
     // LDS-DMA piece i of tile t (this wave's share): i < 4: two rows of dY (64 rows x 32 chunks per tile); i >= 4: 64 chunks of X
     auto dma_piece = [&](int t, int i) {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_n128_stream(GemmP g, int rows_
         const unsigned u = __float_as_uint(bsum2[0] + bsum2[1]);
         const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (lh == 0) unsafeAtomicAdd(g.colsum + 128 * (quad >> 1) + 32 * wn + li, tot);
+        if (lh == 0) unsafeAtomicAdd(grad_target(g.colsum) + 128 * (quad >> 1) + 32 * wn + li, tot);
     }
 }
 

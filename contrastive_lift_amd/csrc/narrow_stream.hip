@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_narrow_stream(const float* __r
         }
     }
     // lane (li, lh) holds gW rows c = 8 q + 4 lh + e, column 32 wave + li
+    gW = grad_target(gW); gb = grad_target(gb); ones_row = grad_target(ones_row);       // (this XCD's shard when a pass has them on)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
     }
     if (WG) {
         // lane (li, lh) holds gW rows c = 8 q + 4 lh + e, column 32 wave + li
+        gW = grad_target(gW); gb = grad_target(gb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 8 * (r >> 2) + 4 * lh + (r & 3);

@@ -460,6 +460,22 @@ def rows_limit(dev):
     return t
 
 
+_grad_shard_record = {}
+
+
+def grad_shard_record(dev):
+    """The library's gradient-shard record of this device (5 x int64: range start, bytes, shard 0, shard stride, enabled), bound once
+    (clift_bind_grad_shards).  All zero -- disabled -- except inside a trainer pass (clift_grad_shards_begin ... clift_grad_shards_fold)."""
+    key = (dev.type, dev.index)
+    t = _grad_shard_record.get(key)
+    if t is None:
+        t = torch.zeros(5, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        call("clift_bind_grad_shards", ptr(t))
+        _grad_shard_record[key] = t
+    return t
+
+
 def reset_rows_limit(dev=None):
     """Back to 'no limit' (stream-ordered).  Called at the end of every sync-free pass, and defensively by the point-wise utilities."""
     global _limit_owner

@@ -8,6 +8,7 @@ that the pass touched -- the reference's DDP does the same exchange bucket by bu
 (SURVEY 2a/2b).  The slow net is an EMA of synchronised fast weights, so it needs no exchange.
 """
 import math
+import os
 import time
 import types
 
@@ -31,8 +32,9 @@ def default_config(**over):
              max_rays_segments=1024, use_symmetric_ce=False, ce_alpha=0.85, ce_beta=0.15, reweight_fg=False,
              mlp_dtype="fp32",     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
              nosync=False,         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
-             skip_discarded_instance_heads=False)    # extension key: do not evaluate the instance heads in the main pass, where the reference
+             skip_discarded_instance_heads=False,    # extension key: do not evaluate the instance heads in the main pass, where the reference
                                                      # computes and discards them (T:155) -- same results, ~12 % less work; the train CLI sets it
+             grad_shards=True)     # extension key: MLP gradients accumulate in eight per-XCD copies, folded once per pass (include/clift.h, ABI 12)
     c.update(over)
     return types.SimpleNamespace(**c)
 
@@ -71,6 +73,17 @@ class ArenaAdam:
         self.m.copy_(sd["m"].to(self.m.device)); self.v.copy_(sd["v"].to(self.v.device))
         self.t = {k: int(sd["t"].get(k, 0)) for k in self.t}
         self.lr_scale = float(sd.get("lr_scale", 1.0))
+
+
+def _shard_guard(fn):
+    def guarded(self, *a, **k):
+        try:
+            return fn(self, *a, **k)
+        except BaseException:
+            self._shards_off()
+            raise
+    guarded.__doc__, guarded.__name__ = fn.__doc__, fn.__name__
+    return guarded
 
 
 class HotPathTrainer:
@@ -133,6 +146,54 @@ class HotPathTrainer:
         # sync-free capacities were learnt for the previous grid / step size / bounding box: forget them (two synchronising steps again)
         if hasattr(self, "_caps"):
             self._caps = {}
+        self._setup_grad_shards()
+
+    # ------------------------------------------------------------------ XCD-private shards of the MLP gradients (include/clift.h, ABI 12)
+    def _setup_grad_shards(self):
+        """Eight copies (one per XCD) of the gradient range of the three trained MLPs (appearance, semantic, fast instance: ~1.5 MB): the
+        weight-gradient kernels of a pass add into the copy of their block's XCD and one fold per pass adds the copies into the gradients --
+        instead of 256 blocks of eight XCDs read-modify-writing the same cache lines at the end of every such launch (8 - 20 us each).
+        ``grad_shards: False`` in the config turns it off."""
+        m = self.model
+        self._shards = None
+        if self.device.type != "cuda" or not bool(getattr(self.config, "grad_shards", True)) or os.environ.get("CLIFT_GRAD_SHARDS", "1") == "0":
+            return
+        s0, s1 = m.arena.range_of("net_app", "net_sem", "inst_fast")
+        n = s1 - s0
+        stride = (n + 63) // 64 * 64                                   # floats; shards start on 256-byte boundaries
+        self._shards = torch.zeros(8 * stride, dtype=torch.float32, device=self.device)
+        self._shard_range = (s0, s1)
+        g = m.grad_flat
+        self._shard_src = torch.tensor([g.data_ptr() + 4 * s0, 4 * n, self._shards.data_ptr(), 4 * stride, 1], dtype=torch.int64, device=self.device)
+        self._shard_grad_ptr = g.data_ptr()
+        self._shard_record = engine.grad_shard_record(self.device)
+
+    def _pass_begin(self, rng):
+        """Clear the pass's gradient range; with shards: one launch that also switches them on for this pass's kernels."""
+        m = self.model
+        g = m.grad_flat[rng[0]:rng[1]]
+        if self._shards is None:
+            g.zero_()
+            return
+        if m.grad_flat.data_ptr() != self._shard_grad_ptr:             # the arena moved (grid resize without a new optimizer): re-describe it
+            self._setup_grad_shards()
+        if g.data_ptr() % 16 != 0:                                      # (the arena pads every tensor to 16 bytes; belt and braces)
+            g.zero_()
+            g = g[:0]
+        _lib.call("clift_grad_shards_begin", _lib.ptr(self._shard_record), _lib.ptr(self._shard_src), _lib.ptr(g) if g.numel() else None, g.numel(),
+                  _lib.stream())
+
+    def _shards_off(self):
+        """A pass that raised between begin and fold must not leave the shards switched on for whoever runs a backward next."""
+        if getattr(self, "_shards", None) is not None:
+            _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), 0, 0, 1, _lib.stream())
+
+    def _pass_fold(self, *groups):
+        """Add the shards of the named arena groups into the gradients and switch the shards off (every later kernel adds directly)."""
+        if self._shards is None:
+            return
+        a, b = self.model.arena.range_of(*groups)
+        _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), a - self._shard_range[0], b - a, 1, _lib.stream())
 
     def on_train_epoch_start(self):
         """T:447: dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch))."""
@@ -238,6 +299,7 @@ class HotPathTrainer:
             st["probe"] = (host, ev)
 
     # ------------------------------------------------------------------ main pass (T:151-208)
+    @_shard_guard
     def main_pass(self, batch, jitter=None, white_bg=None, lean=False, segments=None, segment_jitter=None):
         """batch: dict with rays (B,8), rgbs (B,3), probabilities (B,C), confidences (B,), mask (B,) bool/float.
         ``lean`` skips the instance heads, whose output the reference's main pass computes and discards (T:155).
@@ -246,7 +308,7 @@ class HotPathTrainer:
         c, m, r = self.config, self.model, self.renderer
         rays = batch["rays"]
         B = rays.shape[0]
-        m.grad_flat[self.main_range[0]:self.main_range[1]].zero_()
+        self._pass_begin(self.main_range)
         if jitter is None and c.perturb != 0:
             jitter = c.perturb * torch.rand(B, device=self.device)
         chunk = c.chunk if c.chunk and c.chunk > 0 else B
@@ -298,7 +360,9 @@ class HotPathTrainer:
             self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         for k, ctx in enumerate(ctxs):
             s = slice(k * chunk, k * chunk + ctx.N)
-            hook = (lambda: started.append(self._allreduce_start(self.early_range))) if (early and k == len(ctxs) - 1) else None
+            # (the head chains of the last chunk are issued: the MLP gradients are complete -- fold their shards before they travel)
+            hook = (lambda: (self._pass_fold("net_app", "net_sem"), started.append(self._allreduce_start(self.early_range)))) \
+                if (early and k == len(ctxs) - 1) else None
             engine.render_backward(m, ctx, gv, g_rgb[s], g_sem[s] if sem_on else None, None, g_dist, density_grad=True, before_density=hook)
         if seg_term:
             if getattr(c, "use_symmetric_ce", False):
@@ -307,6 +371,7 @@ class HotPathTrainer:
                 raise NotImplementedError("segment-consistency term with use_symmetric_ce: SCELoss is undefined on class-index targets")
             self._segment_term(segments, segment_jitter, gv, w_sem * float(c.lambda_segment))
         if not early:
+            self._pass_fold("net_app", "net_sem")
             self.losses[2] = m.total_tv_loss(None, c, self.current_epoch, accumulate_grad=True, scale=w_rgb)
         if self.nosync:
             engine.reset_rows_limit(self.device)
@@ -347,13 +412,14 @@ class HotPathTrainer:
         engine.feature_backward(m, ctx, gv, grad)
 
     # ------------------------------------------------------------------ instance pass (T:210-222, 256-310)
+    @_shard_guard
     def instance_pass(self, inst_batch, jitter=None):
         """inst_batch: list of dicts (one per image) with rays (n,8), instances (n,) int, confidences (n,)."""
         c, m, r = self.config, self.model, self.renderer
         if c.instance_loss_mode not in ("slow_fast", "contrastive"):
             raise NotImplementedError(f"HotPathTrainer: instance_loss_mode={c.instance_loss_mode!r} is not wired (slow_fast and "
                                       "contrastive are; linear_assignment / ae_loss are the Panoptic-Lifting baselines)")
-        m.grad_flat[self.inst_range[0]:self.inst_range[1]].zero_()
+        self._pass_begin(self.inst_range)
         gv = m.named_grad_views()
         for img in inst_batch:
             rays = img["rays"]
@@ -385,6 +451,7 @@ class HotPathTrainer:
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
         if self.nosync:
             engine.reset_rows_limit(self.device)
+        self._pass_fold("inst_fast")
         self._allreduce(self.inst_range)
         self.opt_inst.step()
 

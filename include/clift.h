@@ -134,7 +134,23 @@ int clift_compact_fill(const float* w, const int* ray_start, int N, int S, float
  * pass; clift_scan_counts_capped writes min(total, cap) into it (limit_out = the bound address), clamps the offsets to
  * cap and records total in *overflow when total > cap (samples past the capacity are dropped -- memory-safe, and the
  * caller is expected to raise the capacity); clift_compact_fill_capped writes only rows < cap. */
-int clift_bind_rows_limit(const int* dev_limit);   /* NULL unbinds; one-time, synchronous */
+int clift_bind_rows_limit(const int* dev_limit);
+
+/* XCD-private gradient shards (ABI 12).  The kernels that end by adding a per-block partial of a small gradient tensor to memory (the weight
+ * gradients of the MLP layers, the K = 3 / output layers' gradients) are slowed by contention: all eight XCDs read-modify-write the same few
+ * cache lines at the same moment (8 - 20 us per launch).  With shards a block adds into the copy of the gradient range that belongs to its
+ * XCD, and the eight copies are folded into the gradients once per pass.  Record (40 bytes of device memory, little endian):
+ *   int64 lo      address of the first float of the sharded gradient range      int64 bytes   its length
+ *   int64 shard0  address of shard 0 (shard x at shard0 + x * stride; 8 shards, zero-initialised by the caller ONCE)
+ *   int64 stride  bytes between shards                                           int32 enabled, int32 pad
+ * clift_bind_grad_shards(record) publishes the record's address once per process (NULL unbinds).  A pass is bracketed, stream-ordered, by
+ * clift_grad_shards_begin(record, src, zero, zero_n): record := *src with enabled = 1, and zero_n floats at `zero` are cleared (the launch
+ * takes the place of the caller's gradient fill), and clift_grad_shards_fold(record, first, n, disable): gradients[first .. first + n) +=
+ * the eight shards, which are cleared again; disable != 0 ends the bracket.  Outside a bracket every kernel adds straight into the
+ * gradients (the autograd path, direct C callers: nothing changes for them). */
+int clift_bind_grad_shards(const void* dev_record);
+int clift_grad_shards_begin(void* dev_record, const void* dev_src, float* zero, long zero_n, clift_stream_t s);
+int clift_grad_shards_fold(void* dev_record, long first, long n, int disable, clift_stream_t s);   /* NULL unbinds; one-time, synchronous */
 int clift_scan_counts_capped(const int* n_active, int N, int* ray_start, int cap, int* limit_out, int* overflow,
                              clift_stream_t s);
 int clift_compact_fill_capped(const float* w, const int* ray_start, int N, int S, float thres, int* act_idx, int cap,

@@ -33,6 +33,47 @@ def _grads(tr):
     return {k: v.detach().clone() for k, v in tr.model.named_grad_views().items()}
 
 
+def test_gradient_shards_match_direct_accumulation():
+    """XCD-private gradient shards (include/clift.h, ABI 12; default on in the trainer): a main pass + instance pass with the MLP gradients
+    accumulated in eight per-XCD copies and folded once per pass give the gradients of the same passes with every kernel adding straight into
+    the gradient arena (``grad_shards: False``) -- to summation order (2e-5 of each tensor's scale) --, the shards are left all-zero and
+    switched off, and a backward outside a trainer pass (the autograd path) is not redirected afterwards."""
+    import contrastive_lift_amd as cl
+    from contrastive_lift_amd import engine, synthetic
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    res = {}
+    for on in (True, False):
+        model, renderer, pool = synthetic.make_scene(grid=48, num_classes=6, max_instances=3, seed=5, device=DEV, image=96, n_cams=2)
+        cfg = default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0, grad_shards=on)
+        tr = HotPathTrainer(model, renderer, cfg, current_epoch=4)
+        assert (tr._shards is not None) == on
+        batch = synthetic.make_batches(pool, 4096, 1024, 6, 9, seed=77, device=DEV)
+        g = torch.Generator().manual_seed(3)
+        jit = torch.rand(4096, generator=g).to(DEV)
+        jit_i = torch.rand(1024, generator=g).to(DEV)
+        p0 = model.param_flat.clone()
+        tr.main_pass(batch[0], jitter=jit, white_bg=False)
+        g_main = _grads(tr)
+        model.param_flat.copy_(p0)                                  # (the instance pass of both runs starts from the same weights)
+        tr.instance_pass(batch[1], jitter=jit_i)
+        g_inst = {k: v for k, v in _grads(tr).items() if k.startswith("render_instance_mlp.mlp")}
+        res[on] = (g_main, g_inst)
+        if on:
+            torch.cuda.synchronize()
+            assert float(tr._shards.abs().max()) == 0.0            # folded and cleared
+            assert int(engine.grad_shard_record(model.param_flat.device)[4]) == 0
+    n = 0
+    for part in (0, 1):
+        for k, a in res[True][part].items():
+            b = res[False][part][k]
+            scale = max(float(b.abs().max()), 1e-30)
+            assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((a - b).abs().max()) / scale)
+            n += 1
+    assert n >= 40 and any(float(v.abs().max()) > 0 for v in res[True][1].values())
+
+
+
+
 def test_chunked_and_lean_main_pass_match_whole_batch():
     tr, batch, jit = _setup(chunk=0)
     tr.main_pass(batch[0], jitter=jit, white_bg=False)
