@@ -15,6 +15,7 @@
 //   * operands swapped in the MFMA (weights first): a lane owns one output row; v_permlane32_swap pairs the two half-waves'
 //     4-column groups into 8 consecutive bf16 so that every store / mask read is 16 bytes per lane.
 #include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(layer_bf16)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_
         }
     }
     // lane (li, lh) holds gW rows n = 128 wn + 32 tn + 8 q + 4 lh + e, column k = 64 wk + 32 tk + li
+    g.C = grad_target(g.C); g.colsum = grad_target(g.colsum);                // (this XCD's shard when a pass has them on)
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream2d(GemmP g, int row
             if (g.colsum && slice == 0) csum += (bf16_pair_sum(yr[0].x) + bf16_pair_sum(yr[0].y)) + (bf16_pair_sum(yr[1].x) + bf16_pair_sum(yr[1].y));
         }
     }
+    g.C = grad_target(g.C); g.colsum = grad_target(g.colsum);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = 32 * wave + 8 * (r >> 2) + 4 * lh + (r & 3);
