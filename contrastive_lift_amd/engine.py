@@ -124,7 +124,12 @@ APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
 
 
 def _app_precision():
-    return _Precision(0) if (MLP_PRECISION == 1 and APP_FP32_IN_BF16) else _Precision(MLP_PRECISION)
+    # fp32x6 (2): only the 256 x 256 layers have persistent split kernels; the 128-wide appearance layers would fall to the TILED split kernel
+    # (gemm_split.hip), which is slower than the exact persistent kernels and -- seen with two processes sharing the GPU -- the one kernel of that
+    # mode whose results were disturbed by the other process's fp32x6 launches (profiles/r03_x6_notes.txt).  Exact fp32 there.
+    if MLP_PRECISION == 2 or (MLP_PRECISION == 1 and APP_FP32_IN_BF16):
+        return _Precision(0)
+    return _Precision(MLP_PRECISION)
 
 
 def act_dtype():
