@@ -380,7 +380,7 @@ extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, con
                                    float* out, int ldo, int out_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
     if (M <= 0) return 0;
-    if (Nout > 1024 || 256 % (Nout / 4) != 0) {
+    if (Nout > 1024 || 256 % (Nout / 4) != 0 || getenv("CLIFT_K3_ANY") != nullptr) {     // (CLIFT_K3_ANY: diagnostic switch, profiles/r03_x6_notes.txt)
         k_linear_k3_fwd_any<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
         return clift_check_launch("clift_linear_k3_fwd");
     }
