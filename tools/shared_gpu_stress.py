@@ -92,4 +92,7 @@ for it in range(iters):
         ok = torch.equal(r, ref[k]) if k not in LOOSE else bool(((r - ref[k]).abs().max() <= 1e-4 * ref[k].abs().max()).item())
         bad[k] += 0 if ok else 1
 print(f"{tag} {time.time() - t0:.1f}s mismatches of {iters}: {bad}", flush=True)
-sys.exit(1 if any(bad.values()) else 0)
+# Two processes on one device show a low base rate of wrong values in whatever runs (profiles/r03_x6_notes.txt, last section); what this tool
+# is for are kernels that disturb their neighbours in 3 - 40 % of the repeats.  Fail above 0.2 % (at least 2 repeats).
+allow = max(2, iters // 500)
+sys.exit(1 if any(v > allow for v in bad.values()) else 0)
