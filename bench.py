@@ -186,6 +186,7 @@ def main():
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
     real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd, real_first2_wgrad = (engine.gemm, engine.first2, engine.last2, engine.app_last2,
                                                                                               engine.first2_bwd, engine.first2_wgrad)
+    real_first2_x6 = engine.first2_x6
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -229,13 +230,17 @@ def main():
             return bracket("wgrad", 256, 256, M, 2.0 * M * 256 * 3, lambda: real_first2_wgrad(M, *args))
         engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
         engine.first2_bwd, engine.first2_wgrad = recorded_first2_bwd, recorded_first2_wgrad
+
+        def recorded_first2_x6(M, *args):                  # fp32x6 mode: the same fusion on the split kernel (clift_xyz_head_first2_x6_fwd)
+            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, lambda: real_first2_x6(M, *args))
+        engine.first2_x6 = recorded_first2_x6
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
             sync_all()
         finally:
             engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
-            engine.first2_bwd, engine.first2_wgrad = real_first2_bwd, real_first2_wgrad
+            engine.first2_bwd, engine.first2_wgrad, engine.first2_x6 = real_first2_bwd, real_first2_wgrad, real_first2_x6
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays

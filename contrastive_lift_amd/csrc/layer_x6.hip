@@ -83,8 +83,22 @@ static __device__ __forceinline__ void x8_wait_piece(int i) {
     if (i == 3) x6_wait_vm<(DGRAD ? X8_VM_DGRAD : X8_VM_FWD)[3]>();
 }
 
-template <bool DGRAD>
-__global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges) {
+// GEN (forward only): the layer is the SECOND layer of an xyz head and its input is generated, A[m][k] = relu(W0[k] . x_m + b0[k]) with K = 3
+// (tensoRF.py:475,576), instead of being written by a separate launch (clift_linear_k3_fwd) and read back.  Nothing of the row pipeline is
+// needed then: the 32 KB staging area only carries the POSITIONS (a wave DMAs the four it needs, 64 bytes, two tiles ahead into a parity
+// slot), the "read-back" of a staged row becomes one broadcast ds_read_b128 of its position -- the same LDS instruction in the same place, so
+// every counted lgkmcnt wait stays as it is -- and the lane computes its four k values (its 12 weights + 4 biases live in registers, 13 VALU)
+// where it would have unpacked them.  The activation itself is never written: the backward re-derives it (clift_xyz_head_first2_bwd / _wgrad).
+struct X6Gen {
+    const float* x4;      // (M, 4) normalised sample positions
+    const float* W0;      // (256, 3), row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+};
+
+template <bool DGRAD, bool GEN = false>
+__global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Gen gx) {
+    static_assert(!(DGRAD && GEN), "GEN is a forward form");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[X6_XCH + 2 * 16384];                // 160 KB, the only LDS object
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cg = wave & 3, kh = wave >> 2;       // column group, k-half (scalars)
@@ -106,6 +120,20 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * i, rend - 1);
         __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + 4 * lane, (lds_ptr_t)(lds + X6_RAW + (wave * 4 + i) * 1024), 16, 0, 0);
     };
+    // GEN: positions of this wave's rows wave + 8 i of tile t -> staging slot (t & 1): lanes 0..15 = (row i, component), the other lanes repeat them
+    const unsigned posa = lds0 + (unsigned)(X6_RAW + wave * 256);
+    auto pos_dma = [&](int t) {
+        const int gr = min(rbeg + t * X6_ROWS + wave + 8 * ((lane >> 2) & 3), rend - 1);
+        __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)gr * 4 + (lane & 3), (lds_ptr_t)(lds + X6_RAW + (t & 1) * 2048 + wave * 256), 4, 0, 0);
+    };
+    float gw0[4] = {0.f, 0.f, 0.f, 0.f}, gw1[4] = {0.f, 0.f, 0.f, 0.f}, gw2[4] = {0.f, 0.f, 0.f, 0.f}, gbb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (GEN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wr0 = gx.W0 + (size_t)(4 * lane + e) * gx.ldw0;
+            gw0[e] = wr0[0]; gw1[e] = wr0[1]; gw2[e] = wr0[2]; gbb[e] = gx.b0[4 * lane + e];
+        }
+    }
     const unsigned rawa = lds0 + (unsigned)(X6_RAW + wave * 4096 + lane * 16);
     // LDS address (stage 0, plane 0) of this lane's 8-byte piece of row wave + 8 i: (r & 15) = wave + 8 (i & 1); rows i and i + 2 differ by 8 KB
     unsigned wofs[2];
@@ -117,11 +145,30 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     f32x4 sp_x;
     unsigned sp_h0, sp_h1, sp_m0, sp_m1;
     float sp_r0, sp_r1, sp_r2, sp_r3, sp_s0, sp_s1, sp_s2, sp_s3;
-    auto raw_read = [&](int i) {
+    // `tn` = the tile whose rows are being split (GEN: selects the position slot)
+    auto raw_read = [&](int i, int tn) {
+        if (GEN) {
+            const unsigned a = posa + (unsigned)((tn & 1) * 2048);
+            if (i == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(sp_x) : "v"(a) : "memory");
+            if (i == 1) asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(sp_x) : "v"(a) : "memory");
+            if (i == 2) asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(sp_x) : "v"(a) : "memory");
+            if (i == 3) asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(sp_x) : "v"(a) : "memory");
+            return;
+        }
         if (i == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(sp_x) : "v"(rawa) : "memory");
         if (i == 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(sp_x) : "v"(rawa) : "memory");
         if (i == 2) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(sp_x) : "v"(rawa) : "memory");
         if (i == 3) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(sp_x) : "v"(rawa) : "memory");
+    };
+    // GEN: sp_x holds the row's position (after the wait that publishes it): replace it by the lane's four generated values
+    auto gen_values = [&]() {
+        if (!GEN) return;
+        const f32x4 p = sp_x;
+        sp_x[0] = fmaxf(fmaf(gw2[0], p[2], fmaf(gw1[0], p[1], fmaf(gw0[0], p[0], gbb[0]))), 0.f);      // same order as k_linear_k3_fwd
+        sp_x[1] = fmaxf(fmaf(gw2[1], p[2], fmaf(gw1[1], p[1], fmaf(gw0[1], p[0], gbb[1]))), 0.f);
+        sp_x[2] = fmaxf(fmaf(gw2[2], p[2], fmaf(gw1[2], p[1], fmaf(gw0[2], p[0], gbb[2]))), 0.f);
+        sp_x[3] = fmaxf(fmaf(gw2[3], p[2], fmaf(gw1[3], p[1], fmaf(gw0[3], p[0], gbb[3]))), 0.f);
+        asm volatile("" : "+v"(sp_x));
     };
     auto split_a = [&]() {
         sp_h0 = x6_pk(sp_x[0], sp_x[1]); sp_h1 = x6_pk(sp_x[2], sp_x[3]);
@@ -152,13 +199,17 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     };
 
     // ---- prologue: tile 0's rows -> staging -> split into stage 0; tile 1's rows on their way while the weights are prepared
+    if (GEN) { pos_dma(0); pos_dma(1); }
+    else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(0, i);
+        for (int i = 0; i < 4; ++i) dma_piece(0, i);
+    }
     x6_wait_vm<0>();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        raw_read(i);
+        raw_read(i, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sp_x) : : "memory");
+        gen_values();
         split_a(); split_b0(); split_b1(); split_c(0u, i); split_d0(); split_d1(); split_e(0u, i);
     }
     {   // what tile 0 "receives" (exchange parity 1, this wave's slot): zeros
@@ -168,8 +219,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         asm volatile("ds_write_b128 %0, %1 offset:1024" : : "v"(a), "v"(z) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!GEN) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(1, i);
+        for (int i = 0; i < 4; ++i) dma_piece(1, i);
+    }
 
     // ---- weight fragments of this wave's k-half: w?[j] = planes of W(n = ncol + li, k = 128 kh + 16 j + 8 lh .. +7)
     u32x4 wh[8], wm[8], wl[8];
@@ -269,12 +322,15 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             // ---- gap 0
             if (j + 1 < 8) rd(j + 1, fa[(j + 1) & 1]);
             if (even) {
-                x8_wait_piece<DGRAD>(i);
-                raw_read(i);
+                // GEN: the positions of tile t+1 left during tile t-1 (one DMA, before that tile's two stores); younger than it at any of the four
+                // read-backs: those two stores, this tile's position DMA (from i = 2 on) and first store (i = 3) -- vmcnt(2) covers all four
+                if (GEN) x6_wait_vm<2>(); else x8_wait_piece<DGRAD>(i);
+                raw_read(i, t + 1);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");
                 else if (j == 7) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(sp_x) : : "memory");
                 else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(sp_x) : : "memory");
+                gen_values();
                 split_a();
             }
             acc0 = x6_mfma(wh[j], f[0], acc0);
@@ -299,8 +355,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             acc0 = x6_mfma(wm[j], f[1], acc0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 3
-            if (even) { if (i > 0) dma_piece(t + 2, i - 1); }
-            else split_c(nxt, i);
+            if (even) {
+                if (GEN) { if (i == 1) pos_dma(t + 2); }
+                else if (i > 0) dma_piece(t + 2, i - 1);
+            } else split_c(nxt, i);
             acc1 = x6_mfma(wm[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 4
@@ -312,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             // ---- gap 5
             if (!even) {
                 if (j < 7) split_d1();
-                else { split_e(nxt, 3); dma_piece(t + 2, 3); }
+                else { split_e(nxt, 3); if (!GEN) dma_piece(t + 2, 3); }
             }
             acc1 = x6_mfma(wl[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
@@ -345,7 +403,27 @@ int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int rpr = cdiv(cdiv(p.M, nranges), X6_ROWS) * X6_ROWS;
     const int nr = cdiv(p.M, rpr);
     const int grid = 16 * cdiv(nr, 8);                               // block b: half (b >> 3) & 1 of range (b & 7) + 8 (b >> 4)
-    if (b_trans) k_layer_x6<true><<<grid, 512, 0, st>>>(p, rpr, nr);
-    else k_layer_x6<false><<<grid, 512, 0, st>>>(p, rpr, nr);
+    const X6Gen none = {nullptr, nullptr, 0, nullptr};
+    if (b_trans) k_layer_x6<true><<<grid, 512, 0, st>>>(p, rpr, nr, none);
+    else k_layer_x6<false><<<grid, 512, 0, st>>>(p, rpr, nr, none);
     return clift_check_launch("clift_gemm(fp32x6 layer)");
+}
+
+// First TWO layers of an xyz head in one launch, fp32x6 arithmetic for the 256 x 256 layer (the K = 3 layer is exact fp32 FMAs as in
+// clift_linear_k3_fwd): h2 = relu(W1 relu(W0 x + b0) + b1)   (tensoRF.py:475-478, 576-579).  The first layer's activation is not written.
+extern "C" int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1, const float* b1,
+                                            int M, float* h2, int ldh2, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)x4) & 15) == 0 && (((uintptr_t)W1) & 15) == 0 && (((uintptr_t)h2) & 15) == 0 && ldw1 % 4 == 0 && ldw1 >= 256 &&
+                      ldh2 % 4 == 0 && ldh2 >= 256 && ldw0 >= 3,
+                  "clift_xyz_head_first2_x6_fwd: x4 / W1 / h2 must be 16-byte aligned, pitches >= 256 and multiples of 4");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = nullptr; p.lda = 256; p.B = W1; p.ldb = ldw1; p.C = h2; p.ldc = ldh2; p.bias = b1; p.act = 1;
+    const int tiles = cdiv(M, X6_ROWS);
+    const int pairs = clift_persistent_cus() / 2;
+    const int nranges = tiles < pairs ? tiles : pairs;
+    const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
+    const int nr = cdiv(M, rpr);
+    k_layer_x6<false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0});
+    return clift_check_launch("clift_xyz_head_first2_x6_fwd");
 }

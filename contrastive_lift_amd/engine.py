@@ -333,6 +333,11 @@ def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
          stream())
 
 
+def first2_x6(M, xa, W0, b0, W1, b1, h2):
+    """One clift_xyz_head_first2_x6_fwd launch (fp32x6 mode): h2 = relu(W1 relu(W0 x + b0) + b1), the first activation not written."""
+    call("clift_xyz_head_first2_x6_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h2), 256, stream())
+
+
 def first2_wgrad(M, d, W0, b0, xa, gW1, gb1):
     """One clift_xyz_head_first2_wgrad launch: gW1 += d^T relu(xa[:, :3] W0^T + b0), gb1 += column sums of d."""
     call("clift_xyz_head_first2_wgrad", ptr(d), d.shape[1], ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW1), _pitch(gW1), ptr(gb1), stream())
@@ -372,6 +377,16 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
         first2(M, xa, W0, b0, W1, b1, h1, h)
         acts += [h1, h]
+        rest = layers[2:-1]
+    elif (FUSE_FIRST2 and MLP_PRECISION == 2 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
+            and (not keep_first or (FUSE_FIRST2_BWD and DROP_FIRST_ACT)) and os.environ.get("CLIFT_NO_PERSISTENT") is None
+            and os.environ.get("CLIFT_X6_TILED") is None):
+        # fp32x6: the same fusion with the 256 x 256 layer on the split kernels; the first activation is never written (the backward, if any,
+        # re-derives it: first2_bwd / first2_wgrad)
+        W1, b1 = layers[1]
+        h = torch.empty((M, 256), dtype=torch.float32, device=dev)
+        first2_x6(M, xa, W0, b0, W1, b1, h)
+        acts += [None, h]
         rest = layers[2:-1]
     else:
         h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)

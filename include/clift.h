@@ -233,6 +233,11 @@ int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, const float* b
  * activation when a backward pass will need it.  Results are bit-identical to clift_linear_k3_fwd followed by clift_gemm. */
 int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
                               const float* b1, int M, float* h1, int ldh1, float* h2, int ldh2, clift_stream_t s);
+/* clift_xyz_head_first2_fwd in fp32x6 arithmetic (ABI 13): the 256 x 256 layer as six bf16 products per fp32 product on the bf16 matrix
+ * cores (csrc/layer_x6.hip), the K = 3 layer exact; the first layer's activation is never written (the backward does not need it:
+ * clift_xyz_head_first2_bwd / clift_xyz_head_first2_wgrad).  Results within 1e-6 (row-max relative) of clift_xyz_head_first2_fwd. */
+int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
+                                 const float* b1, int M, float* h2, int ldh2, clift_stream_t s);
 /* Backward of the first TWO layers of an xyz head in one launch (tensoRF.py:475-478, 576-579; fp32, ABI 11).  dH2 (M, ldd) is the
  * gradient at the second layer's output, already masked by that layer's ReLU; W0 (256, 3) / b0 the first layer; x4 (M, 4) the sample
  * positions.  The second layer's input gradient dH1 = (W0 x + b0 > 0) . (dH2 W1) is formed tile by tile and consumed in place:

@@ -349,6 +349,28 @@ def test_head_backward_without_the_first_activation_matches_the_stored_form():
             assert err < 2e-5, (tuple(x.shape), err)
 
 
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 4097, 66001, 249000])
+def test_first2_x6_forward_is_the_unfused_pair_bit_for_bit(M):
+    """clift_xyz_head_first2_x6_fwd (ABI 13): the K = 3 layer generated inside the fp32x6 layer kernel.  The generated values are the bits
+    clift_linear_k3_fwd writes (same FMA order) and the split / MFMA path is the same, so the result is BIT-IDENTICAL to that launch followed by
+    clift_gemm(precision 2) -- and within 2e-6 (row-max relative) of float64."""
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    t, h1, _, _ = _first2_case(M, 3000 + M)
+    g = torch.Generator().manual_seed(9)
+    b1 = (0.1 * torch.randn(256, generator=g)).to(DEV)
+    h2 = torch.full((M, 256), -7.0, device=DEV)
+    engine.first2_x6(M, t["x4"], t["W0"], t["b0"], t["W1"], b1, h2)
+    ref = torch.empty(M, 256, device=DEV)
+    with engine._Precision(2):
+        engine.gemm(M, 256, 256, h1, 256, t["W1"], 256, ref, 256, bias=b1, act=1)
+    torch.cuda.synchronize()
+    assert torch.equal(h2, ref)
+    r64 = torch.relu(h1[:M].double() @ t["W1"].double().t() + b1.double())
+    err = float(((h2.double() - r64).abs() / r64.abs().amax(1, keepdim=True).clamp_min(1e-30)).max())
+    assert err <= 2e-6, err
+
+
 def test_fp32x6_mode_full_forward_backward_vs_oracle():
     """mlp_dtype fp32x6 through the renderer, C = 22 mid-size, against the oracle in FLOAT64, next to the exact-fp32 path on the same inputs:
     outputs 1e-3 relative; per gradient tensor the number of entries outside the band (2e-3 relative + 1e-4 of the scale: these are samples
