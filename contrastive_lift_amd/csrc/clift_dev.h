@@ -96,12 +96,15 @@ struct GradShardDesc {
 };
 static __device__ const GradShardDesc* g_grad_shard_desc = nullptr;
 // block-uniform: where this block adds its partial of the gradient tensor at `p`
+// (returned as `p + shift`, not as a pointer rebuilt from an integer: the compiler then still knows it is GLOBAL memory and emits
+// global_atomic_add_f32 -- a pointer made from an integer is generic, and the flush became flat_atomic_add_f32)
 __device__ __forceinline__ float* grad_target(float* p) {
     const GradShardDesc* d = g_grad_shard_desc;
     if (d == nullptr || p == nullptr) return p;
     const long off = (long)(uintptr_t)p - d->lo;
     if (!d->enabled || off < 0 || off >= d->bytes) return p;
-    return reinterpret_cast<float*>((uintptr_t)(d->shard0 + (long)(blockIdx.x & 7) * d->stride + off));
+    const long shift = d->shard0 + (long)(blockIdx.x & 7) * d->stride - d->lo;          // bytes from the gradient range to this XCD's shard
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + shift);
 }
 #define CLIFT_ROWS_LIMIT_BINDER(tu) \
     void clift_bind_rows_limit_##tu(const int* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_limit), &p, sizeof(p)); } \

@@ -389,6 +389,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(recv[0]), "+v"(recv[1]) : : "memory");
     }
     // (the loop's stores wrote the results of tiles 0 .. ntiles - 2 during tiles 1 .. ntiles - 1; prev now holds nothing unsaved)
+    // The DMAs of the two tiles past the end (clamped rows) were issued unconditionally: a wave must not end with them in flight (see layer_x6w.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     finish();
 #pragma unroll
     for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(g.C + (size_t)m_done * g.ldc + fcol + 8 * q) = prev[q];

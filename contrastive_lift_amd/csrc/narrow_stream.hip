@@ -360,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
             }
         }
     }
+    if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the mask prefetch of the tile past the end: a wave must not end with loads in flight
     if (WG) {
         // lane (li, lh) holds gW rows c = 8 q + 4 lh + e, column 32 wave + li
         gW = grad_target(gW); gb = grad_target(gb);
