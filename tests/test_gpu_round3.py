@@ -289,6 +289,29 @@ def test_first2_backward_kernels_with_padded_pitches():
     assert float((gb1.double().cpu() - t["d"].double().cpu().sum(0)).abs().max()) / float(t["d"].double().cpu().sum(0).abs().max()) < 2e-5
 
 
+def test_fused_head_entry_points_reject_bad_arguments():
+    """Error behaviour of the ABI 11 - 13 entry points: misaligned rows, short pitches and missing outputs come back as a non-zero return with
+    a message (CliftError in the binding), nothing is launched."""
+    from contrastive_lift_amd import _lib
+    from contrastive_lift_amd._lib import call, ptr, stream
+    M = 100
+    d = torch.zeros(M, 256, device=DEV); W = torch.zeros(256, 256, device=DEV); W0 = torch.zeros(256, 3, device=DEV); b0 = torch.zeros(256, device=DEV)
+    x4 = torch.zeros(M + 1, 4, device=DEV); gW0 = torch.zeros(256, 3, device=DEV); gb0 = torch.zeros(256, device=DEV); gW1 = torch.zeros(256, 256, device=DEV)
+    h2 = torch.zeros(M, 256, device=DEV)
+    with pytest.raises(_lib.CliftError, match="first2_bwd"):            # dH2 pitch below 256
+        call("clift_xyz_head_first2_bwd", ptr(d), 128, ptr(W), 256, ptr(W0), 3, ptr(b0), ptr(x4), M, ptr(gW0), 3, ptr(gb0), stream())
+    with pytest.raises(_lib.CliftError, match="first2_bwd"):            # no gradient output
+        call("clift_xyz_head_first2_bwd", ptr(d), 256, ptr(W), 256, ptr(W0), 3, ptr(b0), ptr(x4), M, None, 3, ptr(gb0), stream())
+    with pytest.raises(_lib.CliftError, match="first2_wgrad"):          # positions not 16-byte aligned
+        call("clift_xyz_head_first2_wgrad", ptr(d), 256, ptr(W0), 3, ptr(b0), x4.data_ptr() + 4, M, ptr(gW1), 256, None, stream())
+    with pytest.raises(_lib.CliftError, match="first2_x6_fwd"):         # output pitch not a multiple of 4
+        call("clift_xyz_head_first2_x6_fwd", ptr(x4), ptr(W0), 3, ptr(b0), ptr(W), 256, ptr(b0), M, ptr(h2), 258, stream())
+    with pytest.raises(_lib.CliftError, match="grad_shards"):
+        call("clift_grad_shards_begin", None, None, None, 0, stream())
+    assert float(gW0.abs().max()) == 0.0 and float(gW1.abs().max()) == 0.0
+    call("clift_xyz_head_first2_bwd", ptr(d), 256, ptr(W), 256, ptr(W0), 3, ptr(b0), ptr(x4), 0, ptr(gW0), 3, ptr(gb0), stream())      # M = 0: a no-op
+
+
 @pytest.mark.parametrize("M", [1, 63, 64, 65, 4097, 66001, 249000])
 def test_first2_wgrad_against_fp64_and_the_streamed_form(M):
     """clift_xyz_head_first2_wgrad (ABI 11): the second layer's weight / bias gradient with its input, relu(W0 x + b0), generated in-kernel,
