@@ -123,6 +123,11 @@ def exact_fp32():
 APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
 
 
+# Experiment switch (CLIFT_HYBRID_X6=1): the exact mode's fused kernels (K = 3 layer / output layer in-kernel, fused first-two-layers backward)
+# with the REMAINING plain 256 x 256 forward and masked-dgrad launches on the fp32x6 kernels -- what a default built from both would cost.
+HYBRID_X6 = os.environ.get("CLIFT_HYBRID_X6") is not None
+
+
 def _app_precision():
     # fp32x6 (2): only the 256 x 256 layers have persistent split kernels; the 128-wide appearance layers would fall to the TILED split kernel
     # (gemm_split.hip), which is slower than the exact persistent kernels and -- seen with two processes sharing the GPU -- the one kernel of that
@@ -180,6 +185,8 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     # which is faster than the tiled split kernel the library would pick for it
     x6 = N == 256 and K == 256 and not a_trans and not accumulate and not c_trans
     g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6) else 0
+    if HYBRID_X6 and MLP_PRECISION == 0 and x6 and A.dtype == torch.float32:
+        g.precision = 2          # experiment switch: exact mode with the un-fused 256 x 256 forward / dgrad launches on the split kernels
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
     if g.precision == 2:
