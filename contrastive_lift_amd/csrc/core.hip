@@ -41,6 +41,7 @@ void clift_bind_rows_limit_layer_n128(const int* p);
 void clift_bind_rows_limit_narrow_stream(const int* p);
 void clift_bind_rows_limit_layer_x6(const int* p);
 void clift_bind_rows_limit_layer_bf16(const int* p);
+void clift_bind_rows_limit_layer_x6w(const int* p);
 
 extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_march(dev_limit);
@@ -51,6 +52,7 @@ extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_narrow_stream(dev_limit);
     clift_bind_rows_limit_layer_x6(dev_limit);
     clift_bind_rows_limit_layer_bf16(dev_limit);
+    clift_bind_rows_limit_layer_x6w(dev_limit);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { clift_set_error("clift_bind_rows_limit: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -64,6 +66,7 @@ void clift_bind_grad_shards_layer_n128(const void* p);
 void clift_bind_grad_shards_narrow_stream(const void* p);
 void clift_bind_grad_shards_layer_x6(const void* p);
 void clift_bind_grad_shards_layer_bf16(const void* p);
+void clift_bind_grad_shards_layer_x6w(const void* p);
 
 extern "C" int clift_bind_grad_shards(const void* dev_desc) {
     clift_bind_grad_shards_march(dev_desc);
@@ -74,6 +77,7 @@ extern "C" int clift_bind_grad_shards(const void* dev_desc) {
     clift_bind_grad_shards_narrow_stream(dev_desc);
     clift_bind_grad_shards_layer_x6(dev_desc);
     clift_bind_grad_shards_layer_bf16(dev_desc);
+    clift_bind_grad_shards_layer_x6w(dev_desc);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { clift_set_error("clift_bind_grad_shards: %s", hipGetErrorString(e)); return 2; }
     return 0;

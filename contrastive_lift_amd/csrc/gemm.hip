@@ -244,7 +244,12 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         ((!h->b_trans && !h->mask) ||
          (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0)))
         return clift_layer_x6_launch(p, h->b_trans, st);
-    // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); everything else (wgrad: both operands streamed) stays exact fp32
+    // fp32x6 weight gradient of the 256 x 256 layers (layer_x6w.hip; CLIFT_X6_WGRAD=0 keeps the exact quadrant kernel)
+    if (h->precision == 2 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
+        h->act == 0 && h->lda % 4 == 0 && h->ldb % 4 == 0 && (((uintptr_t)h->A) & 15) == 0 && (((uintptr_t)h->B) & 15) == 0 &&
+        !(getenv("CLIFT_X6_WGRAD") && getenv("CLIFT_X6_WGRAD")[0] == '0'))
+        return clift_wgrad_x6_launch(p, st);
+    // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); any other shape takes the tiled split kernel
     if (h->precision == 2 && !h->a_trans && !h->accumulate && splits == 1 && !h->c_trans && (long)h->N * h->K <= (1L << 22)) {
         const long need = clift_gemm_split_workspace_bytes(h->N, h->K);
         CLIFT_REQUIRE(h->workspace != nullptr && h->workspace_bytes >= need && (((uintptr_t)h->workspace & 15) == 0),

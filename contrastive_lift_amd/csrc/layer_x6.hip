@@ -100,6 +100,9 @@ template <bool DGRAD, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Gen gx) {
     static_assert(!(DGRAD && GEN), "GEN is a forward form");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[X6_XCH + 2 * 16384];                // 160 KB, the only LDS object
+    // register ballast: the wave allocates its whole 256-register budget, so that two of them fill the SIMD's file and no wave of another kernel
+    // (another PROCESS sharing the device) is scheduled beside this MFMA stream -- see layer_x6w.hip for what happens otherwise
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cg = wave & 3, kh = wave >> 2;       // column group, k-half (scalars)
     const int b = blockIdx.x, half = (b >> 3) & 1, range = (b & 7) + 8 * (b >> 4);

@@ -1,0 +1,227 @@
+// layer_x6w.hip -- weight gradient of the 256 x 256 hidden layers, fp32-FAITHFUL on the bf16 matrix cores ("fp32x6"):
+//     gW[n][k] += sum_m dY[m][n] X[m][k],   gb[n] += sum_m dY[m][n]            (dY, X: M x 256 fp32, row-major)
+// as six v_mfma_f32_32x32x16_bf16 products of exactly three-way-split operands (see layer_x6.hip for the arithmetic).  Unlike the forward /
+// dgrad kernels this one has NO output stream -- the 128 x 128 partial of a workgroup is flushed once, with atomics -- so the format's
+// advantage is not eaten by HBM writes (profiles/r03_x6_notes.txt).
+//
+// Shape: 64 row ranges x 4 quadrant workgroups (128 n x 128 k each; the four of a range have block ids 8 apart = one XCD, so dY / X come
+// from HBM once), EIGHT waves = 4 n-tiles x 2 pairs of k-tiles, two per SIMD.  BOTH operands are streamed, and the MFMA contraction index is
+// the ROW index m, so a fragment is 8 consecutive rows of one column.  The split does the transposition: rows travel by LDS-DMA into fp32
+// staging (wave v owns rows 4 v .. 4 v + 3 of a 32-row tile, both operands, 4 KB), each lane reads COLUMN runs of its wave's 4 rows
+// (4 x ds_read_b32, lanes along the columns: conflict-free), splits the 4 values (22 VALU) and writes three 8-byte pieces into TRANSPOSED
+// bf16 plane images [operand][plane][column][32 m], column pitch 80 bytes (fragment reads and the writes conflict-free: 80 = 5 x 16).
+// A wave multiplies the dY fragments of its 32 n against the X fragments of its two k-tiles: 24 MFMAs per tile in two groups of 12 that
+// alternate between two accumulators.  Rows past the end of a range are zeroed in the split (a clamped copy would be counted twice).
+// Memory instructions per tile and wave: X rows x 2 (group 0), dY rows x 2 (group 1) -- every wait is vmcnt(2).
+//
+// GPU sharing.  A first build of this kernel (139 registers per wave) made ANOTHER process's kernels return wrong values whenever the two
+// shared the device: bisected with a standalone copy (profiles/r03_x6_notes.txt) to its bf16 MFMAs -- not its LDS-DMA, not its atomics, not
+// its end -- and to CO-RESIDENCY: with 2 x 176 of a SIMD's 512 registers taken, waves of the other process' small kernels were scheduled onto the
+// same SIMD beside the MFMA stream and came back with wrong lanes 48..63 (59 % of the neighbour's launches; one process alone: never).  The
+// remedy is a register ballast: every wave claims 256 registers (one asm clobber of v255), two of them fill the SIMD's file and nothing else
+// fits beside them -- 0 wrong results in 43 000 launches of the same neighbour, same speed.  k_layer_x6 carries the same ballast.
+#include "gemm_common.h"
+CLIFT_ROWS_LIMIT_BINDER(layer_x6w)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int XW_ROWS = 32;
+constexpr int XW_PITCH = 80;                        // bytes per column of a transposed plane image: 32 m x 2 B + 16
+constexpr int XW_PLANE = 128 * XW_PITCH;            // 10240
+constexpr int XW_STAGE = 6 * XW_PLANE;              // [operand 0 = dY, 1 = X][plane]: 61440
+constexpr int XW_RAW = 2 * XW_STAGE;                // fp32 staging: wave w: [operand][8 rows][512 B] = 8 KB
+
+static __device__ __forceinline__ unsigned xw_pk(float lo, float hi) {
+    bf16x2 p;
+    p[0] = (__bf16)lo; p[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, p);
+}
+static __device__ __forceinline__ float xw_lo(unsigned p) { return __uint_as_float(p << 16); }
+static __device__ __forceinline__ float xw_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+static __device__ __forceinline__ f32x16 xw_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[XW_RAW + 8 * 4096];                 // 152 KB, the only LDS object
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (see the header): the wave allocates the whole 256-register budget
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3, kp = wave >> 2;       // n-tile, pair of k-tiles (scalars)
+    const int b = blockIdx.x, quad = (b >> 3) & 3, qn = quad >> 1, qk = quad & 1, range = (b & 7) + 8 * (b >> 5);
+    if (rows_limited()) {
+        g.K = limit_rows(g.K);
+        rows_per_range = ((g.K + 63) / 64 + XW_ROWS - 1) / XW_ROWS * XW_ROWS;
+    }
+    const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + XW_ROWS - 1) / XW_ROWS;
+    const float* __restrict__ Y = g.A + 128 * qn;       // dY columns of this quadrant's n-half
+    const float* __restrict__ X = g.B + 128 * qk;       // X columns of its k-half
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+
+    // ---- rows by LDS-DMA: piece j (0, 1) of operand o = rows 2 j, 2 j + 1 of this wave's four (rows 4 wave .. 4 wave + 3 of the tile), 512 B each
+    auto dma = [&](int t, int o, int j) {
+        const int rr = 2 * j + lh;
+        const int row = min(rbeg + t * XW_ROWS + 4 * wave + rr, rend - 1);       // (rows past the range: any valid row; the split zeroes them)
+        const float* src = (o ? X + (size_t)row * g.ldb : Y + (size_t)row * g.lda) + 4 * li;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + o * 2048 + j * 1024), 16, 0, 0);
+    };
+    // ---- a column run: the 4 rows of this wave at column lane + 64 u of operand o
+    float v[4];
+    auto run_read = [&](int o, int u) {
+        const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + o * 2048 + (lane + 64 * u) * 4);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v[0]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v[1]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(v[2]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(v[3]) : "v"(a) : "memory");
+    };
+    auto run_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory"); };
+    float bs0 = 0.f, bs1 = 0.f;                         // bias gradient of columns lane, lane + 64 (this wave's rows)
+    unsigned sh[2], sm[2], sl[2];
+    auto run_mask = [&](int valid, int o, int u) {      // rows at or past `valid` contribute nothing (a clamped copy would be counted twice)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (4 * wave + e < valid) ? v[e] : 0.f;
+        if (o == 0) {
+            const float s = (v[0] + v[1]) + (v[2] + v[3]);
+            if (u == 0) bs0 += s; else bs1 += s;
+        }
+    };
+    auto run_split = [&](int q) {                       // pair q (rows 2 q, 2 q + 1 of the run)
+        const float a = v[2 * q], c = v[2 * q + 1];
+        unsigned h = xw_pk(a, c);
+        asm volatile("" : "+v"(h));
+        const float ra = a - xw_lo(h), rc = c - xw_hi(h);
+        unsigned m = xw_pk(ra, rc);
+        asm volatile("" : "+v"(m));
+        sh[q] = h; sm[q] = m; sl[q] = xw_pk(ra - xw_lo(m), rc - xw_hi(m));
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto run_write = [&](unsigned stage, int o, int u) {
+        const unsigned a = lds0 + stage + (unsigned)(o * 3 * XW_PLANE + (lane + 64 * u) * XW_PITCH + wave * 8);
+        const u32x2 dh = {sh[0], sh[1]}, dm = {sm[0], sm[1]}, dl = {sl[0], sl[1]};
+        asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(dh) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:10240" : : "v"(a), "v"(dm) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:20480" : : "v"(a), "v"(dl) : "memory");
+    };
+    auto valid_of = [&](int t) { return rend - (rbeg + t * XW_ROWS); };
+
+    // ---- prologue: tile 0 -> staging -> stage 0; tile 1's rows on their way (X first, then dY: the order the loop keeps)
+    dma(0, 1, 0); dma(0, 1, 1); dma(0, 0, 0); dma(0, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = r < 2 ? 1 : 0, u = r & 1;
+        run_read(o, u); run_wait(); run_mask(valid_of(0), o, u); run_split(0); run_split(1); run_write(0u, o, u);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma(1, 1, 0); dma(1, 1, 1); dma(1, 0, 0); dma(1, 0, 1);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    // fragment addresses: column (32 wn | 32 (2 kp + x)) + li, rows 16 s + 8 lh
+    const unsigned fa = lds0 + (unsigned)((32 * wn + li) * XW_PITCH + 16 * lh);
+    const unsigned fb = lds0 + (unsigned)(3 * XW_PLANE + (64 * kp + li) * XW_PITCH + 16 * lh);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned cur = (unsigned)((t & 1) * XW_STAGE), nxt = (unsigned)(((t + 1) & 1) * XW_STAGE);
+        const int valid = valid_of(t + 1);
+        u32x4 A[2][3], B[2][2][3];                      // dY fragments of k-step s; X fragments of k-step s, k-tiles 2 kp, 2 kp + 1
+        auto rd = [&](int s) {
+            const unsigned a = fa + cur + (unsigned)(32 * s);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(A[s][0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(A[s][1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A[s][2]) : "v"(a) : "memory");
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const unsigned c = fb + cur + (unsigned)(x * 32 * XW_PITCH + 32 * s);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(B[s][x][0]) : "v"(c) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(B[s][x][1]) : "v"(c) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(B[s][x][2]) : "v"(c) : "memory");
+            }
+        };
+        rd(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int o = s == 0 ? 1 : 0;                                        // the operand whose two runs are split during this group: X, then dY
+            u32x4 (&a)[3] = A[s];
+            u32x4 (&b0)[3] = B[s][0];
+            u32x4 (&b1)[3] = B[s][1];
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) rd(1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // this operand's rows (DMA'd during the previous tile) have landed
+            run_read(o, 0);
+            acc[0] = xw_mfma(a[0], b0[0], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = xw_mfma(a[0], b1[0], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_wait();
+            run_mask(valid, o, 0);
+            acc[0] = xw_mfma(a[0], b0[1], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_split(0);
+            acc[1] = xw_mfma(a[0], b1[1], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_split(1);
+            acc[0] = xw_mfma(a[1], b0[0], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_write(nxt, o, 0);
+            run_read(o, 1);
+            acc[1] = xw_mfma(a[1], b1[0], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = xw_mfma(a[1], b0[1], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_wait();
+            run_mask(valid, o, 1);
+            acc[1] = xw_mfma(a[1], b1[1], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_split(0);
+            acc[0] = xw_mfma(a[0], b0[2], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_split(1);
+            acc[1] = xw_mfma(a[0], b1[2], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            run_write(nxt, o, 1);
+            acc[0] = xw_mfma(a[2], b0[0], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            dma(t + 2, o, 0); dma(t + 2, o, 1);                                  // both runs of this operand are read: refill its rows with tile t + 2's
+            acc[1] = xw_mfma(a[2], b1[0], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lane (li, lh) holds gW rows n = 128 qn + 32 wn + 8 q + 4 lh + e, column k = 128 qk + 64 kp + 32 x + li
+    // The loop issues its LDS-DMA unconditionally (clamped rows past the end), so the newest ones are still in flight here.  A wave must NOT end with
+    // vector-memory loads outstanding: the hardware frees its registers at s_endpgm and the late data beats land in whatever wave owns them next
+    // (seen as wrong lanes 48..63 in the next kernel to start on the CU -- with two processes on the device that is immediately; r03_x6_notes.txt).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.C = grad_target(g.C); g.colsum = grad_target(g.colsum);            // (this XCD's shard when a pass has them on)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 128 * qn + 32 * wn + 8 * (r >> 2) + 4 * lh + (r & 3), k = 128 * qk + 64 * kp + 32 * x + li;
+            unsafeAtomicAdd(g.C + (size_t)n * g.ldc + k, acc[x][r]);
+        }
+    if (g.colsum && qk == 0) {                          // both k-quadrants saw the same dY: one of them adds the bias gradient
+        unsafeAtomicAdd(g.colsum + 128 * qn + lane, bs0);
+        unsafeAtomicAdd(g.colsum + 128 * qn + 64 + lane, bs1);
+    }
+}
+
+int clift_wgrad_x6_launch(const GemmP& p, hipStream_t st) {
+    const int rpr = cdiv(cdiv(p.K, 64), XW_ROWS) * XW_ROWS;
+    k_wgrad_x6<<<256, 512, 0, st>>>(p, rpr);
+    return clift_check_launch("clift_gemm(fp32x6 wgrad)");
+}

@@ -123,6 +123,9 @@ def exact_fp32():
 APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
 
 
+X6_WGRAD = os.environ.get("CLIFT_X6_WGRAD", "1") != "0"       # fp32x6 mode: the 256 x 256 weight gradients on the split kernel as well
+
+
 # Experiment switch (CLIFT_HYBRID_X6=1): the exact mode's fused kernels (K = 3 layer / output layer in-kernel, fused first-two-layers backward)
 # with the REMAINING plain 256 x 256 forward and masked-dgrad launches on the fp32x6 kernels -- what a default built from both would cost.
 HYBRID_X6 = os.environ.get("CLIFT_HYBRID_X6") is not None
@@ -184,12 +187,15 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, weight gradients -- stays on its exact-fp32 persistent kernel,
     # which is faster than the tiled split kernel the library would pick for it
     x6 = N == 256 and K == 256 and not a_trans and not accumulate and not c_trans
-    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6) else 0
+    # ... and their weight gradients (csrc/layer_x6w.hip; CLIFT_X6_WGRAD=0 keeps the exact quadrant kernel)
+    x6w = (X6_WGRAD and a_trans and b_trans and M == 256 and N == 256 and K >= 4096 and accumulate and not c_trans and bias is None and mask is None
+           and not act and int(lda) % 4 == 0 and int(ldb) % 4 == 0 and A.dtype == torch.float32 and B.dtype == torch.float32)
+    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6 or x6w) else 0
     if HYBRID_X6 and MLP_PRECISION == 0 and x6 and A.dtype == torch.float32:
         g.precision = 2          # experiment switch: exact mode with the un-fused 256 x 256 forward / dgrad launches on the split kernels
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
-    if g.precision == 2:
+    if g.precision == 2 and not x6w:
         # the persistent split kernel takes 16-byte aligned rows; anything else (odd output pitch ...) goes to the library's tiled split
         # kernel, which needs a workspace for the split weight planes
         persistent = (int(lda) % 4 == 0 and int(ldc) % 4 == 0 and g.C % 16 == 0 and (mask is None or (int(ldmask) % 4 == 0 and g.mask % 16 == 0))

@@ -394,6 +394,33 @@ def test_first2_x6_forward_is_the_unfused_pair_bit_for_bit(M):
     assert err <= 2e-6, err
 
 
+@pytest.mark.parametrize("M", [4096, 4097, 5000, 66001, 249000])
+def test_fp32x6_weight_gradient_against_fp64(M):
+    """csrc/layer_x6w.hip (fp32x6 mode): gW += dY^T X, gb += column sums of dY for the 256 x 256 layers as six bf16 products of exactly split
+    operands, against float64 next to the exact quadrant kernel: error (of the largest entry) <= 2e-6 and <= 4x the exact kernel's + 2e-7;
+    accumulating (a second launch doubles the result)."""
+    from contrastive_lift_amd import engine
+    assert engine.X6_WGRAD
+    g = torch.Generator().manual_seed(40 + M)
+    dY = (torch.randn(M, 256, generator=g) * (torch.rand(M, 256, generator=g) > 0.5) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)
+    X = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)
+    ref = dY.double().cpu().t() @ X.double().cpu()
+    rb = dY.double().cpu().sum(0)
+    out = {}
+    for mode in ("fp32", "fp32x6"):
+        gW, gb = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+        with engine._Precision(engine._PRECISIONS[mode]):
+            engine.wgrad(256, 256, M, dY, 256, X, 256, gW, gb)
+            if mode == "fp32x6":
+                gW2, gb2 = gW.clone(), gb.clone()
+                engine.wgrad(256, 256, M, dY, 256, X, 256, gW2, gb2)
+        torch.cuda.synchronize()
+        out[mode] = (float((gW.double().cpu() - ref).abs().max()) / float(ref.abs().max()), float((gb.double().cpu() - rb).abs().max()) / float(rb.abs().max()))
+    assert out["fp32x6"][0] <= 2e-6 and out["fp32x6"][0] <= 4 * out["fp32"][0] + 2e-7, out
+    assert out["fp32x6"][1] <= 4e-6, out
+    assert float((gW2.double().cpu() - 2 * ref).abs().max()) / float(ref.abs().max()) <= 4e-6
+
+
 def test_fp32x6_mode_full_forward_backward_vs_oracle():
     """mlp_dtype fp32x6 through the renderer, C = 22 mid-size, against the oracle in FLOAT64, next to the exact-fp32 path on the same inputs:
     outputs 1e-3 relative; per gradient tensor the number of entries outside the band (2e-3 relative + 1e-4 of the scale: these are samples

@@ -78,8 +78,15 @@ def exact_wgrad():
     return torch.cat([gW.reshape(-1), gb])
 
 
-LOOSE = {"first2_bwd", "first2_wgrad", "exact_wgrad"}
-fns = {"first2_bwd": first2_bwd, "first2_wgrad": first2_wgrad, "exact_wgrad": exact_wgrad, "bf16_fwd": bf16_layer, "n128_fwd": n128_layer, "k3": k3, "x6_fwd": lambda: layer(2, False), "x6_dgrad": lambda: layer(2, True), "exact_fwd": lambda: layer(0, False)}
+def x6_wgrad():              # the fp32x6 weight gradient (csrc/layer_x6w.hip)
+    gW, gb = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
+    with engine._Precision(2):
+        engine.wgrad(256, 256, M, dY, 256, A, 256, gW, gb)
+    return torch.cat([gW.reshape(-1), gb])
+
+
+LOOSE = {"first2_bwd", "first2_wgrad", "exact_wgrad", "x6_wgrad"}
+fns = {"first2_bwd": first2_bwd, "first2_wgrad": first2_wgrad, "exact_wgrad": exact_wgrad, "x6_wgrad": x6_wgrad, "bf16_fwd": bf16_layer, "n128_fwd": n128_layer, "k3": k3, "x6_fwd": lambda: layer(2, False), "x6_dgrad": lambda: layer(2, True), "exact_fwd": lambda: layer(0, False)}
 only = sys.argv[4].split(",") if len(sys.argv) > 4 else list(fns)
 fns = {k: v for k, v in fns.items() if k in only}
 ref = {k: f() for k, f in fns.items()}
