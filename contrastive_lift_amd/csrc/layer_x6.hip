@@ -21,10 +21,11 @@
 // mask and stores its 16 columns.  Symmetric on purpose: both waves of a pair issue the same instruction stream, so the hand-counted waits
 // are shared.  ONE s_barrier per tile.  LDS: 96 KB plane images + 32 KB staging + 32 KB exchange = all 160 KB; 204 VGPRs, no AGPRs.
 //
-// A four-wave form of this kernel (one wave per SIMD, 512 registers each, no exchange) measured the same time and was REMOVED: with two
-// processes sharing the GPU (the two-ranks-on-one-device tests), other kernels running beside it returned corrupted lanes 48..63 --
-// reproduced with a stress test against an unrelated elementwise kernel, gone with this <= 256-register form (profiles/r03_x6_notes.txt).
-// Its fused narrow output layer (clift_xyz_head_last2_x6_fwd, ABI 9) went with it: this form has no LDS left for the cross-wave sum.
+// A four-wave form of this kernel (one wave per SIMD, ~400 of the SIMD's 512 registers, no exchange) measured the same time and was REMOVED: with
+// two processes sharing the GPU, small kernels of the OTHER process that were scheduled onto the leftover registers beside its MFMA stream
+// returned corrupted lanes 48..63.  The mechanism (bisected on the weight-gradient kernel, layer_x6w.hip / profiles/r03_x6_notes.txt) is
+// co-residency with a dense bf16 MFMA stream; this form carries the remedy, a register ballast: every wave allocates 256 registers, two fill the
+// file.  The four-wave form's fused narrow output layer (clift_xyz_head_last2_x6_fwd, ABI 9) went with it: no LDS left here for its cross-wave sum.
 //
 // Memory-instruction bookkeeping.  All vector-memory instructions of the loop are issued by hand so that the waits can be COUNTED (the
 // compiler's own accounting stops at the loop's back edge and falls back to vmcnt(0), which drained the newest prefetch every tile).

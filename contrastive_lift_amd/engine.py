@@ -184,7 +184,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
     # fp32x6 mode: the 256 x 256 hidden layers (forward / dgrad) run as persistent split kernels (csrc/layer_x6.hip); every other
-    # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, weight gradients -- stays on its exact-fp32 persistent kernel,
+    # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, the other weight gradients -- stays on its exact-fp32 persistent kernel,
     # which is faster than the tiled split kernel the library would pick for it
     x6 = N == 256 and K == 256 and not a_trans and not accumulate and not c_trans
     # ... and their weight gradients (csrc/layer_x6w.hip; CLIFT_X6_WGRAD=0 keeps the exact quadrant kernel)
