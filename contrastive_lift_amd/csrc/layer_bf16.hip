@@ -57,6 +57,7 @@ static __device__ __forceinline__ void wait_vm_upto(int n) {       // wave-unifo
 // DEPTH = tiles in flight ahead of the multiply; the ring has DEPTH + 1 stages of 32 KB (A) [+ 32 KB (mask)].
 template <bool DGRAD, int DEPTH>
 __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_block) {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (csrc/layer_x6w.hip): nothing else is scheduled onto this SIMD beside the bf16 MFMA stream
     constexpr int NST = DEPTH + 1, STAGE = (DGRAD ? 2 : 1) * LY_TILE, PER_DMA = DGRAD ? 8 : 4;
     __shared__ __attribute__((aligned(16))) uint4 lds[NST * STAGE];        // the only LDS object of the kernel
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -199,6 +200,7 @@ static __device__ __forceinline__ uint2 tr_read(unsigned addr) {
 static __device__ __forceinline__ float bf16_pair_sum(unsigned u) { return __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u); }
 
 __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_per_block) {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (csrc/layer_x6w.hip): nothing else is scheduled onto this SIMD beside the bf16 MFMA stream
     constexpr int STAGE = 2 * LY_TILE;                                        // uint4 per stage: dY tile then X tile
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * STAGE];            // 128 KB, the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -328,6 +330,7 @@ int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st) {
 constexpr int W2_XB = LY_ROWS * 128, W2_STAGE = LY_TILE * 16 + W2_XB, W2_DEPTH = 2, W2_STAGES = W2_DEPTH + 1;     // bytes
 
 __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream2d(GemmP g, int rows_per_range) {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (csrc/layer_x6w.hip): nothing else is scheduled onto this SIMD beside the bf16 MFMA stream
     __shared__ __attribute__((aligned(16))) unsigned char lds[W2_STAGES * W2_STAGE];          // 120 KB, the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int b = blockIdx.x, slice = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
