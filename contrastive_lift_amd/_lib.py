@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -62,6 +62,10 @@ _SIGNATURES = {
     "clift_density_points": ([_P, _P, _I, _L, _F, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_xyz_head_first2_x6_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P], C.c_int),
+    "clift_xyz_head_first2_x6_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_xyz_head_first2_x6_wgrad": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_xyz_head_last2_x6_workspace_bytes": ([_I], C.c_long),
+    "clift_xyz_head_last2_x6_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _L, _P], C.c_int),
     "clift_xyz_head_first2_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_wgrad": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_last2_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P], C.c_int),

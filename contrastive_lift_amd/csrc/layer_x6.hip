@@ -38,6 +38,7 @@ CLIFT_ROWS_LIMIT_BINDER(layer_x6)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -49,6 +50,9 @@ static __device__ __forceinline__ unsigned x6_pk(float lo, float hi) {        //
     bf16x2 p;
     p[0] = (__bf16)lo; p[1] = (__bf16)hi;
     return __builtin_bit_cast(unsigned, p);
+}
+static __device__ __forceinline__ float x6_uniform(float v) {                  // a wave-uniform value, kept in a scalar register
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 static __device__ __forceinline__ float x6_lo(unsigned p) { return __uint_as_float(p << 16); }
 static __device__ __forceinline__ float x6_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
@@ -73,15 +77,21 @@ template <int N>
 static __device__ __forceinline__ void x6_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int X6_XCH = X6_RAW + X6_ROWS * 1024;     // exchange area: [tile parity][wave][2][lane] float4 = 2 x 16 KB
-constexpr int X8_VM_FWD[4] = {5, 4, 3, 3};          // vmcnt before the read-back of staged row i: D0 D1 S0 D2 S1 D3 per tile (x6_vmcnt_model.py)
-constexpr int X8_VM_DGRAD[4] = {5, 5, 5, 5};        // m0 m1 D0 D1 S0 D2 S1 D3; the masks are needed after 6 younger instructions
+// vmcnt before the read-back of staged row i (tools/x6_vmcnt_model.py replays each stream and prints these tables), by variant:
+constexpr int X8_VM[5][4] = {
+    {5, 4, 3, 3},       // 0 forward:                        D0 D1 S0 D2 S1 D3 per tile
+    {5, 5, 5, 5},       // 1 dgrad:                    m0 m1 D0 D1 S0 D2 S1 D3; the masks are needed after 6 younger instructions
+    {6, 4, 4, 4},       // 2 forward + output layer:         D0 P D1 S0 D2 S1 D3 (P = the store of the output layer's partial sums)
+    {4, 2, 3, 3},       // 3 the same, hidden not written:   D0 P D1 D2 D3
+    {3, 3, 3, 3},       // 4 dgrad consumed in-kernel (K3W): p D0 D1 D2 D3 (p = the rows' positions; needed after 4 younger instructions)
+};
 
-template <bool DGRAD>
+template <int V>
 static __device__ __forceinline__ void x8_wait_piece(int i) {
-    if (i == 0) x6_wait_vm<(DGRAD ? X8_VM_DGRAD : X8_VM_FWD)[0]>();
-    if (i == 1) x6_wait_vm<(DGRAD ? X8_VM_DGRAD : X8_VM_FWD)[1]>();
-    if (i == 2) x6_wait_vm<(DGRAD ? X8_VM_DGRAD : X8_VM_FWD)[2]>();
-    if (i == 3) x6_wait_vm<(DGRAD ? X8_VM_DGRAD : X8_VM_FWD)[3]>();
+    if (i == 0) x6_wait_vm<X8_VM[V][0]>();
+    if (i == 1) x6_wait_vm<X8_VM[V][1]>();
+    if (i == 2) x6_wait_vm<X8_VM[V][2]>();
+    if (i == 3) x6_wait_vm<X8_VM[V][3]>();
 }
 
 // GEN (forward only): the layer is the SECOND layer of an xyz head and its input is generated, A[m][k] = relu(W0[k] . x_m + b0[k]) with K = 3
@@ -97,9 +107,46 @@ struct X6Gen {
     const float* b0;      // (256)
 };
 
-template <bool DGRAD, bool GEN = false>
-__global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Gen gx) {
+// OUTV (forward only, 1 = hidden activation written as well, 2 = not written): the layer is the LAST hidden layer of a head whose output layer
+// is narrow (E <= 4: the instance heads, tensoRF.py:478-481; the semantic head of a 2-class scene) and that layer is applied to the finished
+// tile IN REGISTERS: a lane holds 8 finished columns of one row and the output weights of those columns (32 registers), 32 FMAs give its share
+// of the row's E outputs, one v_permlane32_swap pair folds the two half-waves (lower + upper, a fixed order).  There is no LDS left to sum the
+// shares of the 8 waves, and the other 128 columns live on another CU: every wave STORES its 32 rows x 4 partial sums (8 bytes per lane) into its
+// own slot 8 * half + wave of a 16-slot workspace and a small second launch (k_x6_out_sum) adds the 16 slots of a row in slot order + bias.
+// 256 B per row written and read once instead of the 1 KB hidden activation written here and re-streamed by a 256 -> E GEMM: this kernel is
+// bound by its output stores (profiles/r03_x6_notes.txt), so what it does not write is what it gains.  A row's bits depend on nothing but the
+// row (fixed column partition, fixed order), i.e. not on how many rows share the launch.
+struct X6Out {
+    const float* Wo;      // (E, 256), row pitch ldwo
+    int ldwo, E;
+    float* part;          // workspace: [16][pstride] float4
+    long pstride;         // rows per slot (>= M)
+};
+
+// K3W (dgrad only; the fp32x6 counterpart of k_layer_f32<dgrad, K3W>): the layer is the SECOND layer of an xyz head, so its input gradient
+// dH1 = (W0 x + b0 > 0) . (dH2 W1) has one consumer, the K = 3 first layer's weight gradient gW0[n][0..2] += sum_m dH1[m][n] x_m, gb0[n] += sum_m
+// dH1[m][n] -- a sum over ROWS, and a lane of this kernel owns one row of every tile (8 finished columns of it).  So nothing is exchanged per
+// tile: the lane keeps 8 x 4 running sums over ITS rows for the whole row range (32 registers), re-deriving the ReLU mask from the row's
+// position in the forward's operation order (the forward never wrote the activation); the coefficients of the wave's 16 columns live in
+// SGPRs (the two half-waves own different columns: both candidates are evaluated and one selected).  dH1 is never written, the mask never read:
+// one position per row (16 B) replaces the two mask loads and both stores.  The 32 sums are folded across the lanes once per block, through
+// the plane images' LDS after the last tile, and leave as one atomic per thread (into this XCD's gradient shard when a pass has them on).
+struct X6K3 {
+    const float* x4;      // (M, 4) normalised sample positions
+    const float* W0;      // (256, 3), row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+    float* gW0;           // (256, 3), row pitch ldgw0
+    int ldgw0;
+    float* gb0;           // (256)
+};
+
+template <bool DGRAD, bool GEN = false, int OUTV = 0, bool K3W = false>
+__global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Gen gx, X6Out go, X6K3 gk) {
     static_assert(!(DGRAD && GEN), "GEN is a forward form");
+    static_assert(!(OUTV && (DGRAD || GEN)), "OUTV is a plain forward form");
+    static_assert(!K3W || DGRAD, "K3W is a dgrad form");
+    constexpr int VMV = K3W ? 4 : OUTV ? 1 + OUTV : (DGRAD ? 1 : 0);      // row of X8_VM
     __shared__ __attribute__((aligned(1024))) unsigned char lds[X6_XCH + 2 * 16384];                // 160 KB, the only LDS object
     // register ballast: the wave allocates its whole 256-register budget, so that two of them fill the SIMD's file and no wave of another kernel
     // (another PROCESS sharing the device) is scheduled beside this MFMA stream -- see layer_x6w.hip for what happens otherwise
@@ -284,11 +331,65 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float o = (keep[q][e] + recv[q][e]) + bfin[4 * q + e];
-                if (DGRAD) o = mk[q][e] > 0.f ? o : 0.f;
+                if (K3W) { }                                                      // (masked where it is consumed: k3_col)
+                else if (DGRAD) o = mk[q][e] > 0.f ? o : 0.f;
                 else if (g.act == 1) o = fmaxf(o, 0.f);
                 prev[q][e] = o;
             }
     };
+
+    // K3W: coefficients of the wave's 16 columns (wave-uniform addresses: scalar loads, SGPRs), this lane's running sums, positions
+    float sw[16][4];
+    float kacc[8][4];
+    f32x4 xq = {0.f, 0.f, 0.f, 0.f}, xcur = {0.f, 0.f, 0.f, 0.f};
+    bool ok_done = false, prev_ok = false;                   // whether the lane's row of the tile is a real row (not a clamped copy of the last one)
+    if (K3W) {
+        const int colbase = 128 * half + 32 * cg + 16 * kh;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float* wr0 = gk.W0 + (size_t)(colbase + i) * gk.ldw0;
+            sw[i][0] = x6_uniform(wr0[0]); sw[i][1] = x6_uniform(wr0[1]); sw[i][2] = x6_uniform(wr0[2]); sw[i][3] = x6_uniform(gk.b0[colbase + i]);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { kacc[c][0] = 0.f; kacc[c][1] = 0.f; kacc[c][2] = 0.f; kacc[c][3] = 0.f; }
+    }
+    // finished column c = 4 q + e of this lane is column 8 q + e (+ 4 for the upper half-wave) of the wave's 16
+    auto k3_col = [&](int c) {
+        const int q = c >> 2, e = c & 3, ia = 8 * q + e, ib = ia + 4;
+        const float pa = fmaf(sw[ia][2], xcur[2], fmaf(sw[ia][1], xcur[1], fmaf(sw[ia][0], xcur[0], sw[ia][3])));      // the forward's order
+        const float pb = fmaf(sw[ib][2], xcur[2], fmaf(sw[ib][1], xcur[1], fmaf(sw[ib][0], xcur[0], sw[ib][3])));
+        const float pre = lh ? pb : pa;
+        const float md = (pre > 0.f && prev_ok) ? prev[q][e] : 0.f;
+        kacc[c][0] = fmaf(md, xcur[0], kacc[c][0]);
+        kacc[c][1] = fmaf(md, xcur[1], kacc[c][1]);
+        kacc[c][2] = fmaf(md, xcur[2], kacc[c][2]);
+        kacc[c][3] += md;
+        asm volatile("" : "+v"(kacc[c][0]), "+v"(kacc[c][1]), "+v"(kacc[c][2]), "+v"(kacc[c][3]));      // (pinned to its gap)
+    };
+
+    // OUTV: output weights of this lane's 8 finished columns (rows e >= E are zero), its share of the row's outputs, the half-wave fold
+    float wo[4][8], po[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 pfold = {0.f, 0.f};
+    if (OUTV) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wo[e][c] = e < go.E ? go.Wo[(size_t)e * go.ldwo + fcol + 8 * (c >> 2) + (c & 3)] : 0.f;
+    }
+    auto out_fma = [&](int e) {          // po[e] = sum over the lane's 8 columns, ascending, one FMA chain
+        float a = prev[0][0] * wo[e][0];
+        a = fmaf(prev[0][1], wo[e][1], a); a = fmaf(prev[0][2], wo[e][2], a); a = fmaf(prev[0][3], wo[e][3], a);
+        a = fmaf(prev[1][0], wo[e][4], a); a = fmaf(prev[1][1], wo[e][5], a); a = fmaf(prev[1][2], wo[e][6], a); a = fmaf(prev[1][3], wo[e][7], a);
+        asm volatile("" : "+v"(a));      // (pinned to its gap)
+        po[e] = a;
+    };
+    auto out_fold = [&]() {              // lanes of the lower half end up with outputs 0, 1 of their row, the upper half with 2, 3: (lower + upper) each
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(po[0]), __float_as_uint(po[2]), false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(po[1]), __float_as_uint(po[3]), false, false);
+        pfold[0] = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
+        pfold[1] = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+    };
+    float* const pslot = OUTV ? go.part + ((size_t)(8 * half + wave) * go.pstride) * 4 + 2 * lh : nullptr;
 
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's plane and exchange writes are done ...
@@ -328,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             if (even) {
                 // GEN: the positions of tile t+1 left during tile t-1 (one DMA, before that tile's two stores); younger than it at any of the four
                 // read-backs: those two stores, this tile's position DMA (from i = 2 on) and first store (i = 3) -- vmcnt(2) covers all four
-                if (GEN) x6_wait_vm<2>(); else x8_wait_piece<DGRAD>(i);
+                if (GEN) x6_wait_vm<2>(); else x8_wait_piece<VMV>(i);
                 raw_read(i, t + 1);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");
@@ -345,16 +446,25 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
                 finish();
                 prev_m = m_done;
                 m_done = m;
+                if (K3W) { xcur = xq; prev_ok = ok_done; ok_done = rbeg + t * X6_ROWS + li < rend; }
             } else if (even) split_e(nxt, i - 1);
             else split_b0();
             acc1 = x6_mfma(wh[j], f[1], acc1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 2
             if (even) {
-                if (DGRAD && i < 2) {                                            // the ReLU mask of the columns this lane finishes: steps 0, 2
+                if (DGRAD && !K3W && i < 2) {                                    // the ReLU mask of the columns this lane finishes: steps 0, 2
                     const float* mp = g.mask + (size_t)m * g.ldmask + fcol + 8 * i;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[i]) : "v"(mp) : "memory");
                 }
+                if (K3W && j == 0) {                                             // "p": the position of this lane's row of THIS tile (consumed next tile)
+                    const float* pp = gk.x4 + (size_t)m * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xq) : "v"(pp) : "memory");
+                }
+                if (K3W && j == 2) k3_col(3);
+                if (K3W && j == 4) k3_col(6);
+                if (OUTV && j == 0) out_fma(0);                                  // the previous tile's rows through the output layer: steps 0, 2
+                if (OUTV && j == 2) out_fold();
             } else split_b1();
             acc0 = x6_mfma(wm[j], f[1], acc0);
             __builtin_amdgcn_sched_barrier(0);
@@ -362,12 +472,19 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             if (even) {
                 if (GEN) { if (i == 1) pos_dma(t + 2); }
                 else if (i > 0) dma_piece(t + 2, i - 1);
+                if (OUTV && j == 0) out_fma(1);
+                if (K3W && j == 0) k3_col(0);
             } else split_c(nxt, i);
             acc1 = x6_mfma(wm[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 4
             if (even) {
-                if (i >= 2) *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2];      // steps 4, 6
+                if (OUTV != 2 && !K3W && i >= 2) *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2];      // steps 4, 6
+                if (K3W && j == 0) k3_col(1);
+                if (K3W && j == 2) k3_col(4);
+                if (K3W && j == 4) k3_col(7);
+                if (OUTV && j == 0) out_fma(2);
+                if (OUTV && j == 2) *reinterpret_cast<f32x2*>(pslot + (size_t)prev_m * 4) = pfold;                            // "P"
             } else { split_d0(); if (j == 7) split_d1(); }
             acc0 = x6_mfma(wh[j], f[2], acc0);
             __builtin_amdgcn_sched_barrier(0);
@@ -375,11 +492,16 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             if (!even) {
                 if (j < 7) split_d1();
                 else { split_e(nxt, 3); if (!GEN) dma_piece(t + 2, 3); }
+            } else {
+                if (OUTV && j == 0) out_fma(3);
+                if (K3W && j == 0) k3_col(2);
+                if (K3W && j == 2) k3_col(5);
             }
             acc1 = x6_mfma(wl[j], f[0], acc1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (DGRAD) asm volatile("s_waitcnt vmcnt(6)" : "+v"(mk[0]), "+v"(mk[1]) : : "memory");
+        if (K3W) asm volatile("s_waitcnt vmcnt(4)" : "+v"(xq) : : "memory");
+        else if (DGRAD) asm volatile("s_waitcnt vmcnt(6)" : "+v"(mk[0]), "+v"(mk[1]) : : "memory");
         send(t & 1);
     }
     // the last tile: exchange once more, finish, store
@@ -396,8 +518,51 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     // The DMAs of the two tiles past the end (clamped rows) were issued unconditionally: a wave must not end with them in flight (see layer_x6w.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     finish();
+    if (K3W) {
+        xcur = xq; prev_ok = ok_done;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(g.C + (size_t)m_done * g.ldc + fcol + 8 * q) = prev[q];
+        for (int c = 0; c < 8; ++c) k3_col(c);
+        // fold the 32 sums across the 32 lanes of each half-wave: through LDS (the plane images: every wave is past its last fragment read --
+        // the barrier above -- and the DMAs in flight target the staging area, not this), rows padded to 65 words (conflict-free both ways)
+        float* const red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int a = 0; a < 32; ++a) red[(wave * 32 + a) * 65 + lane] = kacc[a >> 2][a & 3];
+        __syncthreads();
+        const int rw = tid >> 6, rr = tid & 63, hx = rr >> 5, a = rr & 31;
+        const float* src = red + (rw * 32 + a) * 65 + hx * 32;
+        float ssum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) ssum += src[l];
+        const int c = a >> 2, k = a & 3;
+        const int n = 128 * half + 32 * (rw & 3) + 16 * (rw >> 2) + 4 * hx + 8 * (c >> 2) + (c & 3);
+        if (k < 3) unsafeAtomicAdd(grad_target(gk.gW0) + (size_t)n * gk.ldgw0 + k, ssum);
+        else unsafeAtomicAdd(grad_target(gk.gb0) + n, ssum);
+        return;
+    }
+    if (OUTV != 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(g.C + (size_t)m_done * g.ldc + fcol + 8 * q) = prev[q];
+    }
+    if (OUTV) {
+        out_fma(0); out_fma(1); out_fma(2); out_fma(3);
+        out_fold();
+        *reinterpret_cast<f32x2*>(pslot + (size_t)m_done * 4) = pfold;
+    }
+}
+
+// out[m][0..E) = bias + the 16 slot partial sums of row m, added in slot order (second launch of the OUTV form)
+__global__ __launch_bounds__(256) void k_x6_out_sum(const f32x4* __restrict__ part, long pstride, int M, const float* __restrict__ bo, int E,
+                                                    float* __restrict__ out, int ldo) {
+    if (rows_limited()) M = limit_rows(M);
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        f32x4 s = part[m];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) {
+            const f32x4 v = part[(size_t)p * pstride + m];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        for (int e = 0; e < E; ++e) out[(size_t)m * ldo + e] = s[e] + bo[e];
+    }
 }
 
 // Eligibility is decided by the caller (gemm.hip): N = K = 256, plain row-major fp32 A, 16-byte-aligned rows; forward: [n][k] weights,
@@ -410,8 +575,9 @@ int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int nr = cdiv(p.M, rpr);
     const int grid = 16 * cdiv(nr, 8);                               // block b: half (b >> 3) & 1 of range (b & 7) + 8 (b >> 4)
     const X6Gen none = {nullptr, nullptr, 0, nullptr};
-    if (b_trans) k_layer_x6<true><<<grid, 512, 0, st>>>(p, rpr, nr, none);
-    else k_layer_x6<false><<<grid, 512, 0, st>>>(p, rpr, nr, none);
+    const X6Out no_out = {nullptr, 0, 0, nullptr, 0};
+    if (b_trans) k_layer_x6<true><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
+    else k_layer_x6<false><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
     return clift_check_launch("clift_gemm(fp32x6 layer)");
 }
 
@@ -430,6 +596,61 @@ extern "C" int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, in
     const int nranges = tiles < pairs ? tiles : pairs;
     const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
     const int nr = cdiv(M, rpr);
-    k_layer_x6<false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0});
+    k_layer_x6<false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0}, X6Out{nullptr, 0, 0, nullptr, 0}, X6K3{});
     return clift_check_launch("clift_xyz_head_first2_x6_fwd");
+}
+
+// LAST hidden layer of an xyz head together with its narrow output layer (E <= 4), fp32x6 arithmetic for the 256 x 256 layer, exact fp32
+// FMAs for the output layer (the fp32x6 counterpart of clift_xyz_head_last2_fwd; tensoRF.py:478-481, 591-594 at C <= 4):
+//   h = relu(W A^T + b) (written to `hidden` only if it is non-null), out[:, 0:E] = h Wout^T + bout.
+// workspace: clift_xyz_head_last2_x6_workspace_bytes(M) bytes of device memory, 16-byte aligned, private to this call until it has run.
+extern "C" long clift_xyz_head_last2_x6_workspace_bytes(int M) { return M > 0 ? 256L * M : 0; }
+
+extern "C" int clift_xyz_head_last2_x6_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                           const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, void* workspace,
+                                           long workspace_bytes, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(E >= 1 && E <= 4, "clift_xyz_head_last2_x6_fwd: E must be in [1,4] (got %d)", E);
+    CLIFT_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= 256 && ldw >= 256,
+                  "clift_xyz_head_last2_x6_fwd: A / W must be 16-byte aligned with pitches >= 256 that are multiples of 4");
+    CLIFT_REQUIRE(hidden == nullptr || ((((uintptr_t)hidden) & 15) == 0 && ldh % 4 == 0 && ldh >= 256), "clift_xyz_head_last2_x6_fwd: hidden must be 16-byte aligned, pitch >= 256");
+    CLIFT_REQUIRE(workspace != nullptr && (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= clift_xyz_head_last2_x6_workspace_bytes(M),
+                  "clift_xyz_head_last2_x6_fwd: needs a 16-byte aligned workspace of clift_xyz_head_last2_x6_workspace_bytes(M) bytes");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = A; p.lda = lda; p.B = W; p.ldb = ldw; p.C = hidden; p.ldc = ldh; p.bias = b; p.act = 1;
+    const int tiles = cdiv(M, X6_ROWS);
+    const int pairs = clift_persistent_cus() / 2;
+    const int nranges = tiles < pairs ? tiles : pairs;
+    const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
+    const int nr = cdiv(M, rpr);
+    const X6Gen none = {nullptr, nullptr, 0, nullptr};
+    const X6Out op = {Wout, ldwo, E, (float*)workspace, (long)M};
+    if (hidden) k_layer_x6<false, false, 1><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, none, op, X6K3{});
+    else k_layer_x6<false, false, 2><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, none, op, X6K3{});
+    int rc = clift_check_launch("clift_xyz_head_last2_x6_fwd");
+    if (rc) return rc;
+    const int blocks = cdiv(M, 256) < 2048 ? cdiv(M, 256) : 2048;
+    k_x6_out_sum<<<blocks, 256, 0, as_stream(s)>>>((const f32x4*)workspace, (long)M, M, bout, E, out, ldo);
+    return clift_check_launch("clift_xyz_head_last2_x6_fwd(sum)");
+}
+
+// Backward of the first TWO layers of an xyz head in one launch, fp32x6 arithmetic for the 256 x 256 product (the fp32x6 counterpart of
+// clift_xyz_head_first2_bwd; the forward is clift_xyz_head_first2_x6_fwd): with dH2 (M, ldd) the gradient at the second layer's output
+// (already masked by its ReLU), dH1 = (W0 x + b0 > 0) . (dH2 W1) is formed tile by tile and consumed on the spot:
+//   gW0[n][0..2] += sum_m dH1[m][n] x4[m][0..2],   gb0[n] += sum_m dH1[m][n]          (tensoRF.py:475-476, 576-577)
+extern "C" int clift_xyz_head_first2_x6_bwd(const float* dH2, int ldd, const float* W1, int ldw1, const float* W0, int ldw0, const float* b0,
+                                            const float* x4, int M, float* gW0, int ldgw0, float* gb0, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)dH2) & 15) == 0 && (((uintptr_t)x4) & 15) == 0 && ldd % 4 == 0 && ldd >= 256 && ldw1 >= 256 && ldw0 >= 3 && ldgw0 >= 3,
+                  "clift_xyz_head_first2_x6_bwd: dH2 / x4 must be 16-byte aligned, ldd a multiple of 4 and >= 256");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = dH2; p.lda = ldd; p.B = W1; p.ldb = ldw1; p.C = nullptr; p.ldc = 256;
+    const int tiles = cdiv(M, X6_ROWS);
+    const int pairs = clift_persistent_cus() / 2;
+    const int nranges = tiles < pairs ? tiles : pairs;
+    const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
+    const int nr = cdiv(M, rpr);
+    k_layer_x6<true, false, 0, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{nullptr, nullptr, 0, nullptr}, X6Out{nullptr, 0, 0, nullptr, 0},
+                                                                                  X6K3{x4, W0, ldw0, b0, gW0, ldgw0, gb0});
+    return clift_check_launch("clift_xyz_head_first2_x6_bwd");
 }

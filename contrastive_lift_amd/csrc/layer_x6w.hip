@@ -46,16 +46,31 @@ static __device__ __forceinline__ f32x16 xw_mfma(const u32x4& a, const u32x4& b,
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range) {
+// GENX (clift_xyz_head_first2_x6_wgrad): the layer is the SECOND layer of an xyz head and its input X[m][k] = relu(W0[k] . x_m + b0[k]) (K = 3,
+// tensoRF.py:475,576) is GENERATED in the split instead of streamed -- the forward never wrote it (clift_xyz_head_first2_x6_fwd).  The X rows'
+// two DMA slots per tile carry the POSITIONS of the wave's four rows (2 x 32 bytes), a column run reads them back as four broadcast
+// ds_read_b128 where it read four column words, and the lane evaluates its column (4 coefficients per run in registers; the forward's FMA
+// order, so the operand has the forward's bits).  Same number of vector-memory and LDS instructions in the same places: every wait is unchanged.
+struct XwGen {
+    const float* x4;      // (M, 4) normalised sample positions
+    const float* W0;      // (256, 3), row pitch ldw0
+    int ldw0;
+    const float* b0;      // (256)
+};
+
+template <bool GENX>
+__global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range, int nranges, XwGen gx) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[XW_RAW + 8 * 4096];                 // 152 KB, the only LDS object
     asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (see the header): the wave allocates the whole 256-register budget
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3, kp = wave >> 2;       // n-tile, pair of k-tiles (scalars)
     const int b = blockIdx.x, quad = (b >> 3) & 3, qn = quad >> 1, qk = quad & 1, range = (b & 7) + 8 * (b >> 5);
+    (void)gx;
     if (rows_limited()) {
         g.K = limit_rows(g.K);
-        rows_per_range = ((g.K + 63) / 64 + XW_ROWS - 1) / XW_ROWS * XW_ROWS;
+        rows_per_range = ((g.K + nranges - 1) / nranges + XW_ROWS - 1) / XW_ROWS * XW_ROWS;
     }
+    if (range >= nranges) return;
     const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + XW_ROWS - 1) / XW_ROWS;
@@ -65,6 +80,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
 
     // ---- rows by LDS-DMA: piece j (0, 1) of operand o = rows 2 j, 2 j + 1 of this wave's four (rows 4 wave .. 4 wave + 3 of the tile), 512 B each
     auto dma = [&](int t, int o, int j) {
+        if (GENX && o == 1) {                               // positions of rows 2 j, 2 j + 1: lanes 0..7 = (row, component), the other lanes repeat them
+            const int prow = min(rbeg + t * XW_ROWS + 4 * wave + 2 * j + ((lane >> 2) & 1), rend - 1);
+            __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)prow * 4 + (lane & 3), (lds_ptr_t)(lds + XW_RAW + wave * 4096 + 2048 + j * 1024), 4, 0, 0);
+            return;
+        }
         const int rr = 2 * j + lh;
         const int row = min(rbeg + t * XW_ROWS + 4 * wave + rr, rend - 1);       // (rows past the range: any valid row; the split zeroes them)
         const float* src = (o ? X + (size_t)row * g.ldb : Y + (size_t)row * g.lda) + 4 * li;
@@ -72,7 +92,25 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     };
     // ---- a column run: the 4 rows of this wave at column lane + 64 u of operand o
     float v[4];
+    f32x4 pz[4];                                        // GENX: the positions of the wave's four rows
+    float gw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // GENX: W0 row and bias of this lane's X columns lane + 64 u (of this quadrant's k-half)
+    if (GENX) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = 128 * qk + lane + 64 * u;
+            const float* wr0 = gx.W0 + (size_t)col * gx.ldw0;
+            gw[u][0] = wr0[0]; gw[u][1] = wr0[1]; gw[u][2] = wr0[2]; gw[u][3] = gx.b0[col];
+        }
+    }
     auto run_read = [&](int o, int u) {
+        if (GENX && o == 1) {
+            const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + 2048);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(pz[0]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(pz[1]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(pz[2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:1040" : "=v"(pz[3]) : "v"(a) : "memory");
+            return;
+        }
         const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + o * 2048 + (lane + 64 * u) * 4);
         asm volatile("ds_read_b32 %0, %1" : "=v"(v[0]) : "v"(a) : "memory");
         asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v[1]) : "v"(a) : "memory");
@@ -80,6 +118,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
         asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(v[3]) : "v"(a) : "memory");
     };
     auto run_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory"); };
+    auto gen_wait = [&](int u) {                        // GENX, operand X: wait for the positions, then this lane's column of the four rows
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]) : : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e)     // same order as k_linear_k3_fwd / k_layer_x6<GEN>
+            v[e] = fmaxf(fmaf(gw[u][2], pz[e][2], fmaf(gw[u][1], pz[e][1], fmaf(gw[u][0], pz[e][0], gw[u][3]))), 0.f);
+    };
     float bs0 = 0.f, bs1 = 0.f;                         // bias gradient of columns lane, lane + 64 (this wave's rows)
     unsigned sh[2], sm[2], sl[2];
     auto run_mask = [&](int valid, int o, int u) {      // rows at or past `valid` contribute nothing (a clamped copy would be counted twice)
@@ -115,7 +159,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = r < 2 ? 1 : 0, u = r & 1;
-        run_read(o, u); run_wait(); run_mask(valid_of(0), o, u); run_split(0); run_split(1); run_write(0u, o, u);
+        run_read(o, u);
+        if (GENX && o == 1) gen_wait(u); else run_wait();
+        run_mask(valid_of(0), o, u); run_split(0); run_split(1); run_write(0u, o, u);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     dma(1, 1, 0); dma(1, 1, 1); dma(1, 0, 0); dma(1, 0, 1);
@@ -166,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
             acc[1] = xw_mfma(a[0], b1[0], acc[1]);
             __builtin_amdgcn_sched_barrier(0);
-            run_wait();
+            if (GENX && o == 1) gen_wait(0); else run_wait();
             run_mask(valid, o, 0);
             acc[0] = xw_mfma(a[0], b0[1], acc[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = xw_mfma(a[1], b0[1], acc[0]);
             __builtin_amdgcn_sched_barrier(0);
-            run_wait();
+            if (GENX && o == 1) gen_wait(1); else run_wait();
             run_mask(valid, o, 1);
             acc[1] = xw_mfma(a[1], b1[1], acc[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -220,8 +266,28 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     }
 }
 
+// row ranges = a quarter of the CUs the persistent launches may use (clift_set_cu_reserve leaves CUs to a running all-reduce); the four
+// quadrant blocks of a range keep block ids 8 apart (one XCD)
+static int xw_ranges() { const int r = clift_persistent_cus() / 4; return r < 1 ? 1 : r; }
+
 int clift_wgrad_x6_launch(const GemmP& p, hipStream_t st) {
-    const int rpr = cdiv(cdiv(p.K, 64), XW_ROWS) * XW_ROWS;
-    k_wgrad_x6<<<256, 512, 0, st>>>(p, rpr);
+    const int nr = xw_ranges();
+    const int rpr = cdiv(cdiv(p.K, nr), XW_ROWS) * XW_ROWS;
+    k_wgrad_x6<false><<<32 * cdiv(nr, 8), 512, 0, st>>>(p, rpr, nr, XwGen{nullptr, nullptr, 0, nullptr});
     return clift_check_launch("clift_gemm(fp32x6 wgrad)");
+}
+
+// Weight gradient of the SECOND layer of an xyz head without the first layer's activation, fp32x6 arithmetic (the fp32x6 counterpart of
+// clift_xyz_head_first2_wgrad):  gW1[n][k] += sum_m dH2[m][n] relu(W0[k] . x_m + b0[k]),  gb1[n] += sum_m dH2[m][n]   (tensoRF.py:475-478)
+extern "C" int clift_xyz_head_first2_x6_wgrad(const float* dH2, int ldd, const float* W0, int ldw0, const float* b0, const float* x4, int M,
+                                              float* gW1, int ldgw1, float* gb1, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE((((uintptr_t)dH2) & 15) == 0 && ldd % 4 == 0 && ldd >= 256 && (((uintptr_t)x4) & 15) == 0 && ldw0 >= 3 && ldgw1 >= 256,
+                  "clift_xyz_head_first2_x6_wgrad: dH2 / x4 must be 16-byte aligned, ldd a multiple of 4 and >= 256, ldgw1 >= 256");
+    GemmP p = {};
+    p.M = 256; p.N = 256; p.K = M; p.A = dH2; p.lda = ldd; p.B = nullptr; p.ldb = 256; p.C = gW1; p.ldc = ldgw1; p.colsum = gb1; p.accumulate = 1;
+    const int nr = xw_ranges();
+    const int rpr = cdiv(cdiv(M, nr), XW_ROWS) * XW_ROWS;
+    k_wgrad_x6<true><<<32 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, XwGen{x4, W0, ldw0, b0});
+    return clift_check_launch("clift_xyz_head_first2_x6_wgrad");
 }

@@ -124,6 +124,9 @@ APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
 
 
 X6_WGRAD = os.environ.get("CLIFT_X6_WGRAD", "1") != "0"       # fp32x6 mode: the 256 x 256 weight gradients on the split kernel as well
+# fp32x6 mode: the fused ends of the xyz heads (output layer in the last hidden layer's kernel, first-two-layers backward, generated-input weight
+# gradient) on the split kernels too (ABI 14); "0" = the round-3 mix (exact fused backward ends, output layer as its own GEMM)
+X6_FUSED_ENDS = os.environ.get("CLIFT_X6_FUSED_ENDS", "1") != "0"
 
 
 # Experiment switch (CLIFT_HYBRID_X6=1): the exact mode's fused kernels (K = 3 layer / output layer in-kernel, fused first-two-layers backward)
@@ -351,6 +354,28 @@ def first2_x6(M, xa, W0, b0, W1, b1, h2):
     call("clift_xyz_head_first2_x6_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h2), 256, stream())
 
 
+def first2_x6_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
+    """One clift_xyz_head_first2_x6_bwd launch (fp32x6 mode): first2_bwd with the 256 x 256 product on the split kernels."""
+    call("clift_xyz_head_first2_x6_bwd", ptr(d), d.shape[1], ptr(W1), _pitch(W1), ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW0), _pitch(gW0), ptr(gb0),
+         stream())
+
+
+def first2_x6_wgrad(M, d, W0, b0, xa, gW1, gb1):
+    """One clift_xyz_head_first2_x6_wgrad launch (fp32x6 mode): first2_wgrad on the split weight-gradient kernel."""
+    call("clift_xyz_head_first2_x6_wgrad", ptr(d), d.shape[1], ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW1), _pitch(gW1), ptr(gb1), stream())
+
+
+def last2_x6(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
+    """One clift_xyz_head_last2_x6_fwd launch (fp32x6 mode): last2 with the 256 x 256 layer on the split kernel; the output layer's partial
+    sums travel through a stream-ordered scratch buffer (256 B per row)."""
+    nbytes = 256 * M
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=h.device)
+    if _lib._launch_stream is not None:       # launched on a side stream (Branches): the allocator must not recycle it earlier
+        ws.record_stream(_lib._launch_stream)
+    call("clift_xyz_head_last2_x6_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), ptr(Wo), _pitch(Wo), ptr(bo), Wo.shape[0], M, ptr(hidden), 256,
+         C.c_void_p(out.data_ptr() + 4 * col_off), ldo, ptr(ws), nbytes, stream())
+
+
 def first2_wgrad(M, d, W0, b0, xa, gW1, gb1):
     """One clift_xyz_head_first2_wgrad launch: gW1 += d^T relu(xa[:, :3] W0^T + b0), gb1 += column sums of d."""
     call("clift_xyz_head_first2_wgrad", ptr(d), d.shape[1], ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW1), _pitch(gW1), ptr(gb1), stream())
@@ -406,13 +431,14 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
         acts.append(h)
     Wo, bo = layers[-1]
-    fuse_out = (FUSE_LAST2 and MLP_PRECISION == 0 and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
-                and h.dtype == torch.float32 and out.dtype == torch.float32 and os.environ.get("CLIFT_NO_PERSISTENT") is None)
+    fuse_out = (FUSE_LAST2 and MLP_PRECISION in (0, 2) and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
+                and h.dtype == torch.float32 and out.dtype == torch.float32 and os.environ.get("CLIFT_NO_PERSISTENT") is None
+                and (MLP_PRECISION == 0 or (X6_FUSED_ENDS and os.environ.get("CLIFT_X6_TILED") is None)))
     for li_, (W, b) in enumerate(rest):
         if fuse_out and li_ == len(rest) - 1:
             # last hidden layer + the narrow output layer in one launch; the hidden activation is written only for a backward
             hn = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
-            last2(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
+            (last2_x6 if MLP_PRECISION == 2 else last2)(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
             acts.append(hn)
             return acts if keep_first else [None]
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
@@ -441,16 +467,19 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         gW, gb = glayers[li]
         h = acts[li - 1]
         no, ni = W.shape
-        if li == 1 and (h is None or (FUSE_FIRST2_BWD and MLP_PRECISION == 0 and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and
+        if li == 1 and (h is None or (FUSE_FIRST2_BWD and MLP_PRECISION in (0, 2) and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and
                                       d.dtype == torch.float32 and h.dtype == torch.float32 and d.shape[1] % 4 == 0 and
                                       os.environ.get("CLIFT_NO_PERSISTENT") is None)):
             # second layer: its weight gradient (over the first layer's activation -- regenerated from the positions when the forward did not keep
             # it), then its input gradient formed and consumed by the first layer's weight gradient in one launch
+            if no != 256 or ni != 256 or tuple(layers[0][0].shape) != (256, 3) or d.shape[1] != 256 or d.dtype != torch.float32:
+                raise _lib.CliftError("backward through an xyz head whose forward ran with keep_first=False (head not named in grad_heads)")
+            x6_ends = MLP_PRECISION == 2 and X6_FUSED_ENDS and os.environ.get("CLIFT_X6_TILED") is None
             if h is None:
-                first2_wgrad(M, d, layers[0][0], layers[0][1], xa, gW, gb)
+                (first2_x6_wgrad if (x6_ends and X6_WGRAD) else first2_wgrad)(M, d, layers[0][0], layers[0][1], xa, gW, gb)
             else:
                 wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
-            first2_bwd(M, d, W, layers[0][0], layers[0][1], xa, *glayers[0])
+            (first2_x6_bwd if x6_ends else first2_bwd)(M, d, W, layers[0][0], layers[0][1], xa, *glayers[0])
             return
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
         if (FUSE_OUT_BWD and li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and

@@ -184,9 +184,21 @@ class HotPathTrainer:
                   _lib.stream())
 
     def _shards_off(self):
-        """A pass that raised between begin and fold must not leave the shards switched on for whoever runs a backward next."""
-        if getattr(self, "_shards", None) is not None:
-            _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), 0, 0, 1, _lib.stream())
+        """A pass that raised between begin and fold must not leave the shards switched on for whoever runs a backward next, nor the partial
+        sums its kernels already flushed into the eight copies (the next pass's fold would add them to that step's gradients), nor the CUs
+        reserved for an all-reduce that will not be waited for.  Runs inside an ``except``: whatever fails here (the device may be the
+        reason we are here) must not replace the original exception."""
+        try:
+            if getattr(self, "allreduce_cu_reserve", 0) > 0 and self.device.type == "cuda":
+                _lib.call("clift_set_cu_reserve", 0)
+        except Exception:
+            pass
+        try:
+            if getattr(self, "_shards", None) is not None:
+                _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), 0, 0, 1, _lib.stream())
+                self._shards.zero_()                                    # stream-ordered, behind whatever the aborted pass enqueued
+        except Exception:
+            pass
 
     def _pass_fold(self, *groups):
         """Add the shards of the named arena groups into the gradients and switch the shards off (every later kernel adds directly)."""

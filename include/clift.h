@@ -238,6 +238,23 @@ int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const 
  * clift_xyz_head_first2_bwd / clift_xyz_head_first2_wgrad).  Results within 1e-6 (row-max relative) of clift_xyz_head_first2_fwd. */
 int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
                                  const float* b1, int M, float* h2, int ldh2, clift_stream_t s);
+/* The fp32x6 counterparts of the three fused ends of an xyz head's backward / forward (ABI 14; csrc/layer_x6.hip, csrc/layer_x6w.hip): the
+ * 256 x 256 products as six bf16 products per fp32 product of exactly three-way-split operands (fp32 accumulate; within 1e-6 row-max relative
+ * of the exact-fp32 entry points they mirror), everything narrow -- the K = 3 layer, the ReLU masks, the E <= 4 output layer -- in exact fp32.
+ *   clift_xyz_head_first2_x6_bwd    = clift_xyz_head_first2_bwd   (tensoRF.py:475-476, 576-577): dH1 never written, mask never read;
+ *   clift_xyz_head_first2_x6_wgrad  = clift_xyz_head_first2_wgrad (tensoRF.py:477-478, 578-579): the first activation regenerated in the split;
+ *   clift_xyz_head_last2_x6_fwd     = clift_xyz_head_last2_fwd    (tensoRF.py:478-481): the output layer applied to the tile in registers; the
+ *     16 column-group partial sums of a row go through `workspace` (clift_xyz_head_last2_x6_workspace_bytes(M) bytes, 16-byte aligned,
+ *     the caller's scratch until the call has run on the stream) and are added in a fixed order by a second small launch: deterministic,
+ *     and a row's bits do not depend on how many rows share the launch. */
+int clift_xyz_head_first2_x6_bwd(const float* dH2, int ldd, const float* W1, int ldw1, const float* W0, int ldw0, const float* b0,
+                                 const float* x4, int M, float* gW0, int ldgw0, float* gb0, clift_stream_t s);
+int clift_xyz_head_first2_x6_wgrad(const float* dH2, int ldd, const float* W0, int ldw0, const float* b0, const float* x4, int M,
+                                   float* gW1, int ldgw1, float* gb1, clift_stream_t s);
+long clift_xyz_head_last2_x6_workspace_bytes(int M);
+int clift_xyz_head_last2_x6_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, void* workspace,
+                                long workspace_bytes, clift_stream_t s);
 /* Backward of the first TWO layers of an xyz head in one launch (tensoRF.py:475-478, 576-579; fp32, ABI 11).  dH2 (M, ldd) is the
  * gradient at the second layer's output, already masked by that layer's ReLU; W0 (256, 3) / b0 the first layer; x4 (M, 4) the sample
  * positions.  The second layer's input gradient dH1 = (W0 x + b0 > 0) . (dH2 W1) is formed tile by tile and consumed in place:
