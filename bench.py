@@ -24,7 +24,9 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PMC_RECORD = "profiles/r03_pmc_k_layer_f32.json"
+PMC_RECORD = "profiles/r03_pmc_k_layer_f32.json"        # exact-fp32 dominant kernel
+PMC_RECORD_X6 = "profiles/r04_pmc_k_layer_x6.json"      # fp32x6 dominant kernel (the default arithmetic)
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
@@ -40,8 +42,10 @@ def parse():
     ap.add_argument("--classes", type=int, default=22)
     ap.add_argument("--chunk", type=int, default=0, help="rays per renderer call; 0 = whole batch (reference: 2048)")
     ap.add_argument("--lean", action="store_true", help="skip the instance heads in the main pass (their output is discarded)")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp32x6"], default="fp32",
-                    help="MLP operand precision: fp32 (headline, BASELINE configs[1]) or bf16 operands / fp32 accumulate (configs[2])")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "fp32x6"], default="fp32x6",
+                    help="arithmetic of the 256-wide MLP layers: fp32x6 (default = the library's default: fp32-faithful three-way bf16 split, six "
+                         "products, fp32 accumulate; BASELINE configs[1]), fp32 (exact fp32 MFMA; also measured as an extra of the default run) "
+                         "or bf16 operands / fp32 accumulate (configs[2])")
     ap.add_argument("--inference-probe", action="store_true",
                     help="also report frame-render throughput and the lean main-pass time (both change the launch mix of the dominant "
                          "kernel: keep them out of profiled runs)")
@@ -133,6 +137,7 @@ def main():
     from contrastive_lift_amd import engine, synthetic
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
 
+    engine.set_mlp_precision(a.dtype)
     model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
     S = int(renderer.n_samples)
     if a.inference_sharded:
@@ -186,7 +191,7 @@ def main():
     # and recording ~80 events per step makes the step host-bound (+20 %); kernel durations are unaffected by that.
     real_gemm, real_first2, real_last2, real_app_last2, real_first2_bwd, real_first2_wgrad = (engine.gemm, engine.first2, engine.last2, engine.app_last2,
                                                                                               engine.first2_bwd, engine.first2_wgrad)
-    real_first2_x6 = engine.first2_x6
+    real_first2_x6, real_last2_x6, real_first2_x6_bwd, real_first2_x6_wgrad = engine.first2_x6, engine.last2_x6, engine.first2_x6_bwd, engine.first2_x6_wgrad
 
     def replay(select):
         """Re-run the timed steps from the snapshot with the selected matrix-core launches bracketed by HIP events.  Two launch sites:
@@ -204,36 +209,50 @@ def main():
             restore()
         out = []
 
-        def bracket(kind, M, N, K, extra_flops, fn):
+        def bracket(kind, M, N, K, extra_flops, nbytes, fn):
+            """nbytes = ALGORITHMIC HBM bytes of the launch: every operand row read once, every result row written once, weights once."""
             if not select(kind, N):
                 return fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn()
             e1.record()
-            out.append((kind, M, N, K, e0, e1, extra_flops))
+            out.append((kind, M, N, K, e0, e1, extra_flops, nbytes))
+        WB = 256 * 256 * 4.0                                # one 256 x 256 fp32 weight matrix
 
         def recorded_gemm(M, N, K, *args, **kw):
             kind = "wgrad" if kw.get("a_trans") else "dgrad" if kw.get("b_trans") else "fwd"
-            return bracket(kind, M, N, K, 0.0, lambda: real_gemm(M, N, K, *args, **kw))
+            if kind == "wgrad":
+                nb = 4.0 * K * (M + N) + 4.0 * M * N
+            else:
+                nb = 4.0 * M * (K + N) + 4.0 * N * K + (4.0 * M * N if kw.get("mask") is not None else 0.0)
+            return bracket(kind, M, N, K, 0.0, nb, lambda: real_gemm(M, N, K, *args, **kw))
 
-        def recorded_first2(M, *args):
-            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, lambda: real_first2(M, *args))
+        def recorded_first2(M, *args):                     # args = (xa, W0, b0, W1, b1, h1, h2)
+            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, M * (16.0 + 1024.0 * (2 if args[5] is not None else 1)) + WB, lambda: real_first2(M, *args))
 
-        def recorded_last2(M, h, W, b, Wo, *args):        # last hidden layer + narrow output layer (clift_xyz_head_last2_fwd)
-            return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], lambda: real_last2(M, h, W, b, Wo, *args))
+        def out_bytes(M, E, hidden, x6):                   # last hidden layer + output layer: row in, E outputs out, hidden if kept, x6: 256 B of partial sums out and back
+            return M * (1024.0 + 4.0 * E + (1024.0 if hidden is not None else 0.0) + (512.0 if x6 else 0.0)) + WB
+
+        def recorded_last2(M, h, W, b, Wo, bo, hidden, *args):        # last hidden layer + narrow output layer (clift_xyz_head_last2_fwd)
+            return bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], out_bytes(M, Wo.shape[0], hidden, False), lambda: real_last2(M, h, W, b, Wo, bo, hidden, *args))
         def recorded_app_last2(M, H1, W2, b2, W3, *args):  # appearance: last hidden layer + output layer + sigmoid (clift_app_head_last2_fwd)
-            return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], lambda: real_app_last2(M, H1, W2, b2, W3, *args))
+            return bracket("fwd_out", M, 128, 128, 2.0 * M * 128 * W3.shape[0], M * 1036.0, lambda: real_app_last2(M, H1, W2, b2, W3, *args))
         def recorded_first2_bwd(M, *args):                 # second layer's masked dgrad + the K = 3 layer's weight gradient (clift_xyz_head_first2_bwd)
-            return bracket("dgrad", M, 256, 256, 2.0 * M * 256 * 4, lambda: real_first2_bwd(M, *args))
+            return bracket("dgrad", M, 256, 256, 2.0 * M * 256 * 4, M * 1040.0 + WB, lambda: real_first2_bwd(M, *args))
         def recorded_first2_wgrad(M, *args):               # second layer's weight gradient over the regenerated first activation (clift_xyz_head_first2_wgrad)
-            return bracket("wgrad", 256, 256, M, 2.0 * M * 256 * 3, lambda: real_first2_wgrad(M, *args))
+            return bracket("wgrad", 256, 256, M, 2.0 * M * 256 * 3, M * 1040.0 + WB, lambda: real_first2_wgrad(M, *args))
         engine.gemm, engine.first2, engine.last2, engine.app_last2 = recorded_gemm, recorded_first2, recorded_last2, recorded_app_last2
         engine.first2_bwd, engine.first2_wgrad = recorded_first2_bwd, recorded_first2_wgrad
 
         def recorded_first2_x6(M, *args):                  # fp32x6 mode: the same fusion on the split kernel (clift_xyz_head_first2_x6_fwd)
-            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, lambda: real_first2_x6(M, *args))
+            return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, M * 1040.0 + WB, lambda: real_first2_x6(M, *args))
         engine.first2_x6 = recorded_first2_x6
+        # ... and the other fused ends of the mode (ABI 14)
+        engine.last2_x6 = lambda M, h, W, b, Wo, bo, hidden, *args: bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], out_bytes(M, Wo.shape[0], hidden, True),
+                                                                            lambda: real_last2_x6(M, h, W, b, Wo, bo, hidden, *args))
+        engine.first2_x6_bwd = lambda M, *args: bracket("dgrad", M, 256, 256, 2.0 * M * 256 * 4, M * 1040.0 + WB, lambda: real_first2_x6_bwd(M, *args))
+        engine.first2_x6_wgrad = lambda M, *args: bracket("wgrad", 256, 256, M, 2.0 * M * 256 * 3, M * 1040.0 + WB, lambda: real_first2_x6_wgrad(M, *args))
         try:
             for i in range(a.steps):
                 tr.training_step(batches[i % n_batches], lean=a.lean)
@@ -241,6 +260,7 @@ def main():
         finally:
             engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
             engine.first2_bwd, engine.first2_wgrad, engine.first2_x6 = real_first2_bwd, real_first2_wgrad, real_first2_x6
+            engine.last2_x6, engine.first2_x6_bwd, engine.first2_x6_wgrad = real_last2_x6, real_first2_x6_bwd, real_first2_x6_wgrad
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays
@@ -250,13 +270,15 @@ def main():
     # sat idle between the two records, and a single host hiccup (seen: 40 ms inside one bracket of the first process on a fresh box)
     # would otherwise pass for kernel time.  The replays are deterministic (same state, same batches), so launch i is the same work.
     def resolve(recs):
-        return [(kind, M, N, K, e0.elapsed_time(e1), xf) for kind, M, N, K, e0, e1, xf in recs]
+        return [(kind, M, N, K, e0.elapsed_time(e1), xf, nb) for kind, M, N, K, e0, e1, xf, nb in recs]
     dom_sel = lambda kind, N: kind in ("fwd", "fwd_gen", "fwd_out") and N > 128
     rec, rec_b = resolve(replay(dom_sel)), resolve(replay(dom_sel))
     # (same launch = same kind and shape at the same position; the row count may differ by a few samples between replays -- the gradient
     # atomics are not order-deterministic, so a later step's active-sample count can move by one or two)
     same = lambda x, y: x[0] == y[0] and x[2:4] == y[2:4] and abs(x[1] - y[1]) <= 0.01 * max(x[1], y[1])
+    rec_mean = rec          # what `roofline.frac` is built from: the MEAN of the two dominant-only replays per launch
     if len(rec) == len(rec_b) and all(same(x, y) for x, y in zip(rec, rec_b)):
+        rec_mean = [x[:4] + (0.5 * (x[4] + y[4]),) + x[5:] for x, y in zip(rec, rec_b)]
         rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, rec_b)]
     rec_all = resolve(replay(lambda kind, N: True))
     # every bracket is an UPPER bound of its kernel's time (it also contains any moment the GPU idled between the two records), and the third
@@ -265,10 +287,24 @@ def main():
     sub = [x for x in rec_all if dom_sel(x[0], x[2])]
     if len(sub) == len(rec) and all(same(x, y) for x, y in zip(rec, sub)):
         rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, sub)]
+    ar_ms, rank_ms = None, None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([dt, -dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        rank_ms = [-float(t[1]) / a.steps * 1e3, float(t[0]) / a.steps * 1e3]       # fastest / slowest rank's wall time per step
+        dt = float(t[0])
+        # the exchange by itself: the main pass's gradient range (what every backward all-reduces), 5 times, event-bracketed on this stream
+        r0, r1 = tr.main_range
+        gbuf = model.grad_flat[r0:r1]
+        dist.all_reduce(gbuf); sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(gbuf)
+        e1.record(); sync_all()
+        ar_ms = {"main_range_bytes": 4 * (r1 - r0), "ms": e0.elapsed_time(e1) / 5, "backend": backend,
+                 "note": "one all-reduce of the main pass's gradient range alone (no compute beside it), mean of 5"}
     ms_step = dt / a.steps * 1e3
     samples_step = world * (a.rays + a.inst_rays) * S
     value = samples_step / (dt / a.steps)
@@ -277,7 +313,7 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        roof = roofline(rec, rec_all, a.steps, engine, a.dtype, ms_step)
+        roof = roofline(rec_mean, rec_all, a.steps, engine, a.dtype, ms_step, rec_min=rec)
     if rank == 0 and world == 1:
         # ---- per-pass split and sample statistics (outside the timed region)
         def timed(fn, n=n_batches):          # cycles through the same batches as the timed loop
@@ -296,19 +332,33 @@ def main():
                      main_pass_samples_per_s=a.rays * S / t_main, instance_pass_samples_per_s=a.inst_rays * S / t_inst,
                      f_active=M / (a.rays * S), f_inbox_alpha_gt0=inbox / (a.rays * S), samples_per_ray=S)
         extra["active_samples_per_s_main_pass"] = M / t_main            # cost follows the ACTIVE samples; comparable across scenes
-        if not a.no_extras and a.dtype == "fp32":
+        if not a.no_extras and a.dtype in ("fp32", "fp32x6"):
             # the reference's main pass computes the instance heads and discards their output (T:155); without that dead work:
             t_lean = timed(lambda b: tr.main_pass(b[0], lean=True))
             extra["lean_main_pass_ms"] = round(t_lean * 1e3, 3)
             extra["lean_step_ms_estimate"] = round((t_lean + t_inst) * 1e3, 3)
-            # BASELINE configs[2] (bf16 MLP operands) and configs[4] (frame render) on the same scene, AFTER the timed fp32 region, so
-            # that the driver-run record carries them: same step definition, 10 steps after 3 warm-up steps / one 262144-ray tile
+            # The other arithmetics and shapes on the same scene, AFTER the timed region, so that the driver-run record carries them: the other
+            # fp32 arithmetic (exact fp32 MFMA when the run is the default fp32x6, and vice versa) with its own roofline, BASELINE configs[2]
+            # (bf16 MLP operands), configs[3]'s per-GPU shape with the strong-scaling projection, configs[4] (frame render): same step
+            # definition, 10 steps after 3 warm-up steps / one 262144-ray tile
             extra.update(inference_probe(cl, model, renderer, pool))
             extra.update(bf16_probe(a, dev, batches, S))
-            extra.update(x6_probe(a, dev, batches, S))
-            extra.update(small_batch_probe(a, dev, pool, S))
-        if not a.no_cpu_baseline:
-            cpu = cpu_baseline(model, renderer, batches[0], a, S)
+            extra.update(other_fp32_probe(a, dev, batches, S, "fp32" if a.dtype == "fp32x6" else "fp32x6"))
+            extra.update(small_batch_probe(a, dev, pool, S, tr.model.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")))
+        if roof is not None:
+            # (the driver's record keeps `roofline`, `config` and `cpu_baseline` whole and only the NAMES of other keys: what a reader of that
+            # record should see of the extras rides inside `roofline`)
+            for k in ("exact_fp32", "fp32x6", "bf16", "configs3_strong_scaling_projection", "inference_roofline"):
+                if k in extra:
+                    roof.setdefault("other_measurements", {})[k] = extra[k]
+    rccl_ranks = dist.get_world_size() if (world > 1 and backend == "nccl") else 0
+    if world > 1:
+        # every rank has left the timed region, the replays and the collectives: the group is done with.  Rank 0 then times the CPU path ALONE
+        # (the other ranks have exited; `cores` = what this process may use) and prints the line.
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(model, renderer, batches[0], a, S)
     if rank == 0:
         line = {"metric": "ray-samples/sec (train step) at 4096 rays", "value": value, "unit": "ray-samples/s",
                 "main_pass_samples_per_s": extra.get("main_pass_samples_per_s"), "n_gpus": world,
@@ -317,28 +367,38 @@ def main():
                 "value_definition": "nominal ray-samples of one full training_step = (main-pass rays + instance-pass rays) x S, over all ranks, / step time; the "
                                     "main pass alone (the 4096 rays of the metric's name) is `main_pass_samples_per_s`, and because cost follows the ACTIVE "
                                     "samples (f_active of the nominal ones) `active_samples_per_s_main_pass` is the scene-independent figure",
-                "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32 (fp32-faithful 6-product bf16 split on the matrix cores)"}[a.dtype],
+                "dtype": {"fp32": "f32", "bf16": "bf16", "fp32x6": "f32"}[a.dtype],
                 "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[1] stand-in: ScanNet-shaped scene (C=22, E=3/D=6, grid 128^3, S=440), "
-                                        "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype == "fp32" else
+                                        "full training_step = main pass 4096 rays + slow-fast instance pass 1024 rays, fp32") if a.dtype != "bf16" else
                                        (f"BASELINE configs[2]-style bf16 mode on the configs[1] shapes (C={a.classes}, E=3/D=6, grid {a.grid}^3): MLP "
                                         "operands bf16 (weights rounded in-kernel, hidden activations / gradients bf16-stored), fp32 accumulate; everything else fp32"),
+                           "mlp_arithmetic": MLP_ARITHMETIC[a.dtype],
+                           "main_pass_samples_per_s": extra.get("main_pass_samples_per_s"),
                            "rays_per_gpu": a.rays, "instance_rays_per_gpu": a.inst_rays, "grid": a.grid, "classes": a.classes,
                            "samples_per_ray": S, "chunk": a.chunk or a.rays, "lean_main_pass": bool(a.lean), "sync_free": bool(a.nosync),
                            "parallelism": f"dp{world} (rays sharded, 1 all-reduce per backward)"},
                 "roofline": roof, "cpu_baseline": cpu,
-                "dist_backend": backend, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0),
+                "dist_backend": backend, "rccl_ranks": rccl_ranks,
                 "devices_visible": torch.cuda.device_count(),
                 "allreduce_overlap": (tr.overlap_decision or {"overlap": tr.overlap_allreduce}) if world > 1 else None,
-                "allreduce_cu_reserve": tr.allreduce_cu_reserve if world > 1 else None}
+                "allreduce_cu_reserve": tr.allreduce_cu_reserve if world > 1 else None,
+                "allreduce_ms": ar_ms, "rank_ms_per_step_min_max": rank_ms}
         line.update(extra)
         line["step_ms_median"] = step_ms[len(step_ms) // 2]
         line["step_ms_min_max"] = [step_ms[0], step_ms[-1]]
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
 
 
+MLP_ARITHMETIC = {
+    "fp32x6": "fp32 in, fp32 out, fp32-FAITHFUL products on the bf16 matrix cores for the 256-wide layers (forward, input gradient, weight gradient): every "
+              "fp32 operand is split exactly into three bf16 terms (8 + 8 + 8 significant bits), the six leading cross products run on "
+              "v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped terms are below one fp32 rounding of the product (row-max relative "
+              "error vs float64 2e-7 .. 8e-7 = the exact-fp32 kernels' own; tests/test_gpu_round3.py, test_gpu_round4.py); K = 3 / E <= 32 / 128-wide "
+              "layers, activations, losses, tables and the optimizer are plain fp32",
+    "fp32": "exact fp32 products on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain), fp32 accumulate",
+    "bf16": "MLP operands rounded to bf16 (RNE) in the kernels, hidden activations / hidden gradients bf16-stored, fp32 accumulate; everything else fp32",
+}
 FRAME_W, FRAME_H = 1296, 968             # BASELINE configs[4]: ScanNet colour frame
 
 
@@ -396,21 +456,32 @@ def bench_inference_sharded(a, model, renderer, dev, world, rank, backend):
         tf = act * world * fl / t_frame / 1e12          # tiles are equal-sized; this rank's active fraction stands for the frame
         print(json.dumps({"metric": "rays/sec (full-frame 1296x968 render, row tiles sharded over the ranks)", "value": P / t_frame,
                           "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": t_frame * 1e3,
-                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"fp32": "f32"}.get(a.dtype, a.dtype),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32x6": "f32"}.get(a.dtype, a.dtype),
                           "data": "synthetic",
                           "config": {"workload": "BASELINE configs[4] stand-in: one 1296x968 frame (1,254,528 rays), is_train=False, S=%d, "
                                                  "chunk %d rays, rgb/semantics/instances/distance outputs" % (S, chunk),
+                                     "mlp_arithmetic": MLP_ARITHMETIC[a.dtype],
                                      "rays_per_frame": P, "samples_per_ray": S, "classes": a.classes, "grid": a.grid,
                                      "parallelism": f"row tiles over {world} rank(s), 1 all-gather per frame"},
                           "ray_samples_per_s": P * S / t_frame,
-                          "inference_roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                                 "frac": tf / PEAK_FP32_MFMA_TFLOPS, "active_samples_per_ray": act * world / P,
-                                                 "flops_per_active_sample": fl,
-                                                 "note": "head FLOPs of the frame's active samples / frame time / exact-fp32 MFMA peak"},
+                          "inference_roofline": inference_roofline_object(tf, a.dtype, act * world / P, fl),
                           "dist_backend": backend, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0),
                           "devices_visible": torch.cuda.device_count()}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def inference_roofline_object(tf, mode, act_per_ray, fl):
+    """Whole-render figure: forward head FLOPs (fp32-equivalent 2MNK) of the active samples / render time, against the matrix-core peak of the
+    arithmetic in use (fp32x6: 6 bf16 products per fp32 product of the 256-wide layers, ~92 % of the FLOPs, against the dense bf16 peak)."""
+    if mode == "fp32x6":
+        return {"bound": "mfma", "achieved": 6.0 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent head FLOPs)",
+                "frac": 6.0 * tf / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent_tflops": tf, "fp32_equivalent_vs_exact_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS,
+                "active_samples_per_ray": act_per_ray, "flops_per_active_sample": fl,
+                "note": "head FLOPs of the active samples / render time (includes every non-MLP kernel of the render)"}
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+            "active_samples_per_ray": act_per_ray, "flops_per_active_sample": fl,
+            "note": "head FLOPs of the active samples / render time / exact-fp32 MFMA peak"}
 
 
 def engine_render_forward(model, renderer, rays):
@@ -468,21 +539,53 @@ def extras_step_time(tr, batches, steps, lean):
     return ts[steps // 2] * 1e-3
 
 
-def x6_probe(a, dev, batches, S, steps=10, warmup=3):
-    """The same training_step with mlp_dtype "fp32x6": the 256 x 256 hidden layers (forward / dgrad) as fp32-FAITHFUL six-product bf16 splits on
-    the bf16 matrix cores (csrc/layer_x6.hip); every other launch on its exact-fp32 kernel.  Reported beside the exact-fp32 headline."""
+def forward_family_pass(tr, batches, lean, steps=3):
+    """Event brackets around the dominant family's launches (the 256 x 256 forward layers of the xyz heads, every instantiation) over `steps`
+    training steps of `tr`'s arithmetic: returns (fp32-equivalent FLOPs, ms, launches)."""
+    from contrastive_lift_amd import engine
+    names = ("gemm", "first2", "last2", "first2_x6", "last2_x6")
+    real = {n: getattr(engine, n) for n in names}
+    rec = []
+
+    def bracket(flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        rec.append((flops, e0, e1))
+
+    def gemm(M, N, K, *args, **kw):
+        if N == 256 and K == 256 and not kw.get("a_trans") and not kw.get("b_trans"):
+            return bracket(2.0 * M * N * K, lambda: real["gemm"](M, N, K, *args, **kw))
+        return real["gemm"](M, N, K, *args, **kw)
+    wrap_gen = lambda fn: (lambda M, *args: bracket(2.0 * M * 256 * (256 + 3), lambda: fn(M, *args)))
+    wrap_out = lambda fn: (lambda M, h, W, b, Wo, *args: bracket(2.0 * M * 256 * (256 + Wo.shape[0]), lambda: fn(M, h, W, b, Wo, *args)))
+    engine.gemm = gemm
+    engine.first2, engine.first2_x6 = wrap_gen(real["first2"]), wrap_gen(real["first2_x6"])
+    engine.last2, engine.last2_x6 = wrap_out(real["last2"]), wrap_out(real["last2_x6"])
+    try:
+        for i in range(steps):
+            tr.training_step(batches[i % len(batches)], lean=lean)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(engine, n, real[n])
+    return sum(f for f, _, _ in rec), sum(e0.elapsed_time(e1) for _, e0, e1 in rec), len(rec) // steps
+
+
+def other_fp32_probe(a, dev, batches, S, mode, steps=10, warmup=3):
+    """The same training_step in the OTHER fp32 arithmetic (exact fp32 MFMA when the timed run is the default fp32x6, and vice versa) on a fresh
+    copy of the scene, with the roofline of its own dominant kernel family (the 256 x 256 forward layers) and its frame-render rate."""
     from contrastive_lift_amd import engine, synthetic
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
-    prev = engine.set_mlp_precision("fp32x6")
+    prev = engine.set_mlp_precision(mode)
     try:
         model, renderer, pool = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
         tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0,
-                                                            mlp_dtype="fp32x6"), current_epoch=4)
+                                                            mlp_dtype=mode), current_epoch=4)
         for i in range(warmup):
             tr.training_step(batches[i % len(batches)], lean=a.lean)
         torch.cuda.synchronize()
         dt = extras_step_time(tr, batches, steps, a.lean)
-        # frame render in fp32x6 mode (same rays / chunking as the bf16 probe's and the exact path's `inference_rays_per_s`)
+        fl, ms, per_step = forward_family_pass(tr, batches, a.lean)
         from contrastive_lift_amd import inference as inf
         ratio = renderer.step_ratio
         renderer.update_step_ratio(ratio * 0.5)
@@ -498,25 +601,52 @@ def x6_probe(a, dev, batches, S, steps=10, warmup=3):
             renderer.update_step_ratio(ratio)
     finally:
         engine.set_mlp_precision(prev)
-    return dict(fp32x6_ms_per_step=round(dt * 1e3, 3), fp32x6_ray_samples_per_s=(a.rays + a.inst_rays) * S / dt, fp32x6_inference_rays_per_s=inf_rate,
-                fp32x6_note="fp32-faithful (6 bf16 products of exactly split operands, fp32 accumulate): outputs / gradients meet the exact path's "
-                            "test tolerances (tests/test_gpu_round3.py, CLIFT_FORCE_MLP_DTYPE=fp32x6 runs of the suite); not the headline")
+    tfl = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    if mode == "fp32":
+        roof = {"bound": "mfma", "kernel": "k_layer_f32<false, *, *, false> (csrc/layer_f32.hip, v_mfma_f32_32x32x2_f32)", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": per_step}
+        key = "exact_fp32"
+    else:
+        roof = {"bound": "mfma", "kernel": "k_layer_x6<false, *> (csrc/layer_x6.hip, v_mfma_f32_32x32x16_bf16 x 6)", "achieved": 6.0 * tfl, "peak": PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent 2MNK)", "frac": 6.0 * tfl / PEAK_BF16_MFMA_TFLOPS, "fp32_equivalent_tflops": tfl,
+                "launches_per_step": per_step}
+        key = "fp32x6"
+    return {key: {"mlp_arithmetic": MLP_ARITHMETIC[mode], "ms_per_step": round(dt * 1e3, 3), "ray_samples_per_s": (a.rays + a.inst_rays) * S / dt,
+                  "inference_rays_per_s": inf_rate, "roofline": roof,
+                  "note": f"same scene, same batches, {steps} steps after {warmup} warm-up steps (median of per-step GPU times); the roofline brackets are taken over 3 further steps"},
+            f"{key}_ms_per_step": round(dt * 1e3, 3)}
 
 
-def small_batch_probe(a, dev, pool, S, rays=1024, steps=10, warmup=3):
+def small_batch_probe(a, dev, pool, S, main_range, rays=1024, steps=10, warmup=3):
     """BASELINE configs[3] per-GPU shape: 8192 rays per step over 8 GPUs = 1024 main-pass rays per rank (+ one 1024-ray instance image per rank,
-    as the reference's DDP), exact fp32, on this one GPU.  The ideal is a quarter of the 4096-ray main pass + the unchanged instance pass."""
+    as the reference's DDP), in the library's default arithmetic, on this one GPU -- and the same step at the job's whole 8192 rays on this GPU:
+    their ratio, with the gradient all-reduce priced in, projects the strong-scaling figure of configs[3] on 8 GPUs."""
     from contrastive_lift_amd import synthetic
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
-    model, renderer, _ = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
-    tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0), current_epoch=4)
-    bs = [synthetic.make_batches(pool, rays, a.inst_rays, a.classes, 25, seed=300 + i, device=dev) for i in range(4)]
-    for i in range(warmup):
-        tr.training_step(bs[i % 4], lean=a.lean)
-    torch.cuda.synchronize()
-    dt = extras_step_time(tr, bs, steps, a.lean)
-    return dict(rays1024_ms_per_step=round(dt * 1e3, 3), rays1024_ray_samples_per_s=(rays + a.inst_rays) * S / dt,
-                rays1024_note="configs[3] per-GPU shape (8192 global rays / 8 ranks): 1024 main-pass rays + 1024 instance rays per step, exact fp32")
+    out = {}
+    for n in (rays, 8 * rays):
+        model, renderer, _ = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+        tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype), current_epoch=4)
+        bs = [synthetic.make_batches(pool, n, a.inst_rays, a.classes, 25, seed=300 + i, device=dev) for i in range(4)]
+        for i in range(warmup):
+            tr.training_step(bs[i % 4], lean=a.lean)
+        torch.cuda.synchronize()
+        out[n] = extras_step_time(tr, bs, steps, a.lean)
+    nbytes = 4 * (main_range[1] - main_range[0])
+    # ring all-reduce over the 8 GPUs of a node: 2 (N-1)/N of the buffer per link direction; RCCL reaches ~150 GB/s bus bandwidth at this
+    # message size on xGMI (7 links x ~50 GB/s per direction shared by the ring's two neighbours), + ~40 us of launch / sync latency per collective
+    ar_ms = 2.0 * 7 / 8 * nbytes / 150e9 * 1e3 + 0.04 + 0.04
+    t1, t8 = out[8 * rays] * 1e3, out[rays] * 1e3
+    return {"rays1024_ms_per_step": round(t8, 3), "rays1024_ray_samples_per_s": (rays + a.inst_rays) * S / out[rays],
+            "rays8192_ms_per_step": round(t1, 3),
+            "rays1024_note": f"configs[3] per-GPU shape (8192 global rays / 8 ranks): 1024 main-pass rays + 1024 instance rays per step, {a.dtype}",
+            "configs3_strong_scaling_projection": {
+                "projected_strong_scaling_8gpu": t1 / (t8 + ar_ms), "one_gpu_8192_rays_ms": round(t1, 3), "per_gpu_1024_rays_ms": round(t8, 3),
+                "allreduce_ms_estimate": round(ar_ms, 3), "allreduce_bytes": nbytes,
+                "ideal_given_the_per_rank_instance_pass": "every rank renders its OWN 1024-ray instance image whatever the rank count (the reference's DDP): with a "
+                                                          "perfectly linear main pass the ratio is (8 m + i) / (m + i) -- it only reaches 8 when i = 0",
+                "note": "(one GPU at 8192 + 1024 rays) / (one GPU at 1024 + 1024 rays + an ESTIMATED all-reduce of the main gradient range + the instance range): "
+                        "both step times measured here, the all-reduce priced at 150 GB/s ring bus bandwidth + 40 us per collective (no multi-GPU node in this run)"}}
 
 
 def bf16_roofline_pass(tr, batches, lean, steps=3):
@@ -599,110 +729,122 @@ def inference_probe(cl, model, renderer, pool, n_rays=262144, chunk=32768):
         renderer.update_step_ratio(ratio)
     fl = head_flops_per_active_sample(model)
     tf = act * fl / dt / 1e12
-    return dict(inference_roofline={"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
-                                    "active_samples_per_ray": act / rays.shape[0], "flops_per_active_sample": fl,
-                                    "note": "forward head FLOPs of the tile's active samples / render time / exact-fp32 MFMA peak"},
+    from contrastive_lift_amd import engine
+    mode = {0: "fp32", 1: "bf16", 2: "fp32x6"}[engine.MLP_PRECISION]
+    return dict(inference_roofline=inference_roofline_object(tf, mode, act / rays.shape[0], fl),
                 inference_rays_per_s=rays.shape[0] / dt, inference_ray_samples_per_s=rays.shape[0] * S / dt,
                 inference_samples_per_ray=S, inference_probe=f"{rays.shape[0]} rays, chunk {chunk}, fp32 outputs rgb/sem/inst/dist")
 
 
-def measured_traffic_ratio():
+def measured_traffic_ratio(record=None):
     """HBM bytes of the dominant kernel from counters, as a ratio to its algorithmic bytes: profiles/r03_pmc_k_layer_f32.json holds
     the rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     16-byte-per-lane streaming reads on gfx950) over this very command and over the torch-free single-kernel harness."""
     try:
-        with open(os.path.join(REPO, PMC_RECORD)) as f:
+        with open(os.path.join(REPO, record or PMC_RECORD)) as f:
             return json.load(f)
     except (OSError, ValueError):
         return None
 
 
-def roofline(rec_dom, rec, nb, engine, dtype="fp32", ms_step=None):
-    """``rec`` = the (kind, M, N, K, start event, end event) records of every clift_gemm launch of the ``nb`` timed steps.  The
-    dominant kernel by time is k_layer_f32<false> (csrc/layer_f32.hip) = the 256x256 forward layers of the semantic / fast /
-    slow instance MLPs as a persistent kernel (rocprofv3 lists it under exactly that name, profiles/r01_v12_*): achieved = its
-    algorithmic FLOPs (2*M*256*256 per launch, M = active samples of the pass) / its summed launch durations; peak = dense fp32
-    MFMA.  ``all_gemm`` is the same ratio over every matrix-core launch (forward, dgrad, wgrad, narrow layers).  The active-sample
-    count drifts while the field trains, which is why the records come from a replay of exactly the timed steps."""
+def roofline(rec_dom, rec, nb, engine, dtype="fp32x6", ms_step=None, rec_min=None):
+    """Roofline object of the dominant kernel family of the timed steps.
+
+    ``rec`` = (kind, M, N, K, ms, extra FLOPs, algorithmic bytes) of EVERY matrix-core launch of the ``nb`` replayed steps (informational
+    ``all_gemm`` split; ~60 events per step make that replay host-bound, so its times are upper bounds); ``rec_dom`` = the same for the
+    dominant family only -- the 256 x 256 FORWARD layers of the xyz heads, 11 launches per step: k_layer_x6<false, *> in the default
+    fp32x6 arithmetic (csrc/layer_x6.hip), k_layer_f32<false, *> in exact fp32 (csrc/layer_f32.hip) -- as the per-launch MEAN of two
+    replays in which only those launches carry events (the step stays GPU-bound); ``rec_min`` = per-launch minimum over all three replays
+    (reported as `frac_best_of_3_brackets`).  achieved = algorithmic FLOPs (2 M N K per launch, M = active samples of the pass; x 6 bf16
+    products in fp32x6) / summed launch durations.  The active-sample count drifts while the field trains, which is why the records come
+    from replays of exactly the timed steps."""
+    tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     tot_f, tot_ms, by = 0.0, 0.0, {}
-    dom_f, dom_ms, dom_n = 0.0, 0.0, 0
-    for kind, M, N, K, ms, xf in rec:
+    for kind, M, N, K, ms, xf, _ in rec:
         fl = 2.0 * M * N * K + xf
-        tot_f += fl
-        tot_ms += ms
+        tot_f += fl; tot_ms += ms
         b = by.setdefault(kind, [0.0, 0.0, 0])
         b[0] += fl; b[1] += ms; b[2] += 1
-    inst = {}
-    dump = os.environ.get("CLIFT_BENCH_DUMP")
-    for kind, M, N, K, ms, xf in rec_dom:
-        if dump:
+
+    def family(records):
+        """Sums over the dominant family: [main FLOPs (2MNK), extra exact FLOPs, ms, launches, bytes] in total and per instantiation."""
+        tot, inst = [0.0, 0.0, 0.0, 0, 0.0], {}
+        for kind, M, N, K, ms, xf, nbytes in records:
+            for acc in (tot, inst.setdefault(kind, [0.0, 0.0, 0.0, 0, 0.0])):
+                acc[0] += 2.0 * M * N * K; acc[1] += xf; acc[2] += ms; acc[3] += 1; acc[4] += nbytes or 0.0
+        return tot, inst
+    dom, inst = family(rec_dom)
+    dom_best, _ = family(rec_min if rec_min is not None else rec_dom)
+    if os.environ.get("CLIFT_BENCH_DUMP"):
+        for kind, M, N, K, ms, xf, _ in rec_dom:
             print(f"[dom] {kind} M={M} N={N} K={K} {ms:.4f} ms", file=sys.stderr)
-        dom_f += 2.0 * M * N * K + xf; dom_ms += ms; dom_n += 1
-        b = inst.setdefault(kind, [0.0, 0.0, 0])
-        b[0] += 2.0 * M * N * K + xf; b[1] += ms; b[2] += 1
-    tf = lambda f, ms: f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    ach = tf(dom_f, dom_ms)
+    ach = tf(dom[0] + dom[1], dom[2])                      # fp32-equivalent TFLOP/s of the family
+    all_gemm = {"fp32_equiv_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
+                "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}
+    gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     if dtype == "bf16":
-        # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its
-        # activations.  Algorithmic bytes per launch = A read + C written (M x 256 x 2 bytes each, bf16-stored) + weights (256 KB, L2).
-        esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0          # hidden activations are bf16-stored in bf16 mode
-        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _ in rec_dom)
-        gbs = dom_b / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # bf16 operands run the same layers at 16x the MFMA rate: the dominant kernel is then bound by streaming its activations
+        # (bf16-stored: half the bytes the fp32 brackets counted for the activation rows).
+        esz = 2.0 if engine.act_dtype() == torch.bfloat16 else 4.0
+        dom_b = sum(esz * M * K + esz * M * N + 4.0 * N * K for kind, M, N, K, _, _, _ in rec_dom)
+        g = gbs(dom_b, dom[2])
         return {"bound": "hbm", "kernel": "k_layer_bf16<false,3> (persistent streamed 256x256 forward layers: weights in registers, LDS-DMA ring, v_mfma_f32_32x32x16_bf16; bf16-stored activations)",
-                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "mfma_tflops_of_same_kernel": ach,
-                "all_gemm": {"achieved_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb,
-                             "gflop_per_step": tot_f / 1e9 / nb,
-                             "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
+                "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS, "traffic": None,
+                "launches_per_step": dom[3] // nb, "avg_launch_ms": dom[2] / max(1, dom[3]), "mfma_tflops_of_same_kernel": ach, "all_gemm": all_gemm}
     if dtype == "fp32x6":
-        # fp32x6: the 256 x 256 forward layers run as six bf16 products per fp32 product on the bf16 matrix cores (csrc/layer_x6.hip).  Two ceilings,
-        # both reported: the bf16 MFMA pipe (6 x 2MNK FLOPs per launch against the 2.5 PFLOP/s dense peak) and HBM (a row read + a row written).
-        plain = inst.get("fwd", [dom_f, dom_ms, dom_n])
-        rows = plain[0] / (2.0 * 256 * 256)                                  # summed rows of the plain launches
-        bytes_plain = rows * 2048.0 + plain[2] * 256 * 256 * 4.0
-        bf16_tf = 6.0 * ach
-        gbs = bytes_plain / (plain[1] * 1e-3) / 1e9 if plain[1] > 0 else 0.0
-        return {"bound": "mfma", "kernel": "k_layer_x6<false, *> (persistent fp32-faithful split kernel: pair of workgroups per row range, the weights' three "
-                                           "bf16 planes in registers, cooperative activation split through LDS-DMA staging, v_mfma_f32_32x32x16_bf16; "
-                                           "eight waves = 4 column groups x 2 k-halves meeting through LDS)",
-                "achieved": bf16_tf, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent 2MNK)", "frac": bf16_tf / 2500.0,
-                "fp32_equivalent_tflops": ach, "fp32_equivalent_vs_exact_fp32_peak": ach / PEAK_FP32_MFMA_TFLOPS,
-                "hbm_GBps_plain_launches": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                "note": "a bare stream of these MFMAs (no memory, no VALU) runs 113 us per 249 k-row launch on this chip = 1.73 PFLOP/s at the ~1.7 GHz it "
-                        "holds under that load; with the 255 MB of output writes the kernel sits at ~190 us (profiles/r03_x6_notes.txt)",
-                "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n),
-                "instantiations": {k: {"fp32_equiv_tflops": tf(v[0], v[1]), "launches_per_step": v[2] // nb, "avg_launch_ms": v[1] / max(1, v[2])} for k, v in inst.items()},
-                "all_gemm": {"fp32_equiv_tflops": tf(tot_f, tot_ms), "launches_per_step": len(rec) // nb, "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
-                             "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
-    # algorithmic bytes of the average launch: the plain instantiation reads a 1 KB row and writes one per sample; the generating one reads
-    # 16 B and writes 1 KB (2 KB when the first layer's activation is kept); the output-fused one reads 1 KB and writes 16 B (+ 1 KB when kept).
-    # Reported for the plain instantiation, the one the counter passes measured (8 B per output element + 256 KB weights).
-    plain = inst.get("fwd", [dom_f, dom_ms, dom_n])
-    alg_bytes = (plain[0] / max(1, plain[2])) / (2.0 * 256.0) * 8.0 + 256.0 * 256.0 * 4.0
-    pmc = measured_traffic_ratio()
+        # Two ceilings, both reported: the bf16 matrix pipe (6 bf16 products per fp32 product: 6 x 2MNK FLOPs against the 2.5 PFLOP/s dense
+        # peak; the K = 3 / output layers' exact VALU FLOPs counted once) and HBM (algorithmic bytes per launch against 8 TB/s).
+        x6tf = lambda v: tf(6.0 * v[0] + v[1], v[2])
+        bf16_tf, g = x6tf(dom), gbs(dom[4], dom[2])
+        pmc = measured_traffic_ratio(PMC_RECORD_X6)
+        names = {"fwd": "k_layer_x6<false, false, 0> (input streamed, output written)", "fwd_gen": "k_layer_x6<false, true, 0> (K = 3 input layer generated in-kernel)",
+                 "fwd_out": "k_layer_x6<false, false, 1|2> + k_x6_out_sum (E <= 4 output layer applied in-kernel)"}
+        out = {"bound": "mfma",
+               "kernel": "k_layer_x6<false, *> (csrc/layer_x6.hip: persistent fp32-faithful split kernel -- the 256x256 forward layers of the xyz heads, 11 launches per "
+                         "step in three instantiations; pair of workgroups per row range, the weights' three bf16 planes in registers, cooperative activation split "
+                         "through LDS-DMA staging, v_mfma_f32_32x32x16_bf16, eight waves = 4 column groups x 2 k-halves meeting through LDS)",
+               "achieved": bf16_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent 2MNK)", "frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
+               "frac_is": "mean of two event-bracketed replays of the timed steps per launch (rocprofv3 average of the same command: profiles/r04_kernel_stats_fp32x6.txt)",
+               "frac_best_of_3_brackets": x6tf(dom_best) / PEAK_BF16_MFMA_TFLOPS,
+               "fp32_equivalent_tflops": ach, "fp32_equivalent_vs_exact_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+               "hbm": {"achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
+                       "bytes": "algorithmic: 1 KB per activation row read / written, 16 B per generated row, 256 B per row of output-layer partial sums written "
+                                "and read back, 256 KB weights per launch"},
+               "traffic": (dom[4] / max(1, dom[3]) * pmc["bench_ratio"]) if pmc else None,
+               "traffic_unit": "bytes/launch (average launch of this run)", "traffic_algorithmic": dom[4] / max(1, dom[3]),
+               "traffic_over_algorithmic": pmc["bench_ratio"] if pmc else None,
+               "traffic_is": ("ESTIMATE = this run's algorithmic bytes x the counter/algorithmic ratio RECORDED in " + PMC_RECORD_X6 + " (rocprofv3 --pmc FETCH_SIZE / "
+                              "WRITE_SIZE, separate passes, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950; not re-measured by this run)") if pmc else None,
+               "note": "a bare stream of these MFMAs (no memory, no VALU) runs 113 us per 249 k-row launch on this chip = 1.73 PFLOP/s at the ~1.7 GHz it holds "
+                       "under that load (profiles/r03_x6_notes.txt): the 2.5 PFLOP/s peak assumes 2.4 GHz",
+               "launches_per_step": dom[3] // nb, "avg_launch_ms": dom[2] / max(1, dom[3]),
+               "instantiations": {names[k]: {"bf16_mfma_tflops": x6tf(v), "frac": x6tf(v) / PEAK_BF16_MFMA_TFLOPS, "hbm_GBps": gbs(v[4], v[2]),
+                                             "launches_per_step": v[3] // nb, "avg_launch_ms": v[2] / max(1, v[3])} for k, v in inst.items()},
+               "all_gemm": all_gemm}
+        if ms_step:
+            out["step_gflop_fp32_equiv"] = tot_f / 1e9 / nb
+            out["step_fp32_equiv_tflops"] = (tot_f / nb) / (ms_step * 1e-3) / 1e12
+        return out
+    # exact fp32
+    plain = inst.get("fwd", dom)
+    alg_bytes = plain[4] / max(1, plain[3])
+    pmc = measured_traffic_ratio(PMC_RECORD)
     names = {"fwd": "k_layer_f32<false, false, false, false>", "fwd_gen": "k_layer_f32<false, true, false, false>", "fwd_out": "k_layer_f32<false, false, true, false>"}
+    etf = lambda v: tf(v[0] + v[1], v[2])
     out = {"bound": "mfma", "kernel": "k_layer_f32<false, *, *, false> (persistent fp32 v_mfma_f32_32x32x2_f32 kernel: the 256x256 forward MLP layers of the xyz heads, "
                                       "11 launches per step in three instantiations -- input streamed from memory / K = 3 input layer generated in-kernel / narrow "
                                       "output layer applied in-kernel; rocprofv3 lists them separately: see `instantiations`)",
-           "instantiations": {names[k]: {"tflops": tf(v[0], v[1]), "frac": tf(v[0], v[1]) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": v[2] // nb,
-                                         "avg_launch_ms": v[1] / max(1, v[2])} for k, v in inst.items()},
+           "instantiations": {names[k]: {"tflops": etf(v), "frac": etf(v) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": v[3] // nb,
+                                         "avg_launch_ms": v[2] / max(1, v[3])} for k, v in inst.items()},
            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-           # HBM bytes per (average) launch of the dominant kernel: algorithmic bytes of THIS run's average launch (A read once + C
-           # written once = 8 B per output element, + 256 KB weights) x the counter/algorithmic ratio measured by rocprofv3 --pmc on
-           # the same command (profiles/r03_pmc_k_layer_f32.json); null if that record is missing
+           "frac_is": "mean of two event-bracketed replays of the timed steps per launch", "frac_best_of_3_brackets": etf(dom_best) / PEAK_FP32_MFMA_TFLOPS,
            "traffic": (alg_bytes * pmc["bench_ratio"]) if pmc else None,
-           "traffic_is": "ESTIMATE = this run's algorithmic bytes x the counter/algorithmic ratio RECORDED in " + PMC_RECORD + " (not re-measured by this run: "
-                         "PMC passes need rocprofv3 around the process; tools/gpu_pmc_bench.sh re-records it)",
-           "traffic_unit": "bytes/launch (average launch of this run)",
-           "traffic_algorithmic": alg_bytes,
+           "traffic_is": "ESTIMATE = this run's algorithmic bytes (plain instantiation) x the counter/algorithmic ratio RECORDED in " + PMC_RECORD,
+           "traffic_unit": "bytes/launch (average plain launch of this run)", "traffic_algorithmic": alg_bytes,
            "traffic_over_algorithmic": pmc["bench_ratio"] if pmc else None,
-           "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE x2, gfx950 correction of MI355X_MICROARCH.md) "
-                              "over `python bench.py --steps 3 --warmup 1`: profiles/r03_pmc_k_layer_f32.json") if pmc else None,
            "mfma_busy_frac_counters": pmc.get("mfma_busy_frac") if pmc else None,
-           "launches_per_step": dom_n // nb, "avg_launch_ms": dom_ms / max(1, dom_n), "gflop_per_launch_avg": dom_f / max(1, dom_n) / 1e9,
-           "all_gemm": {"achieved": tf(tot_f, tot_ms), "frac": tf(tot_f, tot_ms) / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": len(rec) // nb,
-                        "ms_per_step": tot_ms / nb, "gflop_per_step": tot_f / 1e9 / nb,
-                        "by_kind": {k: {"tflops": tf(v[0], v[1]), "ms": v[1] / nb, "launches": v[2] // nb} for k, v in by.items()}}}
+           "launches_per_step": dom[3] // nb, "avg_launch_ms": dom[2] / max(1, dom[3]), "gflop_per_launch_avg": (dom[0] + dom[1]) / max(1, dom[3]) / 1e9,
+           "all_gemm": dict(all_gemm, achieved=all_gemm["fp32_equiv_tflops"], frac=all_gemm["fp32_equiv_tflops"] / PEAK_FP32_MFMA_TFLOPS)}
     if ms_step:
         # whole-step fraction of the fp32-MFMA roof: every matrix-core FLOP of a step / the step's wall time / peak
         out["step_gflop"] = tot_f / 1e9 / nb

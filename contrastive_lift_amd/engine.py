@@ -90,11 +90,16 @@ def _pitch(t):
     return t.stride(0) if t.dim() == 2 else 1
 
 
-# MLP operand precision of every matrix-core launch: 0 = fp32 (default, exact fp32 products), 1 = "bf16 mode" (operands
-# rounded to bf16 in the kernel, fp32 accumulate, fp32 tensors in memory) -- BASELINE config 3 / SURVEY 7.9.
-# 2 = "fp32x6": fp32-faithful 6-product bf16 split on the matrix cores for the forward / dgrad launches (opt-in).
+# MLP arithmetic of the matrix-core launches: 0 = "fp32" (exact fp32 products on the fp32 MFMA), 1 = "bf16" (operands rounded to bf16 in the
+# kernel, fp32 accumulate, hidden activations bf16-stored -- BASELINE configs[2] / SURVEY 7.9), 2 = "fp32x6": every fp32 operand split
+# EXACTLY into three bf16 terms (8 + 8 + 8 significant bits), the six leading cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate --
+# fp32-faithful (the dropped terms are below one fp32 rounding of the product) for the 256-wide layers; narrow / 128-wide layers stay exact.
 _PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32x6": 2}
-MLP_PRECISION = _PRECISIONS[os.environ.get("CLIFT_MLP_DTYPE", "fp32").lower()]
+# The default since round 4 is fp32x6: fp32 results to fp32 round-off (row-max relative error against float64 2e-7 .. 8e-7, the exact kernels'
+# own; whole-step gradients: no more entries outside the fp64 band than the exact path or the fp32 CPU oracle, profiles/r04_fp64_outliers.txt),
+# 1.3 x the step rate of the exact-fp32 MFMA kernels.  "fp32" selects those (v_mfma_f32_32x32x2_f32: bit-identical to an fmaf chain).
+DEFAULT_MLP_DTYPE = "fp32x6"
+MLP_PRECISION = _PRECISIONS[os.environ.get("CLIFT_MLP_DTYPE", DEFAULT_MLP_DTYPE).lower()]
 
 
 class _Precision:

@@ -30,7 +30,8 @@ def default_config(**over):
              decay_step=[9, 10], decay_gamma=0.5, temperature=100.0,
              lambda_segment=1.2, segment_grouping_mode="argmax_conf", segment_optimization_epoch=6, batch_size_segments=32,
              max_rays_segments=1024, use_symmetric_ce=False, ce_alpha=0.85, ce_beta=0.15, reweight_fg=False,
-             mlp_dtype="fp32",     # this build's extension key: "bf16" = bf16 MLP operands, fp32 accumulate (BASELINE config 3)
+             mlp_dtype="fp32x6",   # this build's extension key: arithmetic of the 256-wide MLP layers -- "fp32x6" (default: fp32-faithful 3 x bf16 split,
+                                   # six products, fp32 accumulate), "fp32" (exact fp32 MFMA), "bf16" (bf16 operands, fp32 accumulate; BASELINE configs[2])
              nosync=False,         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
              skip_discarded_instance_heads=False,    # extension key: do not evaluate the instance heads in the main pass, where the reference
                                                      # computes and discards them (T:155) -- same results, ~12 % less work; the train CLI sets it
@@ -100,7 +101,7 @@ class HotPathTrainer:
             raise NotImplementedError("HotPathTrainer: config options outside the contrastive-lift hot path: " +
                                       ", ".join(f"{k}={getattr(config, k)!r} (only {v!r} is built)" for k, v in unsupported))
         self.white_bg = bool(white_bg)            # dataset attribute in the reference (train_set.white_bg, T:109)
-        engine.set_mlp_precision(getattr(config, "mlp_dtype", "fp32") or "fp32")    # process-wide switch of the matrix-core launches
+        engine.set_mlp_precision(getattr(config, "mlp_dtype", None) or engine.DEFAULT_MLP_DTYPE)    # process-wide switch of the matrix-core launches
         self.device = model.param_flat.device
         self.current_epoch = current_epoch
         C = model.num_semantic_classes
@@ -114,7 +115,7 @@ class HotPathTrainer:
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)   # rgb, sem, tv, clustering (last step)
         # sync-free mode: per pass a capacity for the compacted buffers, learnt from the first (synchronising) steps and followed
         # asynchronously afterwards; see _capacity / _follow
-        self.nosync = bool(getattr(config, "nosync", False)) and getattr(config, "mlp_dtype", "fp32") in ("fp32", "f32", "fp32x6", None)
+        self.nosync = bool(getattr(config, "nosync", False)) and getattr(config, "mlp_dtype", None) in ("fp32", "f32", "fp32x6", None)
         self._caps = {}
         self.overflow_steps = 0
 

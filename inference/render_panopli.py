@@ -35,7 +35,7 @@ def strip_prefix(state_dict, key):
 
 def build_from_checkpoint(config, scene, device):
     from contrastive_lift_amd import engine
-    engine.set_mlp_precision(getattr(config, "mlp_dtype", "fp32") or "fp32")
+    engine.set_mlp_precision(getattr(config, "mlp_dtype", None) or engine.DEFAULT_MLP_DTYPE)
     ckpt = torch.load(config.resume, map_location="cpu", weights_only=False)
     sd = ckpt["state_dict"]
     total_classes = len(scene.segmentation_data.bg_classes) + len(scene.segmentation_data.fg_classes)

@@ -226,7 +226,8 @@ def _frame_worker(rank, world, port, q):
         model, renderer, rays = _frame_setup()
         whole = inf.render_rays(model, renderer, rays, FRAME_CHUNK)
         shard = inf.render_rays_sharded(model, renderer, rays, FRAME_CHUNK)
-        same = [bool(torch.equal(a, b)) for a, b in zip(whole, shard)]
+        # rays whose values differ between the two renders, per output (0 everywhere = bit-identical)
+        same = [int((a != b).reshape(a.shape[0], -1).any(1).sum()) for a, b in zip(whole, shard)]
         b = inf.tile_bounds(rays.shape[0], world)
         q.put((rank, same, [tuple(x.shape) for x in shard], b))
     finally:
@@ -265,35 +266,28 @@ def test_config4_full_frame_render_single_gpu():
 
 def test_config4_full_frame_render_sharded_two_ranks():
     """The same frame through render_rays_sharded with the REAL renderer: two ranks (gloo, sharing the one GPU of the test box) each
-    render a contiguous tile of 627,264 rays, one all-gather assembles the frame; every output is bit-identical to the unsharded
-    render on both ranks."""
-    import warnings
+    render a contiguous tile of 627,264 rays, one all-gather assembles the frame; every output is compared ray by ray with the unsharded
+    render on both ranks.  No retry: a wrong tile bound, offset or gather order differs in ~600 000 rays, deterministically.  What is
+    tolerated is the OPEN ISSUE of two PROCESSES on one device ("Two processes on one device"; not the production layout,
+    which is one process per GPU): with the device shared, one render in ~1000 returns ONE wrong ray in the exact-fp32 mode (round 4: 2 of
+    2 x 2000 renders of 131 072 rays, each differing in the rgb of a single ray; a process alone: 0 of 400; profiles/r04_two_process_*.txt),
+    cause unknown.  The test prints the count and fails above 4 rays per output."""
     import torch.multiprocessing as mp
     torch.cuda.empty_cache()                 # the two ranks share this process's GPU: hand its cached blocks back first
-
-    def attempt():
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, q)) for r in range(2)]
-        for p in procs:
-            p.start()
-        res = [q.get(timeout=600) for _ in range(2)]
-        for p in procs:
-            p.join(120)
-            assert p.exitcode == 0
-        return res
-
-    # Two PROCESSES on one device is a property of this test box, not of the path (one process per GPU): under that sharing a render now and
-    # then returns a few wrong values whatever the kernels (profiles/r03_x6_notes.txt: 2 wrong renders of 600 in the shipped exact mode's rgb,
-    # none in 400 renders of one process alone).  The test is about the row-tile logic, which fails deterministically if it is wrong: one
-    # retry, with a warning, keeps that rare event from being reported as a sharding bug.
-    res = attempt()
-    if not all(all(same) for _, same, _, _ in res):
-        warnings.warn(f"sharded vs unsharded frame differed on the first attempt ({[(r, s) for r, s, _, _ in res]}): retrying once")
-        res = attempt()
-    for rank, same, shapes, b in res:
-        assert all(same), (rank, same)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, ndiff, shapes, b in res:
+        if any(ndiff):
+            print(f"\n[two processes on one device] rank {rank}: rays differing between the sharded and the unsharded render, per output: {ndiff}")
+        assert all(n <= 4 for n in ndiff), (rank, ndiff)
         assert shapes[0] == (1254528, 3) and shapes[3] == (1254528,)
         assert b == [0, 627264, 1254528]
 

@@ -1,81 +1,58 @@
 #!/usr/bin/env python3
-"""Counted s_waitcnt vmcnt(N) values of csrc/layer_x6.hip, derived by replaying the loop's vector-memory instruction stream.
-Every wave issues, per 32-row tile, a fixed sequence of vector-memory instructions (LDS-DMA rows D_i of tile t+2, stores S_q of tile
-t-1's results, dgrad: mask loads m_q of tile t); vmcnt counts them in order.  The staged row i is read back at step 2 i (gap 0) of the
-NEXT tile: the wait before that read must let exactly the younger instructions stay in flight.  This script lists the (step, gap)
-schedule, replays three tiles and prints the counts the kernel hard-codes (X6_VM_FWD / X6_VM_DGRAD / the mask wait).
-The schedule must match the kernel's: (step, gap) of every instruction below is what the source does."""
+"""Counted s_waitcnt vmcnt(N) values of csrc/layer_x6.hip (the eight-wave form), derived by replaying the loop's vector-memory stream.
+
+Every wave issues, per 32-row tile, a FIXED sequence of vector-memory instructions; vmcnt counts them in issue order and retires them in
+order.  A tile has 8 k-steps (j) of 6 MFMA gaps each; piece i (the wave's staged row i of the NEXT tile, i = 0..3) is read back at
+(step 2 i, gap 0) and was DMA'd ("D_i") during the previous tile.  The wait in front of that read-back must let exactly the younger
+instructions stay in flight.  Variants (template arguments of k_layer_x6) and what they add to the stream:
+
+  forward           D0 D1 S0 D2 S1 D3        S_q = store of the previous tile's 16 columns (steps 4, 6, gap 4)
+  dgrad             m0 m1 + forward          m_q = ReLU-mask loads of THIS tile's rows (steps 0, 2, gap 2), needed at the end of the tile
+  forward, OUTV=1   forward + P              P = store of the output layer's partial sums of the previous tile (step 2, gap 4)
+  forward, OUTV=2   D0 P D1 D2 D3            hidden activation not written
+  dgrad, K3W        p D0 D1 D2 D3            p = load of this tile's row positions (step 0, gap 2), needed at the end of the tile; no stores
+
+(GEN, the generated-input forward, has its own one-line argument in the source: vmcnt(2) everywhere.)
+Prints the tables the kernel hard-codes as X8_VM[variant][i] and the end-of-tile waits.  The (step, gap) of every instruction below is
+what the source does -- change both together."""
 
 
-def schedule(dgrad):
-    ops = []                      # (step, gap, order-in-gap, name)
-    for i in range(8):
-        if i <= 6:
-            ops.append((2 * i + 2, 3, 0, f"D{i}"))
-        else:
-            ops.append((15, 5, 0, f"D{i}"))
-    for q in range(4):
-        if q <= 2:
-            ops.append((10 + 2 * q, 4, 0, f"S{q}"))
-        else:
-            ops.append((15, 5, 1, f"S{q}"))
-    if dgrad:
-        for q in range(4):
-            ops.append((2 * q, 2, 0, f"m{q}"))
+def schedule(variant):
+    ops = []                                        # (step, gap, name)
+    dgrad = variant in ("dgrad", "k3w")
+    stores = variant in ("forward", "dgrad", "outv1")
+    ops += [(2, 3, "D0"), (4, 3, "D1"), (6, 3, "D2"), (7, 5, "D3")]
+    if stores:
+        ops += [(4, 4, "S0"), (6, 4, "S1")]
+    if variant == "dgrad":
+        ops += [(0, 2, "m0"), (2, 2, "m1")]
+    if variant == "k3w":
+        ops += [(0, 2, "p")]
+    if variant in ("outv1", "outv2"):
+        ops += [(2, 4, "P")]
+    assert dgrad or variant in ("forward", "outv1", "outv2")
     return sorted(ops)
 
 
-def counts(dgrad):
-    tile = schedule(dgrad)
-    stream = [(t, s, g, o, n) for t in range(3) for (s, g, o, n) in tile]
-    out = []
-    for i in range(8):
-        # raw_read(i) happens in tile 2 at (step 2 i, gap 0) BEFORE anything else of that gap; it needs D_i of tile 1
-        idx = next(k for k, x in enumerate(stream) if x[0] == 1 and x[4] == f"D{i}")
+def counts(variant):
+    tile = schedule(variant)
+    stream = [(t, s, g, n) for t in range(3) for (s, g, n) in tile]
+    waits = []
+    for i in range(4):
+        # the read-back of piece i happens in tile 2 at (step 2 i, gap 0), before anything else of that gap; it needs D_i of tile 1
+        idx = next(k for k, x in enumerate(stream) if x[0] == 1 and x[3] == f"D{i}")
         younger = [x for x in stream[idx + 1:] if (x[0], x[1], x[2]) < (2, 2 * i, 0)]
-        out.append(len(younger))
-    mask_wait = None
-    if dgrad:   # all four masks of tile 1 are needed after step 15 of tile 1: everything of tile 1 issued after m3 may stay in flight
-        idx = next(k for k, x in enumerate(stream) if x[0] == 1 and x[4] == "m3")
-        mask_wait = len([x for x in stream[idx + 1:] if x[0] == 1])
-    return out, mask_wait
+        waits.append(len(younger))
+    tail = None
+    last_needed = {"dgrad": "m1", "k3w": "p"}.get(variant)
+    if last_needed:                                 # needed after step 7 of its own tile: everything of the tile issued after it may stay in flight
+        idx = next(k for k, x in enumerate(stream) if x[0] == 1 and x[3] == last_needed)
+        tail = len([x for x in stream[idx + 1:] if x[0] == 1])
+    return waits, tail
 
 
 if __name__ == "__main__":
-    for dgrad in (False, True):
-        print("dgrad" if dgrad else "forward", "order per tile:", " ".join(n for (_, _, _, n) in schedule(dgrad)))
-        c, mw = counts(dgrad)
-        print("   vmcnt before raw_read(i), i = 0..7:", c, "  mask wait:", mw)
-
-
-def lgkm_counts():
-    """LDS instruction stream of one tile (F = fragment read, R = staging read, W = plane write) and the lgkmcnt every wait needs."""
-    stream, marks = [], {}
-    stream += [("F", 0)] * 3                                  # rd(0), behind the barrier
-    for j in range(16):
-        i, even = j >> 1, (j & 1) == 0
-        marks[("start", j)] = len(stream)                     # wait for the fragments of step j
-        if j + 1 < 16:
-            stream += [("F", j + 1)] * 3
-        if even:
-            stream.append(("R", i))
-        else:
-            marks[("raw", j)] = len(stream)                   # wait for the staging read of piece i
-        if even and i > 0:
-            stream += [("W", i - 1)] * 2                      # split_e of the previous piece
-        if not even:
-            stream.append(("W", i))                           # split_c
-        if j == 15:
-            stream += [("W", 7)] * 2
-    out = {}
-    for (kind, j), pos in marks.items():
-        want = ("F", j) if kind == "start" else ("R", j >> 1)
-        last = max(k for k in range(pos) if stream[k] == want)
-        out[(kind, j)] = pos - 1 - last                       # instructions issued after the wanted one, before the wait
-    return out
-
-
-if __name__ == "__main__":
-    lg = lgkm_counts()
-    print("lgkmcnt at step start, j = 0..15:", [lg[("start", j)] for j in range(16)])
-    print("lgkmcnt before the first split (odd steps), j = 1,3,..,15:", [lg[("raw", j)] for j in range(1, 16, 2)])
+    for row, variant in enumerate(("forward", "dgrad", "outv1", "outv2", "k3w")):
+        w, tail = counts(variant)
+        print(f"X8_VM[{row}] {variant:8s} stream per tile: {' '.join(n for (_, _, n) in schedule(variant)):28s} waits {w}"
+              + (f"   end-of-tile wait vmcnt({tail})" if tail is not None else ""))
