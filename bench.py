@@ -203,10 +203,6 @@ def main():
             tr.opt_inst.load_state_dict(snap[2])
             tr.load_rng_state(snap[3])          # the per-ray jitter: same samples, same launch sizes
         restore()
-        if os.environ.get("CLIFT_BENCH_PRESTEP"):
-            tr.training_step(batches[0], lean=a.lean)
-            sync_all()
-            restore()
         out = []
 
         def bracket(kind, M, N, K, extra_flops, nbytes, fn):
@@ -345,6 +341,9 @@ def main():
             extra.update(bf16_probe(a, dev, batches, S))
             extra.update(other_fp32_probe(a, dev, batches, S, "fp32" if a.dtype == "fp32x6" else "fp32x6"))
             extra.update(small_batch_probe(a, dev, pool, S, tr.model.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")))
+        if "bf16_ms_per_step" in extra:
+            extra["bf16"] = {"mlp_arithmetic": MLP_ARITHMETIC["bf16"], "ms_per_step": extra["bf16_ms_per_step"], "ray_samples_per_s": extra["bf16_ray_samples_per_s"],
+                             "roofline": {k: v for k, v in (extra.get("bf16_roofline") or {}).items() if k != "families"}}
         if roof is not None:
             # (the driver's record keeps `roofline`, `config` and `cpu_baseline` whole and only the NAMES of other keys: what a reader of that
             # record should see of the extras rides inside `roofline`)

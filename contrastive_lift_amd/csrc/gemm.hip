@@ -244,10 +244,9 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         ((!h->b_trans && !h->mask) ||
          (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0)))
         return clift_layer_x6_launch(p, h->b_trans, st);
-    // fp32x6 weight gradient of the 256 x 256 layers (layer_x6w.hip; CLIFT_X6_WGRAD=0 keeps the exact quadrant kernel)
+    // fp32x6 weight gradient of the 256 x 256 layers (layer_x6w.hip)
     if (h->precision == 2 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
-        h->act == 0 && h->lda % 4 == 0 && h->ldb % 4 == 0 && (((uintptr_t)h->A) & 15) == 0 && (((uintptr_t)h->B) & 15) == 0 &&
-        !(getenv("CLIFT_X6_WGRAD") && getenv("CLIFT_X6_WGRAD")[0] == '0'))
+        h->act == 0 && h->lda % 4 == 0 && h->ldb % 4 == 0 && (((uintptr_t)h->A) & 15) == 0 && (((uintptr_t)h->B) & 15) == 0)
         return clift_wgrad_x6_launch(p, st);
     // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); any other shape takes the tiled split kernel
     if (h->precision == 2 && !h->a_trans && !h->accumulate && splits == 1 && !h->c_trans && (long)h->N * h->K <= (1L << 22)) {
@@ -275,13 +274,10 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
         return clift_dgrad_narrow_stream_launch(p, 0, st);          // unmasked narrow-K dgrad (appearance basis 27 -> 144): a stream over the result
     // (up to ~150 k rows: beyond that the split-K tiled launch, whose k-loop is long by then, is as fast or faster: 304 vs 332 us at 249 k)
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
-        h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr) {
-        // persistent 2-D weight gradient.  Default: 64 row ranges x four 128 x 128 quadrants, 64-row tiles (layer_n128.hip) -- 92 / 318 us at
-        // 62 k / 249 k rows; the older 256 x 64 slices with 32-row tiles (layer_f32.hip): 95 / 340; the split-K tiled launch: 127 / 349.
-        const char* mode = getenv("CLIFT_WGRAD256");                // A/B switch: "quads" | "slices" | "tiled"
-        if (!mode || !strcmp(mode, "quads")) return clift_wgrad_f32_quads_launch(p, st);
-        if (!strcmp(mode, "slices")) return clift_wgrad_f32_stream_launch(p, st);
-    }
+        h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        // persistent 2-D weight gradient: 64 row ranges x four 128 x 128 quadrants, 64-row tiles (layer_n128.hip) -- 92 / 318 us at 62 k / 249 k rows
+        // (measured against 256 x 64 slices with 32-row tiles: 95 / 340, and the split-K tiled launch: 127 / 349; profiles/r02_*)
+        return clift_wgrad_f32_quads_launch(p, st);
     // weight gradients of the 128-wide appearance layers (128 x 128 and 128 x 160 results): persistent row-range stream
     if (h->precision == 0 && h->a_trans && h->b_trans && h->M == 128 && (h->N == 128 || h->N == 160) && h->ldb >= h->N && h->lda >= 128 && h->K >= 4096 &&
         h->accumulate && !h->c_trans && !h->bias && !h->mask && h->act == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
@@ -385,7 +381,7 @@ extern "C" int clift_linear_k3_fwd(const float* x4, const float* W, int ldw, con
                                    float* out, int ldo, int out_bf16, clift_stream_t s) {
     CLIFT_REQUIRE(Nout % 4 == 0 && ldo % 4 == 0, "clift_linear_k3_fwd: Nout and ldo must be multiples of 4");
     if (M <= 0) return 0;
-    if (Nout > 1024 || 256 % (Nout / 4) != 0 || getenv("CLIFT_K3_ANY") != nullptr) {     // (CLIFT_K3_ANY: diagnostic switch, profiles/r03_x6_notes.txt)
+    if (Nout > 1024 || 256 % (Nout / 4) != 0) {
         k_linear_k3_fwd_any<<<cdiv((long)M * (Nout / 4), 256), 256, 0, as_stream(s)>>>(x4, W, ldw, b, M, Nout, relu, out, ldo, out_bf16);
         return clift_check_launch("clift_linear_k3_fwd");
     }
@@ -511,8 +507,7 @@ extern "C" int clift_wgrad_narrow(const float* dY, int ldd, int no, const float*
     CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_wgrad_narrow: out_features must be in [1,32] (got %d)", no);
     if (M <= 0 || ni <= 0) return 0;
     if ((ni == 256 || (!x_bf16 && ni >= 32 && ni < 256 && ni % 4 == 0)) && M >= 4096 && ldd % 4 == 0 && ldd >= no && ldd <= 32 &&
-        (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)X) & 15) == 0 && ldx % (x_bf16 ? 8 : 4) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr &&
-        getenv("CLIFT_NARROW_WGRAD_VALU") == nullptr)
+        (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)X) & 15) == 0 && ldx % (x_bf16 ? 8 : 4) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_wgrad_narrow_stream_launch(dY, ldd, no, X, ldx, ni, M, gW, ldw, gb, x_bf16, as_stream(s));   // matrix-core stream over X
     const int rpb = 128;        // (insensitive between 64 and 520 rows per block: the kernel is FMA-bound, not launch-shape-bound)
     const dim3 grid(cdiv(M, rpb), cdiv(ni, 256));

@@ -39,7 +39,6 @@ int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits,
 int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_bf16.hip
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st);
 int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st);                             // layer_f32.hip
-int clift_wgrad_f32_stream_launch(const GemmP& p, hipStream_t st);
 int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_n128.hip
 int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st);
 int clift_wgrad_f32_quads_launch(const GemmP& p, hipStream_t st);

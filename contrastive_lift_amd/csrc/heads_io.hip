@@ -406,8 +406,7 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
     int threads, per_cu;
     const bool use_lds = scatter_geometry(lds_bytes, &threads, &per_cu);
-    const char* mode = getenv("CLIFT_APP_SCATTER");                   // "walk" = lane-per-(plane, channel) walk (the only form without xa)
-    if (xa != nullptr && h_app->comps <= 64 && !(mode && strcmp(mode, "walk") == 0)) {
+    if (xa != nullptr && h_app->comps <= 64) {          // (otherwise: the lane-per-(plane, channel) walk, the only form without xa / for comps > 64)
         // one wave per (segment, plane): the line slab + a 2 KB record slot per wave; as many waves per CU as that allows
         const int rec_bytes = AU_SEG * (int)sizeof(WalkRec);
         const int slab = (lds_bytes + 15) / 16 * 16;

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_bf16_stream(GemmP g, int rows_
 // Eligibility decided by the caller: M = N = 256 (gW is 256 x 256), both streamed operands bf16-stored with 16-byte-aligned rows.
 int clift_wgrad_bf16_stream2d_launch(const GemmP& p, hipStream_t st);
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st) {
-    if (p.K >= 4096 && getenv("CLIFT_WGRAD_1D") == nullptr) return clift_wgrad_bf16_stream2d_launch(p, st);      // 64 row ranges x 4 column slices
+    if (p.K >= 4096) return clift_wgrad_bf16_stream2d_launch(p, st);      // 64 row ranges x 4 column slices
     const int tiles = cdiv(p.K, LY_ROWS);
     const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(p.K, blocks), LY_ROWS) * LY_ROWS;

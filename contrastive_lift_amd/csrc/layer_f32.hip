@@ -479,115 +479,3 @@ extern "C" int clift_xyz_head_first2_bwd(const float* dH2, int ldd, const float*
     k_layer_f32<true, false, false, true><<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(p, rpb, none, no_out, K3P{x4, W0, ldw0, b0, gW0, ldgw0, gb0});
     return clift_check_launch("clift_xyz_head_first2_bwd");
 }
-
-// ============================================================================ weight gradient of the same layers, persistent
-// gW[n][k] += sum_m dY[m][n] X[m][k]  (+ gb[n] += sum_m dY[m][n]),  fp32, M rows.  The split-K tiled launch (gemm.hip) ends with every CU
-// adding a full 256 x 256 partial to gW: 1024 atomic wave-instructions per CU, ~45 us per launch whatever their scope -- per-CU atomic
-// issue, not contention.  Here the launch is cut in TWO dimensions instead: 64 row ranges x 4 column slices of 64 (= 256 persistent
-// blocks, one per CU); a block streams its rows of dY (all 256 columns) and of its X slice through a three-stage LDS ring by LDS-DMA
-// and ends with a 256 x 64 partial (a quarter of the atomics).  The four slice-blocks of a row range get block ids 8 apart, i.e. the
-// same XCD, so dY is fetched from HBM once and re-read from that L2.  Wave w owns dY columns 32 w .. +31 (rows of gW) for both
-// 32-column halves of the slice: per MFMA step a lane reads one dY and two X elements (row-contiguous ds_read_b32, conflict-free
-// without swizzle); fragment reads run one 4-step group ahead of the MFMAs.
-constexpr int WG_ROWS = 32, WG_DEPTH = 2, WG_STAGES = WG_DEPTH + 1;
-constexpr int WG_YB = WG_ROWS * 1024, WG_XB = WG_ROWS * 256, WG_STAGE = WG_YB + WG_XB;       // bytes
-
-__global__ __launch_bounds__(512, 2) void k_wgrad_f32_stream(GemmP g, int rows_per_range) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WG_STAGES * WG_STAGE];         // 120 KB, the only LDS object
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.x, slice = (b >> 3) & 3, range = (b & 7) + 8 * (b >> 5);
-    if (rows_limited()) {
-        g.K = limit_rows(g.K);
-        rows_per_range = ((g.K + 63) / 64 + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
-    }
-    const int rbeg = range * rows_per_range, rend = min(g.K, rbeg + rows_per_range);
-    if (rbeg >= rend) return;
-    const int ntiles = (rend - rbeg + WG_ROWS - 1) / WG_ROWS;
-    const float* __restrict__ Y = g.A;            // dY (rows, 256), pitch lda
-    const float* __restrict__ X = g.B + 64 * slice;
-    auto dma = [&](int t) {
-        const int r0 = rbeg + t * WG_ROWS;
-        unsigned char* st = lds + (t % WG_STAGES) * WG_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 4 + i, gr = min(r0 + row, rend - 1);
-            __builtin_amdgcn_global_load_lds(Y + (size_t)gr * g.lda + lane * 4, (lds_ptr_t)(st + row * 1024), 16, 0, 0);
-        }
-        const int row = wave * 4 + (lane >> 4), gr = min(r0 + row, rend - 1);
-        __builtin_amdgcn_global_load_lds(X + (size_t)gr * g.ldb + (lane & 15) * 4, (lds_ptr_t)(st + WG_YB + wave * 1024), 16, 0, 0);
-    };
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    float bsum = 0.f;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    const unsigned yoff = (unsigned)(lh * 1024 + (32 * wave + li) * 4);                       // dY element (row lh, column 32 wave + li)
-    const unsigned xoff = (unsigned)(WG_YB + lh * 256 + li * 4);                              // X element (row lh, slice column li)
-
-    for (int t = 0; t < WG_DEPTH && t < ntiles; ++t) dma(t);
-    for (int t = 0; t < ntiles; ++t) {
-        if (min(t + WG_DEPTH - 1, ntiles - 1) > t) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // one younger tile (5 DMAs) stays in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + WG_DEPTH < ntiles) dma(t + WG_DEPTH);
-        const int valid = rend - (rbeg + t * WG_ROWS);
-        if (valid < WG_ROWS) {                                               // last tile of the range: rows past its end contribute nothing
-            float* yt = reinterpret_cast<float*>(lds + (t % WG_STAGES) * WG_STAGE);
-            for (int e = valid * 256 + tid; e < WG_ROWS * 256; e += 512) yt[e] = 0.f;
-            __syncthreads();
-        }
-        const unsigned sb = lds0 + (unsigned)((t % WG_STAGES) * WG_STAGE);
-        float fa[2][4], fb[2][4], fc[2][4];       // ping-pong groups of 4 steps: dY element, X element of either 32-column half
-        auto rd = [&](int grp, int set) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = 4 * grp + u;
-                asm volatile("ds_read_b32 %0, %1" : "=v"(fa[set][u]) : "v"(sb + yoff + (unsigned)(2 * s * 1024)) : "memory");
-                asm volatile("ds_read_b32 %0, %1" : "=v"(fb[set][u]) : "v"(sb + xoff + (unsigned)(2 * s * 256)) : "memory");
-                asm volatile("ds_read_b32 %0, %1" : "=v"(fc[set][u]) : "v"(sb + xoff + (unsigned)(2 * s * 256 + 128)) : "memory");
-            }
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            const int set = grp & 1;
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fb[set][0]), "+v"(fb[set][1]), "+v"(fb[set][2]),
-                           "+v"(fb[set][3]), "+v"(fc[set][0]), "+v"(fc[set][1]), "+v"(fc[set][2]), "+v"(fc[set][3])
-                         :
-                         : "memory");
-            if (grp + 1 < 4) rd(grp + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u], fb[set][u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][u], fc[set][u], acc1, 0, 0, 0);
-                bsum += fa[set][u];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // lane (li, lh) holds gW rows n = 32 wave + 8 q + 4 lh + e, columns 64 slice + li (acc0) and + 32 + li (acc1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = 32 * wave + 8 * (r >> 2) + 4 * lh + (r & 3);
-        float* dst = grad_target(g.C) + (size_t)n * g.ldc + 64 * slice + li;
-        unsafeAtomicAdd(dst, acc0[r]);
-        unsafeAtomicAdd(dst + 32, acc1[r]);
-    }
-    if (g.colsum && slice == 0) {      // the four slice-blocks of a range all saw the same dY: one of them adds the bias gradient
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const unsigned u = __float_as_uint(bsum);
-        const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (lh == 0) unsafeAtomicAdd(grad_target(g.colsum) + 32 * wave + li, tot);
-    }
-}
-
-// Eligibility decided by the caller (gemm.hip): wgrad form with a 256 x 256 result, K (rows) >= 4096, plain 16-byte-aligned rows.
-int clift_wgrad_f32_stream_launch(const GemmP& p, hipStream_t st) {
-    const int rpr = cdiv(cdiv(p.K, 64), WG_ROWS) * WG_ROWS;
-    k_wgrad_f32_stream<<<256, 512, 0, st>>>(p, rpr);
-    return clift_check_launch("clift_gemm(fp32 wgrad stream)");
-}

@@ -395,14 +395,6 @@ extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const flo
     const dim3 grid(cdiv(M, rpb));
     hipStream_t st = as_stream(s);
     const int kj = cdiv(no, 8);
-    const char* pf = getenv("CLIFT_NARROW_PREFETCH");          // A/B switch: "0" = fetch a tile's mask inside the tile (the round-2 form)
-    if (pf && pf[0] == '0') {
-        if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
-        else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
-        else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
-        else k_dgrad_narrow_stream<4, false, true, true, false><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
-        return clift_check_launch("clift_out_layer_bwd");
-    }
     if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);

@@ -45,21 +45,13 @@ def vm_struct(views, prefix, res):
     return v
 
 
-XCD_PRIVATE = os.environ.get("CLIFT_XCD_PRIVATE", "1") != "0"
 _GROUP_OF = {"density": "grid_density", "appearance": "grid_app"}
 
 
 def vm_grad_struct(model, gviews, prefix):
-    """Gradient target of a scatter kernel.  Default: eight per-XCD accumulation copies (model-owned, persistent,
-    zero between uses) that ``vm_grad_finish`` folds into ``gviews``; CLIFT_XCD_PRIVATE=0: the final tables directly
-    with device-scope atomics."""
+    """Gradient target of a scatter kernel: eight per-XCD accumulation copies (model-owned, persistent, zero between uses: XCD-local L2
+    atomics) that ``vm_grad_finish`` folds into ``gviews``.  (xcd_stride = 0 in the C struct means "the final tables directly".)"""
     g = VMGrad()
-    if not XCD_PRIVATE:
-        for i in range(3):
-            g.plane[i] = gviews[f"{prefix}_plane.{i}"].data_ptr()
-            g.line[i] = gviews[f"{prefix}_line.{i}"].data_ptr()
-        g.xcd_stride = 0
-        return g
     a, b = model.arena.range_of(_GROUP_OF[prefix])
     n = b - a
     work = model.xcd_workspace(prefix, 8 * n)
@@ -125,25 +117,17 @@ def exact_fp32():
 # bf16 mode: the 128-wide appearance MLP stays on the exact-fp32 persistent kernels (layer_n128.hip) -- they are FASTER than the tiled
 # bf16 kernels on these short-K layers (fp32 persistent ~0.76 ms vs bf16 tiled ~1.0 ms per step, profiles/r02_bf16_*), and it is the
 # more accurate choice.  The 256-wide xyz heads, where the bf16 streaming / fused kernels pay, run in bf16.
-APP_FP32_IN_BF16 = os.environ.get("CLIFT_APP_FP32_IN_BF16", "1") != "0"
 
 
-X6_WGRAD = os.environ.get("CLIFT_X6_WGRAD", "1") != "0"       # fp32x6 mode: the 256 x 256 weight gradients on the split kernel as well
-# fp32x6 mode: the fused ends of the xyz heads (output layer in the last hidden layer's kernel, first-two-layers backward, generated-input weight
-# gradient) on the split kernels too (ABI 14); "0" = the round-3 mix (exact fused backward ends, output layer as its own GEMM)
-X6_FUSED_ENDS = os.environ.get("CLIFT_X6_FUSED_ENDS", "1") != "0"
 
 
-# Experiment switch (CLIFT_HYBRID_X6=1): the exact mode's fused kernels (K = 3 layer / output layer in-kernel, fused first-two-layers backward)
-# with the REMAINING plain 256 x 256 forward and masked-dgrad launches on the fp32x6 kernels -- what a default built from both would cost.
-HYBRID_X6 = os.environ.get("CLIFT_HYBRID_X6") is not None
 
 
 def _app_precision():
     # fp32x6 (2): only the 256 x 256 layers have persistent split kernels; the 128-wide appearance layers would fall to the TILED split kernel
     # (gemm_split.hip), which is slower than the exact persistent kernels and -- seen with two processes sharing the GPU -- the one kernel of that
     # mode whose results were disturbed by the other process's fp32x6 launches (profiles/r03_x6_notes.txt).  Exact fp32 there.
-    if MLP_PRECISION == 2 or (MLP_PRECISION == 1 and APP_FP32_IN_BF16):
+    if MLP_PRECISION in (1, 2):
         return _Precision(0)
     return _Precision(MLP_PRECISION)
 
@@ -151,27 +135,14 @@ def _app_precision():
 def act_dtype():
     """Storage type of the hidden activations / hidden gradients of the xyz-MLP heads: bf16 in bf16 mode (they are only ever
     consumed as bf16 matrix-core operands or as ReLU masks there), fp32 otherwise."""
-    return torch.bfloat16 if (MLP_PRECISION == 1 and BF16_STORAGE) else torch.float32
-
-
-BF16_STORAGE = os.environ.get("CLIFT_BF16_STORAGE", "1") == "1"
-
-
-# CLIFT_FORCE_MLP_DTYPE=fp32x6 (test switch): every request for the default "fp32" precision is served in that mode instead, so the whole
-# GPU suite can be run with the mode forced on at unchanged tolerances
-_FORCED = os.environ.get("CLIFT_FORCE_MLP_DTYPE", "").lower()
-if _FORCED:
-    MLP_PRECISION = _PRECISIONS[_FORCED]
+    return torch.bfloat16 if MLP_PRECISION == 1 else torch.float32
 
 
 def set_mlp_precision(name):
     """'fp32', 'bf16' or 'fp32x6'; returns the previous setting's name."""
     global MLP_PRECISION
     prev = {0: "fp32", 1: "bf16", 2: "fp32x6"}[MLP_PRECISION]
-    want = _PRECISIONS[str(name).lower()]
-    if want == 0 and _FORCED:
-        want = _PRECISIONS[_FORCED]
-    MLP_PRECISION = want
+    MLP_PRECISION = _PRECISIONS[str(name).lower()]
     return prev
 
 
@@ -195,12 +166,10 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, the other weight gradients -- stays on its exact-fp32 persistent kernel,
     # which is faster than the tiled split kernel the library would pick for it
     x6 = N == 256 and K == 256 and not a_trans and not accumulate and not c_trans
-    # ... and their weight gradients (csrc/layer_x6w.hip; CLIFT_X6_WGRAD=0 keeps the exact quadrant kernel)
-    x6w = (X6_WGRAD and a_trans and b_trans and M == 256 and N == 256 and K >= 4096 and accumulate and not c_trans and bias is None and mask is None
+    # ... and their weight gradients (csrc/layer_x6w.hip)
+    x6w = (a_trans and b_trans and M == 256 and N == 256 and K >= 4096 and accumulate and not c_trans and bias is None and mask is None
            and not act and int(lda) % 4 == 0 and int(ldb) % 4 == 0 and A.dtype == torch.float32 and B.dtype == torch.float32)
     g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6 or x6w) else 0
-    if HYBRID_X6 and MLP_PRECISION == 0 and x6 and A.dtype == torch.float32:
-        g.precision = 2          # experiment switch: exact mode with the un-fused 256 x 256 forward / dgrad launches on the split kernels
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
     if g.precision == 2 and not x6w:
@@ -296,12 +265,6 @@ class Branches:
 
 
 # ----------------------------------------------------------------------------- xyz MLP heads (semantic / instance)
-FUSE_FIRST2 = os.environ.get("CLIFT_FUSE_FIRST2", "1") != "0"     # K = 3 layer generated inside the second layer's kernel (fp32 path)
-
-
-FUSE_LAST2 = os.environ.get("CLIFT_FUSE_LAST2", "1") != "0"       # narrow (E <= 4) output layer applied inside the last hidden layer's kernel
-
-
 def last2(M, h, W, b, Wo, bo, hidden, out, ldo, col_off):
     """One clift_xyz_head_last2_fwd launch: hidden = relu(h W^T + b) (written if not None), out[:, col_off:col_off+E] = hidden Wo^T + bo."""
     call("clift_xyz_head_last2_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), ptr(Wo), _pitch(Wo), ptr(bo), Wo.shape[0], M, ptr(hidden), 256,
@@ -314,15 +277,6 @@ def app_last2(M, H1, W2, b2, W3, b3, H2, rgb):
          ptr(H2), 128, None, 0, ptr(rgb), rgb.shape[1], 1, stream())
 
 
-# xyz heads: the output layer's weight gradient and input gradient in one launch (clift_out_layer_bwd)
-FUSE_OUT_BWD = os.environ.get("CLIFT_FUSE_OUT_BWD", "1") != "0"
-# density table gradients: hand the forward's sigma to the scatter (softplus derivative = 1 - exp(-sigma), once per sample) instead of
-# letting it re-sum the sample's feature over planes and channels
-DENS_BWD_SIGMA = os.environ.get("CLIFT_DENS_BWD_SIGMA", "1") != "0"
-# appearance table gradients: hand the forward's sample positions to the scatter (its wave-per-(segment, plane) walk); "walk" = the
-# lane-per-(plane, channel) walk that re-derives them from the rays
-APP_SCATTER_XA = os.environ.get("CLIFT_APP_SCATTER", "walk4") != "walk"
-FUSE_HEAD_BF16 = os.environ.get("CLIFT_FUSE_HEAD_BF16", "1") != "0"   # bf16 mode: first three layers (+ narrow output layer) of an xyz head in one launch
 
 
 def head_bf16(M, xa, l0, l1, l2, lout, h1, h2, h3, out, ldo, col_off):
@@ -340,11 +294,13 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
     call("clift_xyz_head_first2_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h1), 256, ptr(h2), 256, stream())
 
 
-# backward: the second layer's input gradient is consumed inside its kernel by the K = 3 first layer's weight / bias gradient (never written)
-FUSE_FIRST2_BWD = os.environ.get("CLIFT_FUSE_FIRST2_BWD", "1") != "0"
-# ... and the forward then does not write the first layer's activation at all: the second layer's weight gradient regenerates it as well
-# ("0": the forward keeps it and that weight gradient streams it -- 14 us faster per 249 k-row launch, 255 MB more per head)
-DROP_FIRST_ACT = os.environ.get("CLIFT_DROP_FIRST_ACT", "1") != "0"
+# The fusions of the xyz heads are not switchable (their A/Bs are settled: profiles/r02_*, r03_ab_first2_bwd.txt, r04_ab_x6_fused_ends.txt): the K = 3
+# layer is generated inside the second layer's kernel; the first activation is never written -- the backward consumes the second layer's input
+# gradient inside its kernel (first2_bwd) and regenerates the activation for the weight gradient (first2_wgrad); an E <= 4 output layer is
+# applied inside the last hidden layer's kernel; the output layer's weight and input gradient are one launch.  CLIFT_NO_PERSISTENT=1 selects
+# the independent tiled kernels for every layer instead (the cross-check the tests use).
+KEEP_FIRST_ACT = False      # tests set this to compare against the stored-activation backward (masked dgrad + K = 3 weight gradient)
+FUSE_HEAD_BF16 = True       # bf16 mode: first three layers (+ E <= 4 output layer) of an xyz head in one launch; tests clear it to compare with the per-layer launches
 
 
 def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
@@ -411,18 +367,18 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
             return acts if keep_first else [None]
         h = h3
         rest = layers[3:-1]
-    elif (FUSE_FIRST2 and MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
+    elif (MLP_PRECISION == 0 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
             and os.environ.get("CLIFT_NO_PERSISTENT") is None):
         W1, b1 = layers[1]
         # (with the fused backward the first layer's activation has no reader: both of its uses -- the ReLU mask of the second layer's input
         # gradient and the second layer's weight gradient -- re-derive it from the positions, so it is never written)
-        h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if (keep_first and not (FUSE_FIRST2_BWD and DROP_FIRST_ACT)) else None
+        h1 = torch.empty((M, 256), dtype=torch.float32, device=dev) if (keep_first and KEEP_FIRST_ACT) else None
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
         first2(M, xa, W0, b0, W1, b1, h1, h)
         acts += [h1, h]
         rest = layers[2:-1]
-    elif (FUSE_FIRST2 and MLP_PRECISION == 2 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
-            and (not keep_first or (FUSE_FIRST2_BWD and DROP_FIRST_ACT)) and os.environ.get("CLIFT_NO_PERSISTENT") is None
+    elif (MLP_PRECISION == 2 and len(layers) >= 3 and W0.shape[0] == 256 and tuple(layers[1][0].shape) == (256, 256)
+            and (not keep_first or not KEEP_FIRST_ACT) and os.environ.get("CLIFT_NO_PERSISTENT") is None
             and os.environ.get("CLIFT_X6_TILED") is None):
         # fp32x6: the same fusion with the 256 x 256 layer on the split kernels; the first activation is never written (the backward, if any,
         # re-derives it: first2_bwd / first2_wgrad)
@@ -436,9 +392,9 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         call("clift_linear_k3_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), M, W0.shape[0], 1, ptr(h), h.shape[1], int(hdt == torch.bfloat16), stream())
         acts.append(h)
     Wo, bo = layers[-1]
-    fuse_out = (FUSE_LAST2 and MLP_PRECISION in (0, 2) and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
+    fuse_out = (MLP_PRECISION in (0, 2) and len(rest) >= 1 and Wo.shape[0] <= 4 and tuple(rest[-1][0].shape) == (256, 256)
                 and h.dtype == torch.float32 and out.dtype == torch.float32 and os.environ.get("CLIFT_NO_PERSISTENT") is None
-                and (MLP_PRECISION == 0 or (X6_FUSED_ENDS and os.environ.get("CLIFT_X6_TILED") is None)))
+                and (MLP_PRECISION == 0 or os.environ.get("CLIFT_X6_TILED") is None))
     for li_, (W, b) in enumerate(rest):
         if fuse_out and li_ == len(rest) - 1:
             # last hidden layer + the narrow output layer in one launch; the hidden activation is written only for a backward
@@ -472,22 +428,22 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
         gW, gb = glayers[li]
         h = acts[li - 1]
         no, ni = W.shape
-        if li == 1 and (h is None or (FUSE_FIRST2_BWD and MLP_PRECISION in (0, 2) and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and
+        if li == 1 and (h is None or (not KEEP_FIRST_ACT and MLP_PRECISION in (0, 2) and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and
                                       d.dtype == torch.float32 and h.dtype == torch.float32 and d.shape[1] % 4 == 0 and
                                       os.environ.get("CLIFT_NO_PERSISTENT") is None)):
             # second layer: its weight gradient (over the first layer's activation -- regenerated from the positions when the forward did not keep
             # it), then its input gradient formed and consumed by the first layer's weight gradient in one launch
             if no != 256 or ni != 256 or tuple(layers[0][0].shape) != (256, 3) or d.shape[1] != 256 or d.dtype != torch.float32:
                 raise _lib.CliftError("backward through an xyz head whose forward ran with keep_first=False (head not named in grad_heads)")
-            x6_ends = MLP_PRECISION == 2 and X6_FUSED_ENDS and os.environ.get("CLIFT_X6_TILED") is None
+            x6_ends = MLP_PRECISION == 2 and os.environ.get("CLIFT_X6_TILED") is None
             if h is None:
-                (first2_x6_wgrad if (x6_ends and X6_WGRAD) else first2_wgrad)(M, d, layers[0][0], layers[0][1], xa, gW, gb)
+                (first2_x6_wgrad if x6_ends else first2_wgrad)(M, d, layers[0][0], layers[0][1], xa, gW, gb)
             else:
                 wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
             (first2_x6_bwd if x6_ends else first2_bwd)(M, d, W, layers[0][0], layers[0][1], xa, *glayers[0])
             return
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
-        if (FUSE_OUT_BWD and li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and
+        if (li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and
                 MLP_PRECISION in (0, 2) and h.dtype == torch.float32 and d.dtype == torch.float32 and dn.dtype == torch.float32):
             # output layer: weight gradient and masked input gradient in one pass over the hidden activation
             call("clift_out_layer_bwd", ptr(d), d.shape[1], no, ptr(W), _pitch(W), ptr(h), h.shape[1], M, ptr(dn), ni, ptr(gW), _pitch(gW),
@@ -663,7 +619,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             H1 = torch.empty((M, W1.shape[0]), dtype=hdt, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
-            if (FUSE_LAST2 and MLP_PRECISION in (0, 2) and hdt == torch.float32 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4 and W3.shape[1] == 128
+            if (MLP_PRECISION in (0, 2) and hdt == torch.float32 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4 and W3.shape[1] == 128
                     and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # second hidden layer + output layer + sigmoid in one launch; H2 is written only for a backward
                 H2 = torch.empty((M, 128), dtype=torch.float32, device=dev) if "app" in grad_heads else None
@@ -810,7 +766,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
+                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa), stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 
@@ -871,7 +827,7 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
     vd = vm_struct(views, "density", ctx.res)
     gd = vm_grad_struct(model, gviews, "density")
     call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma),
-         ptr(ctx.sigma) if DENS_BWD_SIGMA else None, stream())
+         ptr(ctx.sigma), stream())
     vm_grad_finish(model, gviews, "density", gd)
     keep.append(dsigma)
 

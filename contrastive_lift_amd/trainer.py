@@ -157,7 +157,7 @@ class HotPathTrainer:
         ``grad_shards: False`` in the config turns it off."""
         m = self.model
         self._shards = None
-        if self.device.type != "cuda" or not bool(getattr(self.config, "grad_shards", True)) or os.environ.get("CLIFT_GRAD_SHARDS", "1") == "0":
+        if self.device.type != "cuda" or not bool(getattr(self.config, "grad_shards", True)):
             return
         s0, s1 = m.arena.range_of("net_app", "net_sem", "inst_fast")
         n = s1 - s0

@@ -339,7 +339,7 @@ def test_first2_wgrad_against_fp64_and_the_streamed_form(M):
 
 def test_head_backward_without_the_first_activation_matches_the_stored_form():
     """xyz_mlp_fwd / xyz_mlp_bwd of a 5-layer head (3 -> 256 -> 256 -> 256 -> 256 -> 22) with the fused first-two-layers backward (the forward
-    keeps no first-layer activation) against the same head with CLIFT_FUSE_FIRST2_BWD off (activation stored, masked dgrad + K = 3 weight
+    keeps no first-layer activation) against the same head with engine.KEEP_FIRST_ACT set (activation stored, masked dgrad + K = 3 weight
     gradient as separate launches): every parameter gradient within 2e-5 of its scale; the forward outputs bit-identical."""
     from contrastive_lift_amd import engine
     M, C_ = 20011, 22
@@ -351,10 +351,10 @@ def test_head_backward_without_the_first_activation_matches_the_stored_form():
     dpre[:, :C_] = torch.randn(M, C_, generator=g)
     dpre = dpre.to(DEV)
     res = {}
-    prev = engine.FUSE_FIRST2_BWD
+    prev = engine.KEEP_FIRST_ACT
     try:
         for flag in (True, False):
-            engine.FUSE_FIRST2_BWD = flag
+            engine.KEEP_FIRST_ACT = not flag
             out = torch.zeros(M, 24, device=DEV)
             gl = [(torch.zeros_like(W), torch.zeros_like(b)) for W, b in layers]
             with engine.exact_fp32():
@@ -364,7 +364,7 @@ def test_head_backward_without_the_first_activation_matches_the_stored_form():
             torch.cuda.synchronize()
             res[flag] = (out, gl)
     finally:
-        engine.FUSE_FIRST2_BWD = prev
+        engine.KEEP_FIRST_ACT = prev
     assert torch.equal(res[True][0], res[False][0])
     for (a, ab), (b, bb) in zip(res[True][1], res[False][1]):
         for x, y in ((a, b), (ab, bb)):
@@ -400,7 +400,6 @@ def test_fp32x6_weight_gradient_against_fp64(M):
     operands, against float64 next to the exact quadrant kernel: error (of the largest entry) <= 2e-6 and <= 4x the exact kernel's + 2e-7;
     accumulating (a second launch doubles the result)."""
     from contrastive_lift_amd import engine
-    assert engine.X6_WGRAD
     g = torch.Generator().manual_seed(40 + M)
     dY = (torch.randn(M, 256, generator=g) * (torch.rand(M, 256, generator=g) > 0.5) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)
     X = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)

@@ -11,6 +11,7 @@ and the trainer's exception path: a pass that dies between ``grad_sh
 import pytest
 import torch
 
+from conftest import grad_close
 from test_gpu_parity import DEV
 from test_gpu_round3 import _first2_case
 
@@ -185,8 +186,9 @@ def test_first2_x6_backward_kernels_row_limit_and_padded_pitches():
 def test_fp32x6_head_backward_matches_the_exact_path_end_to_end():
     """A four-layer (instance) and a five-layer (semantic, C = 2) head, forward + backward through engine.xyz_mlp_fwd / xyz_mlp_bwd in fp32x6
     mode (every fused end on the split kernels) against the same calls in exact fp32: outputs to 1e-5 of the output scale, every gradient
-    to 1e-3 of its largest entry (grad_close's band: one sample whose hidden unit lands on the other side of a ReLU kink between the two
-    arithmetics moves an entry by ~1 / M of the scale; the kernels themselves are held to 2e-5 against fp64 above)."""
+    within conftest.grad_close's band (2e-3 relative + 1e-3 of the scale, 0.1 % of the entries up to 1e-2 of the scale: one sample whose
+    hidden unit lands on the other side of a ReLU kink between the two arithmetics moves whole rows of the downstream gradients by its
+    contribution; the kernels themselves are held to 2e-5 against fp64 above)."""
     from contrastive_lift_amd import engine
     M = 30011
     g = torch.Generator().manual_seed(4)
@@ -213,7 +215,7 @@ def test_fp32x6_head_backward_matches_the_exact_path_end_to_end():
         assert float((o0 - o6).abs().max()) <= 1e-5 * float(o0.abs().max())
         for (gW0, gb0), (gW6, gb6) in zip(res["fp32"][1], res["fp32x6"][1]):
             for a, b in ((gW0, gW6), (gb0, gb6)):
-                assert float((a - b).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-30)
+                grad_close(b, a, what=f"{nl}-layer head, {tuple(a.shape)}")
 
 
 # ============================================================================ trainer: a pass that dies leaves nothing behind

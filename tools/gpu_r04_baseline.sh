@@ -9,6 +9,6 @@ N=${1:-2000}
   timeout 1500 python tools/shared_gpu_render_stress.py B fp32 $N > $out/stress_B.log 2>&1 &
   wait )
 tail -3 $out/stress_A.log $out/stress_B.log
-CLIFT_FORCE_MLP_DTYPE=fp32x6 timeout 1500 python -m pytest tests -q -m gpu --timeout 900 > $out/pytest_forced_x6.log 2>&1
+CLIFT_MLP_DTYPE=fp32x6 timeout 1500 python -m pytest tests -q -m gpu --timeout 900 > $out/pytest_forced_x6.log 2>&1
 echo "forced x6 rc=$?"
 tail -15 $out/pytest_forced_x6.log

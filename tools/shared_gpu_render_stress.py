@@ -1,7 +1,7 @@
 """Render-level two-processes-on-one-device stress (profiles/r03_x6_notes.txt, last section): re-render the same 131 072 rays of the 128^3
 bench scene `iters` times in the given MLP mode and compare every output bit for bit with the first render.  Run TWO instances at once:
     python tools/shared_gpu_render_stress.py A fp32x6 300 &  python tools/shared_gpu_render_stress.py B fp32x6 300
-(modes: fp32 | bf16 | fp32x6; environment switches such as CLIFT_FUSE_FIRST2=0 select the kernels in the mix).  One instance alone is the control."""
+(modes: fp32 | bf16 | fp32x6).  One instance alone is the control."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
