@@ -42,6 +42,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Timing probes (tools/x6_ablation.sh builds variants of the library with -DX6_ABL=<bits>; results are garbage by construction, never shipped):
+// 1 no fragment reads after a tile's first, 2 no activation split (staging reads, VALU, plane writes), 4 no k-half exchange / finish,
+// 8 no LDS-DMA and no waits for it, 16 no output stores, 32 no barrier.
+#ifndef X6_ABL
+#define X6_ABL 0
+#endif
 constexpr int X6_ROWS = 32;                         // rows per tile
 constexpr int X6_PLANE = X6_ROWS * 512;             // bytes of one bf16 plane image of a tile (32 rows x 256 k x 2 B)
 constexpr int X6_STAGE = 3 * X6_PLANE;              // 48 KB
@@ -168,12 +174,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 
     // ---- cooperative split: this wave provides rows wave + 8 i (i = 0..3) of every tile, lane = 16-byte piece (k = 4 lane .. +3)
     auto dma_piece = [&](int t, int i) {
+        if (X6_ABL & 8) return;
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * i, rend - 1);
         __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + 4 * lane, (lds_ptr_t)(lds + X6_RAW + (wave * 4 + i) * 1024), 16, 0, 0);
     };
     // GEN: positions of this wave's rows wave + 8 i of tile t -> staging slot (t & 1): lanes 0..15 = (row i, component), the other lanes repeat them
     const unsigned posa = lds0 + (unsigned)(X6_RAW + wave * 256);
     auto pos_dma = [&](int t) {
+        if (X6_ABL & 8) return;
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * ((lane >> 2) & 3), rend - 1);
         __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)gr * 4 + (lane & 3), (lds_ptr_t)(lds + X6_RAW + (t & 1) * 2048 + wave * 256), 4, 0, 0);
     };
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     float sp_r0, sp_r1, sp_r2, sp_r3, sp_s0, sp_s1, sp_s2, sp_s3;
     // `tn` = the tile whose rows are being split (GEN: selects the position slot)
     auto raw_read = [&](int i, int tn) {
+        if (X6_ABL & 2) return;
         if (GEN) {
             const unsigned a = posa + (unsigned)((tn & 1) * 2048);
             if (i == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(sp_x) : "v"(a) : "memory");
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     };
     // GEN: sp_x holds the row's position (after the wait that publishes it): replace it by the lane's four generated values
     auto gen_values = [&]() {
-        if (!GEN) return;
+        if (!GEN || (X6_ABL & 2)) return;
         const f32x4 p = sp_x;
         sp_x[0] = fmaxf(fmaf(gw2[0], p[2], fmaf(gw1[0], p[1], fmaf(gw0[0], p[0], gbb[0]))), 0.f);      // same order as k_linear_k3_fwd
         sp_x[1] = fmaxf(fmaf(gw2[1], p[2], fmaf(gw1[1], p[1], fmaf(gw0[1], p[0], gbb[1]))), 0.f);
@@ -222,11 +231,12 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         asm volatile("" : "+v"(sp_x));
     };
     auto split_a = [&]() {
+        if (X6_ABL & 2) return;
         sp_h0 = x6_pk(sp_x[0], sp_x[1]); sp_h1 = x6_pk(sp_x[2], sp_x[3]);
         asm volatile("" : "+v"(sp_h0), "+v"(sp_h1));
     };
-    auto split_b0 = [&]() { sp_r0 = sp_x[0] - x6_lo(sp_h0); sp_r1 = sp_x[1] - x6_hi(sp_h0); };
-    auto split_b1 = [&]() { sp_r2 = sp_x[2] - x6_lo(sp_h1); sp_r3 = sp_x[3] - x6_hi(sp_h1); };
+    auto split_b0 = [&]() { if (X6_ABL & 2) return; sp_r0 = sp_x[0] - x6_lo(sp_h0); sp_r1 = sp_x[1] - x6_hi(sp_h0); };
+    auto split_b1 = [&]() { if (X6_ABL & 2) return; sp_r2 = sp_x[2] - x6_lo(sp_h1); sp_r3 = sp_x[3] - x6_hi(sp_h1); };
     auto wr = [&](unsigned addr, int plane, int i, unsigned a, unsigned c) {
         const u32x2 d = {a, c};
         const int off = plane * X6_PLANE + (i >> 1) * 8192;
@@ -238,13 +248,15 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         if (off == 40960) asm volatile("ds_write_b64 %0, %1 offset:40960" : : "v"(addr), "v"(d) : "memory");
     };
     auto split_c = [&](unsigned stage, int i) {
+        if (X6_ABL & 2) return;
         sp_m0 = x6_pk(sp_r0, sp_r1); sp_m1 = x6_pk(sp_r2, sp_r3);
         asm volatile("" : "+v"(sp_m0), "+v"(sp_m1));
         wr(wofs[i & 1] + stage, 0, i, sp_h0, sp_h1);
     };
-    auto split_d0 = [&]() { sp_s0 = sp_r0 - x6_lo(sp_m0); sp_s1 = sp_r1 - x6_hi(sp_m0); };
-    auto split_d1 = [&]() { sp_s2 = sp_r2 - x6_lo(sp_m1); sp_s3 = sp_r3 - x6_hi(sp_m1); };
+    auto split_d0 = [&]() { if (X6_ABL & 2) return; sp_s0 = sp_r0 - x6_lo(sp_m0); sp_s1 = sp_r1 - x6_hi(sp_m0); };
+    auto split_d1 = [&]() { if (X6_ABL & 2) return; sp_s2 = sp_r2 - x6_lo(sp_m1); sp_s3 = sp_r3 - x6_hi(sp_m1); };
     auto split_e = [&](unsigned stage, int i) {
+        if (X6_ABL & 2) return;
         wr(wofs[i & 1] + stage, 1, i, sp_m0, sp_m1);
         wr(wofs[i & 1] + stage, 2, i, x6_pk(sp_s0, sp_s1), x6_pk(sp_s2, sp_s3));
     };
@@ -314,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     // sum of the two chains; the half the partner finishes goes to the exchange area (parity par), the other half stays in `keep`
     auto send = [&](int par) {
+        if (X6_ABL & 4) return;
         f32x4 sendv[2];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -326,6 +339,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         asm volatile("ds_write_b128 %0, %1 offset:1024" : : "v"(a), "v"(sendv[1]) : "memory");
     };
     auto finish = [&]() {                // keep + received + bias, activation / mask -> prev
+        if (X6_ABL & 4) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's plane and exchange writes are done ...
-        __builtin_amdgcn_s_barrier();                                            // ... and everyone's; everyone is done reading the other stage
+        if (!(X6_ABL & 32)) __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone is done reading the other stage
         asm volatile("" ::: "memory");
         const unsigned cur = (unsigned)((t & 1) * X6_STAGE), nxt = (unsigned)(((t + 1) & 1) * X6_STAGE);
         const int m = min(rbeg + t * X6_ROWS + li, rend - 1);
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(f[2]) : "v"(a) : "memory");
         };
         rd(0, fa[0]);
-        {   // the partner's share of the previous tile (parity (t - 1) & 1 = (t + 1) & 1); tile 0 reads the zeros written in the prologue
+        if (!(X6_ABL & 4)) {   // the partner's share of the previous tile (parity (t - 1) & 1 = (t + 1) & 1); tile 0 reads the zeros written in the prologue
             const unsigned a = xrd + (unsigned)(((t + 1) & 1) * 16384);
             asm volatile("ds_read_b128 %0, %1" : "=v"(recv[0]) : "v"(a) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(recv[1]) : "v"(a) : "memory");
@@ -425,11 +439,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 0
-            if (j + 1 < 8) rd(j + 1, fa[(j + 1) & 1]);
+            if (j + 1 < 8 && !(X6_ABL & 1)) rd(j + 1, fa[(j + 1) & 1]);
             if (even) {
                 // GEN: the positions of tile t+1 left during tile t-1 (one DMA, before that tile's two stores); younger than it at any of the four
                 // read-backs: those two stores, this tile's position DMA (from i = 2 on) and first store (i = 3) -- vmcnt(2) covers all four
-                if (GEN) x6_wait_vm<2>(); else x8_wait_piece<VMV>(i);
+                if (X6_ABL & 8) { } else if (GEN) x6_wait_vm<2>(); else x8_wait_piece<VMV>(i);
                 raw_read(i, t + 1);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");
@@ -479,12 +493,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 4
             if (even) {
-                if (OUTV != 2 && !K3W && i >= 2) *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2];      // steps 4, 6
+                if (OUTV != 2 && !K3W && !(X6_ABL & 16) && i >= 2)
+                    *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2];      // steps 4, 6
                 if (K3W && j == 0) k3_col(1);
                 if (K3W && j == 2) k3_col(4);
                 if (K3W && j == 4) k3_col(7);
                 if (OUTV && j == 0) out_fma(2);
-                if (OUTV && j == 2) *reinterpret_cast<f32x2*>(pslot + (size_t)prev_m * 4) = pfold;                            // "P"
+                if (OUTV && j == 2 && !(X6_ABL & 16)) *reinterpret_cast<f32x2*>(pslot + (size_t)prev_m * 4) = pfold;       // "P"
             } else { split_d0(); if (j == 7) split_d1(); }
             acc0 = x6_mfma(wh[j], f[2], acc0);
             __builtin_amdgcn_sched_barrier(0);
