@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -46,7 +46,7 @@ class Gemm(C.Structure):
                 ("mask", C.c_void_p), ("ldmask", C.c_int),
                 ("accumulate", C.c_int), ("split_k", C.c_int), ("c_trans", C.c_int), ("colsum", C.c_void_p),
                 ("precision", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
-                ("a_bf16", C.c_int), ("b_bf16", C.c_int), ("c_bf16", C.c_int), ("mask_bf16", C.c_int)]
+                ("a_bf16", C.c_int), ("b_bf16", C.c_int), ("c_bf16", C.c_int), ("mask_bf16", C.c_int), ("sign_bits", C.c_void_p)]
 
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
@@ -61,7 +61,8 @@ _SIGNATURES = {
     "clift_density_fwd": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
     "clift_density_points": ([_P, _P, _I, _L, _F, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], C.c_int),
-    "clift_xyz_head_first2_x6_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P], C.c_int),
+    "clift_xyz_head_first2_x6_fwd": ([_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_sign_bits_bytes": ([_I], C.c_long),
     "clift_xyz_head_first2_x6_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_x6_wgrad": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_last2_x6_workspace_bytes": ([_I], C.c_long),

@@ -227,6 +227,11 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     p.bias = h->bias; p.act = h->act; p.mask = h->mask; p.ldmask = h->ldmask; p.accumulate = h->accumulate;
     p.c_trans = h->c_trans; p.colsum = h->colsum;
     p.a_bf16 = h->a_bf16; p.b_bf16 = h->b_bf16; p.c_bf16 = h->c_bf16; p.mask_bf16 = h->mask_bf16;
+    p.sign_bits = (unsigned char*)h->sign_bits;
+    CLIFT_REQUIRE(!h->sign_bits || (h->precision == 2 && !h->a_trans && h->N == 256 && h->K == 256 && splits == 1 && !h->accumulate && !h->c_trans &&
+                                     h->lda % 4 == 0 && h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_X6_TILED") == nullptr &&
+                                     ((!h->b_trans && !h->mask) || (h->b_trans && !h->mask && !h->bias && h->act == 0))),
+                  "clift_gemm: sign_bits goes with the persistent fp32x6 256 x 256 forms only (forward: written; dgrad with mask = NULL: read)");
     CLIFT_REQUIRE(h->precision == 1 || !(h->a_bf16 || h->b_bf16 || h->c_bf16 || h->mask_bf16),
                   "clift_gemm: bf16-stored tensors (a/b/c/mask_bf16) are only supported with precision 1");
     CLIFT_REQUIRE(!h->c_bf16 || (!h->accumulate && !h->c_trans), "clift_gemm: a bf16-stored output cannot be accumulated into or transposed");
@@ -242,7 +247,8 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (h->precision == 2 && !h->a_trans && h->N == 256 && h->K == 256 && splits == 1 && !h->accumulate && !h->c_trans && h->lda % 4 == 0 &&
         h->ldc % 4 == 0 && (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_X6_TILED") == nullptr &&
         ((!h->b_trans && !h->mask) ||
-         (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0)))
+         (h->b_trans && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && (((uintptr_t)h->mask) & 15) == 0) ||
+         (h->b_trans && !h->mask && h->sign_bits && !h->bias && h->act == 0)))
         return clift_layer_x6_launch(p, h->b_trans, st);
     // fp32x6 weight gradient of the 256 x 256 layers (layer_x6w.hip)
     if (h->precision == 2 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&

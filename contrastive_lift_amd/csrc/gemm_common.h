@@ -20,6 +20,9 @@ struct GemmP {
     float* colsum;    // nullable: colsum[m] += sum_k A(m,k)   (bias gradient fused into the wgrad, a_trans only)
     // bf16 mode only (gemm_bf16.hip): which of the tensors are STORED as bf16 (2 bytes per element, pitches in elements)
     int a_bf16, b_bf16, c_bf16, mask_bf16;
+    // fp32x6 persistent layer kernels only (layer_x6.hip): one byte per lane and 32-row tile holding the signs of the 8 columns the lane finishes
+    // -- written by a forward, read by the masked dgrad of the following layer INSTEAD of the fp32 mask (32 B per row instead of 1 KB)
+    unsigned char* sign_bits;
 };
 
 static __device__ __forceinline__ float bf16_bits_to_float(unsigned short u) { return __uint_as_float((unsigned)u << 16); }

@@ -84,13 +84,14 @@ static __device__ __forceinline__ void x6_wait_vm() { asm volatile("s_waitcnt vm
 
 constexpr int X6_XCH = X6_RAW + X6_ROWS * 1024;     // exchange area: [tile parity][wave][2][lane] float4 = 2 x 16 KB
 // vmcnt before the read-back of staged row i (tools/x6_vmcnt_model.py replays each stream and prints these tables), by variant:
-constexpr int X8_VM[5][4] = {
+constexpr int X8_VM[6][4] = {
     {5, 4, 3, 3},       // 0 forward:                        D0 D1 S0 D2 S1 D3 per tile
     {5, 5, 5, 5},       // 1 dgrad:                    m0 m1 D0 D1 S0 D2 S1 D3; the masks are needed after 6 younger instructions
     {6, 4, 4, 4},       // 2 forward + output layer:         D0 P D1 S0 D2 S1 D3 (P = the store of the output layer's partial sums)
     {4, 2, 3, 3},       // 3 the same, hidden not written:   D0 P D1 D2 D3
     {3, 3, 3, 3},       // 4 dgrad consumed in-kernel (K3W): p D0 D1 D2 D3 (p = the rows' positions; needed after 4 younger instructions)
-};
+    {5, 5, 4, 4},       // 5 dgrad with the mask as sign bytes (BM): b D0 D1 S0 D2 S1 D3 (b = one byte per lane; needed after 6 younger)
+};                      // (forward that WRITES sign bytes: D0 B D1 S0 D2 S1 D3 = row 2 with B in P's place)
 
 template <int V>
 static __device__ __forceinline__ void x8_wait_piece(int i) {
@@ -147,12 +148,18 @@ struct X6K3 {
     float* gb0;           // (256)
 };
 
-template <bool DGRAD, bool GEN = false, int OUTV = 0, bool K3W = false>
+// BM (sign bytes, g.sign_bits): a forward also writes, a masked dgrad reads INSTEAD of the fp32 mask, ONE byte per lane and tile: bit 4 q + e = the
+// sign of the lane's finished column fcol + 8 q + e.  Forward and dgrad of consecutive layers use the same (block half, wave, lane) -> column map
+// and tiles are 32-row aligned from row 0, so byte ((row / 32) * 16 + 8 half + wave) * 64 + lane is read by the lane that needs it: one
+// coalesced 64-byte access per wave and tile, 32 B per row instead of the 1 KB fp32 mask row.  Bit-identical results (the stored activation
+// is the value whose sign was taken).
+template <bool DGRAD, bool GEN = false, int OUTV = 0, bool K3W = false, bool BM = false>
 __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range, int nranges, X6Gen gx, X6Out go, X6K3 gk) {
     static_assert(!(DGRAD && GEN), "GEN is a forward form");
     static_assert(!(OUTV && (DGRAD || GEN)), "OUTV is a plain forward form");
     static_assert(!K3W || DGRAD, "K3W is a dgrad form");
-    constexpr int VMV = K3W ? 4 : OUTV ? 1 + OUTV : (DGRAD ? 1 : 0);      // row of X8_VM
+    static_assert(!(BM && (OUTV || K3W)), "sign bytes go with the plain / generating forward and the plain dgrad");
+    constexpr int VMV = K3W ? 4 : OUTV ? 1 + OUTV : (DGRAD ? (BM ? 5 : 1) : (BM ? 2 : 0));      // row of X8_VM
     __shared__ __attribute__((aligned(1024))) unsigned char lds[X6_XCH + 2 * 16384];                // 160 KB, the only LDS object
     // register ballast: the wave allocates its whole 256-register budget, so that two of them fill the SIMD's file and no wave of another kernel
     // (another PROCESS sharing the device) is scheduled beside this MFMA stream -- see layer_x6w.hip for what happens otherwise
@@ -320,6 +327,9 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     f32x4 prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 keep[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, recv[2];
     f32x4 mk[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    unsigned mbyte = 0xffu, sbyte = 0;                                       // BM: the tile's sign byte of this lane (dgrad: read; forward: to write)
+    unsigned char* const sb0 = BM ? g.sign_bits + (size_t)(8 * half + wave) * 64 + lane : nullptr;
+    int tb_prev = rbeg / X6_ROWS, tb_done = tb_prev;                         // tile (global index) of `prev` / of the tile just multiplied
     int prev_m = min(rbeg + li, rend - 1), m_done = prev_m;                                          // (tile 0 "stores" zeros to its own rows first)
     f32x16 acc0, acc1;
 #pragma unroll
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             for (int e = 0; e < 4; ++e) {
                 float o = (keep[q][e] + recv[q][e]) + bfin[4 * q + e];
                 if (K3W) { }                                                      // (masked where it is consumed: k3_col)
+                else if (DGRAD && BM) o = ((mbyte >> (4 * q + e)) & 1u) ? o : 0.f;
                 else if (DGRAD) o = mk[q][e] > 0.f ? o : 0.f;
                 else if (g.act == 1) o = fmaxf(o, 0.f);
                 prev[q][e] = o;
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             if (even) {
                 // GEN: the positions of tile t+1 left during tile t-1 (one DMA, before that tile's two stores); younger than it at any of the four
                 // read-backs: those two stores, this tile's position DMA (from i = 2 on) and first store (i = 3) -- vmcnt(2) covers all four
-                if (X6_ABL & 8) { } else if (GEN) x6_wait_vm<2>(); else x8_wait_piece<VMV>(i);
+                if (X6_ABL & 8) { } else if (GEN) x6_wait_vm<BM ? 3 : 2>(); else x8_wait_piece<VMV>(i);
                 raw_read(i, t + 1);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
                 finish();
                 prev_m = m_done;
                 m_done = m;
+                if (BM) { tb_prev = tb_done; tb_done = rbeg / X6_ROWS + t; }
                 if (K3W) { xcur = xq; prev_ok = ok_done; ok_done = rbeg + t * X6_ROWS + li < rend; }
             } else if (even) split_e(nxt, i - 1);
             else split_b0();
@@ -467,9 +479,19 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
             // ---- gap 2
             if (even) {
-                if (DGRAD && !K3W && i < 2) {                                    // the ReLU mask of the columns this lane finishes: steps 0, 2
+                if (DGRAD && !K3W && !BM && i < 2) {                             // the ReLU mask of the columns this lane finishes: steps 0, 2
                     const float* mp = g.mask + (size_t)m * g.ldmask + fcol + 8 * i;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mk[i]) : "v"(mp) : "memory");
+                }
+                if (DGRAD && BM && j == 0) {                                     // "b": ... or its sign byte of THIS tile (consumed next tile)
+                    const unsigned char* bp = sb0 + (size_t)(rbeg / X6_ROWS + t) * 1024;
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(mbyte) : "v"(bp) : "memory");
+                }
+                if (!DGRAD && BM && j == 0) {                                    // signs of the previous tile's finished values
+                    sbyte = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sbyte |= prev[e >> 2][e & 3] > 0.f ? (1u << e) : 0u;
+                    asm volatile("" : "+v"(sbyte));
                 }
                 if (K3W && j == 0) {                                             // "p": the position of this lane's row of THIS tile (consumed next tile)
                     const float* pp = gk.x4 + (size_t)m * 4;
@@ -499,6 +521,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
                 if (K3W && j == 2) k3_col(4);
                 if (K3W && j == 4) k3_col(7);
                 if (OUTV && j == 0) out_fma(2);
+                if (!DGRAD && BM && j == 2) sb0[(size_t)tb_prev * 1024] = (unsigned char)sbyte;                                              // "B"
                 if (OUTV && j == 2 && !(X6_ABL & 16)) *reinterpret_cast<f32x2*>(pslot + (size_t)prev_m * 4) = pfold;       // "P"
             } else { split_d0(); if (j == 7) split_d1(); }
             acc0 = x6_mfma(wh[j], f[2], acc0);
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
         }
         if (K3W) asm volatile("s_waitcnt vmcnt(4)" : "+v"(xq) : : "memory");
+        else if (DGRAD && BM) asm volatile("s_waitcnt vmcnt(6)" : "+v"(mbyte) : : "memory");
         else if (DGRAD) asm volatile("s_waitcnt vmcnt(6)" : "+v"(mk[0]), "+v"(mk[1]) : : "memory");
         send(t & 1);
     }
@@ -558,6 +582,12 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 #pragma unroll
         for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(g.C + (size_t)m_done * g.ldc + fcol + 8 * q) = prev[q];
     }
+    if (!DGRAD && BM) {
+        sbyte = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sbyte |= prev[e >> 2][e & 3] > 0.f ? (1u << e) : 0u;
+        sb0[(size_t)tb_done * 1024] = (unsigned char)sbyte;
+    }
     if (OUTV) {
         out_fma(0); out_fma(1); out_fma(2); out_fma(3);
         out_fold();
@@ -591,6 +621,11 @@ int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st) {
     const int grid = 16 * cdiv(nr, 8);                               // block b: half (b >> 3) & 1 of range (b & 7) + 8 (b >> 4)
     const X6Gen none = {nullptr, nullptr, 0, nullptr};
     const X6Out no_out = {nullptr, 0, 0, nullptr, 0};
+    if (p.sign_bits) {          // (gemm.hip checked the form: forward writes the sign bytes, dgrad with mask = NULL reads them)
+        if (b_trans) k_layer_x6<true, false, 0, false, true><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
+        else k_layer_x6<false, false, 0, false, true><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
+        return clift_check_launch("clift_gemm(fp32x6 layer, sign bytes)");
+    }
     if (b_trans) k_layer_x6<true><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
     else k_layer_x6<false><<<grid, 512, 0, st>>>(p, rpr, nr, none, no_out, X6K3{});
     return clift_check_launch("clift_gemm(fp32x6 layer)");
@@ -598,8 +633,11 @@ int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st) {
 
 // First TWO layers of an xyz head in one launch, fp32x6 arithmetic for the 256 x 256 layer (the K = 3 layer is exact fp32 FMAs as in
 // clift_linear_k3_fwd): h2 = relu(W1 relu(W0 x + b0) + b1)   (tensoRF.py:475-478, 576-579).  The first layer's activation is not written.
+// bytes of the sign-byte record of an M-row activation (clift_gemm_t::sign_bits): 16 waves x 64 lanes per 32-row tile
+extern "C" long clift_sign_bits_bytes(int M) { return M > 0 ? (long)cdiv(M, X6_ROWS) * 1024 : 0; }
+
 extern "C" int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1, const float* b1,
-                                            int M, float* h2, int ldh2, clift_stream_t s) {
+                                            int M, float* h2, int ldh2, void* sign_bits, clift_stream_t s) {
     if (M <= 0) return 0;
     CLIFT_REQUIRE((((uintptr_t)x4) & 15) == 0 && (((uintptr_t)W1) & 15) == 0 && (((uintptr_t)h2) & 15) == 0 && ldw1 % 4 == 0 && ldw1 >= 256 &&
                       ldh2 % 4 == 0 && ldh2 >= 256 && ldw0 >= 3,
@@ -611,7 +649,9 @@ extern "C" int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, in
     const int nranges = tiles < pairs ? tiles : pairs;
     const int rpr = cdiv(cdiv(M, nranges), X6_ROWS) * X6_ROWS;
     const int nr = cdiv(M, rpr);
-    k_layer_x6<false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0}, X6Out{nullptr, 0, 0, nullptr, 0}, X6K3{});
+    p.sign_bits = (unsigned char*)sign_bits;
+    if (sign_bits) k_layer_x6<false, true, 0, false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0}, X6Out{nullptr, 0, 0, nullptr, 0}, X6K3{});
+    else k_layer_x6<false, true><<<16 * cdiv(nr, 8), 512, 0, as_stream(s)>>>(p, rpr, nr, X6Gen{x4, W0, ldw0, b0}, X6Out{nullptr, 0, 0, nullptr, 0}, X6K3{});
     return clift_check_launch("clift_xyz_head_first2_x6_fwd");
 }
 

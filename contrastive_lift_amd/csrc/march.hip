@@ -505,7 +505,8 @@ extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_d
     int lg = 0;
     while ((1 << lg) < Cc) ++lg;
     const int DENS_SEG = DENS_SEG_DEFAULT;
-    if (Cc <= 16) {                                                   // (otherwise: the group-per-segment walk, the only form for comps > 16)
+    const char* mode = getenv("CLIFT_DENS_SCATTER");                  // test hook: "walk" = the group-per-segment walk (the only form for comps > 16) for any comps
+    if (Cc <= 16 && !(mode && strcmp(mode, "walk") == 0)) {
         const int slab = (line_lds_floats(h_dens->res, Cc) * 4 + 15) / 16 * 16;
         const int rec_bytes = 3 * DU_SEG * (int)sizeof(DensRec);     // 6 KB per wave
         int wpb = 16, bpc = 1;

@@ -146,8 +146,13 @@ def set_mlp_precision(name):
     return prev
 
 
+def sign_bits_for(M, dev):
+    """Scratch for the sign bytes of an (M, 256) activation written by a persistent fp32x6 forward (clift_gemm_t.sign_bits): 32 B per row."""
+    return torch.empty(((M + 31) // 32 * 1024,), dtype=torch.uint8, device=dev)
+
+
 def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=0, mask=None, ldmask=0,
-         accumulate=0, split_k=1, a_off=0, c_off=0, c_trans=0, colsum=None):
+         accumulate=0, split_k=1, a_off=0, c_off=0, c_trans=0, colsum=None, sign_bits=None):
     """One clift_gemm launch.  Pitches and offsets are in ELEMENTS of the respective tensor; a tensor of dtype bfloat16 is
     passed as bf16-stored (bf16 mode only: hidden activations and their gradients)."""
     g = Gemm()
@@ -162,6 +167,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     g.accumulate, g.split_k = int(accumulate), int(split_k)
     g.c_trans = int(c_trans)
     g.colsum = colsum.data_ptr() if colsum is not None else None
+    g.sign_bits = sign_bits.data_ptr() if sign_bits is not None else None
     # fp32x6 mode: the 256 x 256 hidden layers (forward / dgrad) run as persistent split kernels (csrc/layer_x6.hip); every other
     # launch -- narrow layers (HBM streams), the 128-wide appearance MLP, the other weight gradients -- stays on its exact-fp32 persistent kernel,
     # which is faster than the tiled split kernel the library would pick for it
@@ -176,7 +182,7 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
         # the persistent split kernel takes 16-byte aligned rows; anything else (odd output pitch ...) goes to the library's tiled split
         # kernel, which needs a workspace for the split weight planes
         persistent = (int(lda) % 4 == 0 and int(ldc) % 4 == 0 and g.C % 16 == 0 and (mask is None or (int(ldmask) % 4 == 0 and g.mask % 16 == 0))
-                      and ((not b_trans and mask is None) or (b_trans and mask is not None and bias is None and not act))
+                      and ((not b_trans and mask is None) or (b_trans and (mask is not None or sign_bits is not None) and bias is None and not act))
                       and not os.environ.get("CLIFT_X6_TILED"))
         if not persistent:
             nbytes = int(_lib.load().clift_gemm_workspace_bytes(int(N), int(K)))
@@ -299,6 +305,8 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
 # gradient inside its kernel (first2_bwd) and regenerates the activation for the weight gradient (first2_wgrad); an E <= 4 output layer is
 # applied inside the last hidden layer's kernel; the output layer's weight and input gradient are one launch.  CLIFT_NO_PERSISTENT=1 selects
 # the independent tiled kernels for every layer instead (the cross-check the tests use).
+APP_SCATTER_XA = True       # tests clear it: clift_app_gather_bwd without the forward's positions (xa = NULL: the lane-per-(plane, channel) walk)
+DENS_BWD_SIGMA = True       # tests clear it: clift_density_bwd without the forward's sigma (sigma = NULL: the softplus derivative re-summed)
 KEEP_FIRST_ACT = False      # tests set this to compare against the stored-activation backward (masked dgrad + K = 3 weight gradient)
 FUSE_HEAD_BF16 = True       # bf16 mode: first three layers (+ E <= 4 output layer) of an xyz head in one launch; tests clear it to compare with the per-layer launches
 
@@ -310,9 +318,10 @@ def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
          stream())
 
 
-def first2_x6(M, xa, W0, b0, W1, b1, h2):
-    """One clift_xyz_head_first2_x6_fwd launch (fp32x6 mode): h2 = relu(W1 relu(W0 x + b0) + b1), the first activation not written."""
-    call("clift_xyz_head_first2_x6_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h2), 256, stream())
+def first2_x6(M, xa, W0, b0, W1, b1, h2, sign_bits=None):
+    """One clift_xyz_head_first2_x6_fwd launch (fp32x6 mode): h2 = relu(W1 relu(W0 x + b0) + b1), the first activation not written;
+    ``sign_bits`` (optional uint8 scratch from sign_bits_for) receives the signs of h2 for the next layer's masked dgrad."""
+    call("clift_xyz_head_first2_x6_fwd", ptr(xa), ptr(W0), _pitch(W0), ptr(b0), ptr(W1), _pitch(W1), ptr(b1), M, ptr(h2), 256, ptr(sign_bits), stream())
 
 
 def first2_x6_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
@@ -384,7 +393,10 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         # re-derives it: first2_bwd / first2_wgrad)
         W1, b1 = layers[1]
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
-        first2_x6(M, xa, W0, b0, W1, b1, h)
+        # a backward will run: the kernel also leaves the SIGNS of its output (32 B per row) for the next layer's masked dgrad, which then
+        # does not stream the 1 KB-per-row activation a second time just to test it against zero
+        h.sign_bits = sign_bits_for(M, dev) if (keep_first and len(layers) >= 4) else None
+        first2_x6(M, xa, W0, b0, W1, b1, h, h.sign_bits)
         acts += [None, h]
         rest = layers[2:-1]
     else:
@@ -403,7 +415,12 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
             acts.append(hn)
             return acts if keep_first else [None]
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
-        gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
+        # (fp32x6, a backward will run, and this is not the last hidden layer -- whose output the output layer's backward reads as values: sign bytes too)
+        sb = (sign_bits_for(M, dev) if (keep_first and MLP_PRECISION == 2 and li_ < len(rest) - 1 and tuple(W.shape) == (256, 256) and h.dtype == torch.float32
+                                        and os.environ.get("CLIFT_X6_TILED") is None and os.environ.get("CLIFT_NO_PERSISTENT") is None) else None)
+        gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1, sign_bits=sb)
+        if sb is not None:
+            hn.sign_bits = sb
         acts.append(hn)
         h = hn
     W, b = Wo, bo
@@ -452,7 +469,12 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
             keep.append(d)
             continue
         wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
-        gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
+        sb = getattr(h, "sign_bits", None)
+        if (sb is not None and MLP_PRECISION == 2 and no == 256 and ni == 256 and d.dtype == torch.float32 and d.shape[1] % 4 == 0
+                and os.environ.get("CLIFT_X6_TILED") is None):
+            gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, sign_bits=sb)      # mask = the signs the forward left behind
+        else:
+            gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, mask=h, ldmask=h.shape[1])
         d = dn
         keep.append(d)
     gW, gb = glayers[0]
@@ -766,7 +788,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa), stream())
+                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 
@@ -827,7 +849,7 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
     vd = vm_struct(views, "density", ctx.res)
     gd = vm_grad_struct(model, gviews, "density")
     call("clift_density_bwd", C.byref(ctx.ms), C.byref(vd), C.byref(gd), ptr(ctx.rays), ptr(ctx.jitter), N, ptr(dsigma),
-         ptr(ctx.sigma), stream())
+         ptr(ctx.sigma) if DENS_BWD_SIGMA else None, stream())
     vm_grad_finish(model, gviews, "density", gd)
     keep.append(dsigma)
 

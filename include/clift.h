@@ -211,8 +211,14 @@ typedef struct {
     long workspace_bytes;           /* >= clift_gemm_workspace_bytes(N, K) */
     int a_bf16, b_bf16, c_bf16, mask_bf16;  /* precision 1 only: the tensor is STORED as bf16 (2-byte elements, pitches in elements);
                                      * the pointers are passed through the float* fields */
+    void* sign_bits;                /* nullable; precision 2, N = K = 256 persistent forms only (ABI 15): clift_sign_bits_bytes(M) bytes.  A forward
+                                     * (act = 1) also WRITES the signs of its output there (one byte per lane of the kernel and 32-row tile: 32 B per
+                                     * row); the masked dgrad of the NEXT layer (b_trans, mask = NULL) READS them instead of the 1 KB-per-row fp32 mask --
+                                     * same results bit for bit.  The layout is private to csrc/layer_x6.hip: only pass what such a forward wrote for
+                                     * the same M. */
 } clift_gemm_t;
 long clift_gemm_workspace_bytes(int N, int K);
+long clift_sign_bits_bytes(int M);
 
 /* Backward of a narrow output layer (no <= 32 outputs: 22 classes / 3 instance dims) over a 256-wide ReLU hidden layer in ONE pass over
  * the hidden activation H (tensoRF.py:480-481, 593-594 backward): dX = (H > 0) . (dOut W), gW += dOut^T H, gb += column sums of dOut.
@@ -237,7 +243,8 @@ int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const 
  * cores (csrc/layer_x6.hip), the K = 3 layer exact; the first layer's activation is never written (the backward does not need it:
  * clift_xyz_head_first2_bwd / clift_xyz_head_first2_wgrad).  Results within 1e-6 (row-max relative) of clift_xyz_head_first2_fwd. */
 int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
-                                 const float* b1, int M, float* h2, int ldh2, clift_stream_t s);
+                                 const float* b1, int M, float* h2, int ldh2, void* sign_bits /* nullable, see clift_gemm_t (ABI 15) */,
+                                 clift_stream_t s);
 /* The fp32x6 counterparts of the three fused ends of an xyz head's backward / forward (ABI 14; csrc/layer_x6.hip, csrc/layer_x6w.hip): the
  * 256 x 256 products as six bf16 products per fp32 product of exactly three-way-split operands (fp32 accumulate; within 1e-6 row-max relative
  * of the exact-fp32 entry points they mirror), everything narrow -- the K = 3 layer, the ReLU masks, the E <= 4 output layer -- in exact fp32.

@@ -745,7 +745,7 @@ def test_density_scatter_wave_walk_matches_group_walk(res, N, monkeypatch):
 @pytest.mark.parametrize("M,no,ldd,ni", [(4099, 3, 4, 128), (249003, 3, 4, 128), (40001, 27, 28, 144), (8191, 27, 28, 144), (5000, 22, 24, 36), (4096, 8, 8, 252)])
 def test_narrow_wgrad_stream_on_narrower_activations(M, no, ldd, ni):
     """k_wgrad_narrow_stream with X narrower than 256 columns (the appearance output layer: 3 x 128; the appearance basis matrix: 27 x 144):
-    waves whose 32 columns start past the width only copy and wait.  Against fp64 and against the VALU kernel (CLIFT_NARROW_WGRAD_VALU),
+    waves whose 32 columns start past the width only copy and wait.  Against fp64 and against the VALU kernel (CLIFT_NO_PERSISTENT),
     accumulating onto existing contents, with and without a bias gradient, ragged row counts."""
     from contrastive_lift_amd import engine
     g = torch.Generator().manual_seed(M + no + ni)
@@ -758,7 +758,7 @@ def test_narrow_wgrad_stream_on_narrower_activations(M, no, ldd, ni):
     outs = []
     for valu in (False, True):
         if valu:
-            os.environ["CLIFT_NARROW_WGRAD_VALU"] = "1"
+            os.environ["CLIFT_NO_PERSISTENT"] = "1"
         try:
             gW = torch.full((no, ni), 0.25, device=DEV)
             gb = torch.full((no,), -1.0, device=DEV)
@@ -766,7 +766,7 @@ def test_narrow_wgrad_stream_on_narrower_activations(M, no, ldd, ni):
             gW_nb = torch.full((no, ni), 0.25, device=DEV)
             engine.call("clift_wgrad_narrow", engine.ptr(dYd), ldd, no, engine.ptr(X), ni, ni, M, engine.ptr(gW_nb), ni, None, 0, engine.stream())
         finally:
-            os.environ.pop("CLIFT_NARROW_WGRAD_VALU", None)
+            os.environ.pop("CLIFT_NO_PERSISTENT", None)
         rel_close(gW, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what=f"narrow wgrad ni={ni} valu={valu}")
         rel_close(gb, refb, 2e-5, atol=2e-5 * M ** 0.5, what="bias sums")
         rel_close(gW_nb, refw, 2e-5, atol=2e-5 * float(refw.abs().max()), what="no-bias form")

@@ -305,7 +305,7 @@ def test_fused_head_entry_points_reject_bad_arguments():
     with pytest.raises(_lib.CliftError, match="first2_wgrad"):          # positions not 16-byte aligned
         call("clift_xyz_head_first2_wgrad", ptr(d), 256, ptr(W0), 3, ptr(b0), x4.data_ptr() + 4, M, ptr(gW1), 256, None, stream())
     with pytest.raises(_lib.CliftError, match="first2_x6_fwd"):         # output pitch not a multiple of 4
-        call("clift_xyz_head_first2_x6_fwd", ptr(x4), ptr(W0), 3, ptr(b0), ptr(W), 256, ptr(b0), M, ptr(h2), 258, stream())
+        call("clift_xyz_head_first2_x6_fwd", ptr(x4), ptr(W0), 3, ptr(b0), ptr(W), 256, ptr(b0), M, ptr(h2), 258, None, stream())
     with pytest.raises(_lib.CliftError, match="grad_shards"):
         call("clift_grad_shards_begin", None, None, None, 0, stream())
     assert float(gW0.abs().max()) == 0.0 and float(gW1.abs().max()) == 0.0

@@ -97,6 +97,69 @@ def test_last2_x6_under_a_device_side_row_limit_and_bad_arguments():
     assert int(_lib.load().clift_xyz_head_last2_x6_workspace_bytes(100)) == 25600
 
 
+# ============================================================================ sign bytes instead of the fp32 mask (ABI 15)
+@pytest.mark.parametrize("M", [1, 31, 33, 4097, 62003, 249000])
+def test_fp32x6_dgrad_from_sign_bytes_is_the_masked_dgrad_bit_for_bit(M):
+    """A persistent fp32x6 forward (plain and with the K = 3 layer generated) that also writes the SIGNS of its output (clift_gemm_t.sign_bits,
+    32 B per row) -- same activation bits as without -- and the next layer's masked input gradient reading them instead of the fp32 mask:
+    bit-identical to the dgrad that streams the activation as its mask, at ragged row counts and under a row limit."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(50 + M)
+    A = (torch.randn(M, 256, generator=g) * (torch.rand(M, 256, generator=g) > 0.3)).to(DEV)
+    W = (torch.randn(256, 256, generator=g) / 16).to(DEV); b = (0.3 * torch.randn(256, generator=g)).to(DEV)
+    W0 = torch.randn(256, 3, generator=g).to(DEV); b0 = (0.5 * torch.randn(256, generator=g)).to(DEV)
+    x4 = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, torch.zeros(M, 1)], 1).contiguous().to(DEV)
+    dY = torch.randn(M, 256, generator=g).to(DEV)
+    prev = engine.set_mlp_precision("fp32x6")
+    try:
+        for gen in (False, True):
+            h_ref, h = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
+            sb = engine.sign_bits_for(M, DEV)
+            sb.fill_(0xA5)
+            if gen:
+                engine.first2_x6(M, x4, W0, b0, W, b, h_ref)
+                engine.first2_x6(M, x4, W0, b0, W, b, h, sb)
+            else:
+                engine.gemm(M, 256, 256, A, 256, W, 256, h_ref, 256, bias=b, act=1)
+                engine.gemm(M, 256, 256, A, 256, W, 256, h, 256, bias=b, act=1, sign_bits=sb)
+            d_ref, d = torch.empty(M, 256, device=DEV), torch.empty(M, 256, device=DEV)
+            engine.gemm(M, 256, 256, dY, 256, W, 256, d_ref, 256, b_trans=1, mask=h_ref, ldmask=256)
+            engine.gemm(M, 256, 256, dY, 256, W, 256, d, 256, b_trans=1, sign_bits=sb)
+            torch.cuda.synchronize()
+            assert torch.equal(h, h_ref), (M, gen)
+            assert torch.equal(d, d_ref), (M, gen)
+            assert float((d_ref == 0).float().mean()) > 0.2          # the mask does mask
+    finally:
+        engine.set_mlp_precision(prev)
+
+
+def test_fp32x6_sign_bytes_under_a_row_limit_and_bad_arguments():
+    from contrastive_lift_amd import _lib, engine
+    cap, M = 9000, 5003
+    g = torch.Generator().manual_seed(8)
+    A = torch.randn(cap, 256, generator=g).to(DEV); A[M:] = float("nan")
+    W = (torch.randn(256, 256, generator=g) / 16).to(DEV); b = torch.zeros(256, device=DEV)
+    dY = torch.randn(cap, 256, generator=g).to(DEV); dY[M:] = float("nan")
+    prev = engine.set_mlp_precision("fp32x6")
+    lim = engine.rows_limit(A.device)
+    try:
+        h = torch.full((cap, 256), -7.0, device=DEV); d = torch.full((cap, 256), -7.0, device=DEV); d_ref = torch.full((cap, 256), -7.0, device=DEV)
+        sb = engine.sign_bits_for(cap, DEV)
+        lim[0:1].fill_(M)
+        engine.gemm(cap, 256, 256, A, 256, W, 256, h, 256, bias=b, act=1, sign_bits=sb)
+        engine.gemm(cap, 256, 256, dY, 256, W, 256, d, 256, b_trans=1, sign_bits=sb)
+        engine.gemm(cap, 256, 256, dY, 256, W, 256, d_ref, 256, b_trans=1, mask=h, ldmask=256)
+        torch.cuda.synchronize()
+        assert torch.equal(d, d_ref) and bool((d[M:] == -7.0).all()) and bool(torch.isfinite(d[:M]).all())
+    finally:
+        engine.reset_rows_limit(A.device)
+        engine.set_mlp_precision(prev)
+    with pytest.raises(_lib.CliftError, match="sign_bits"):          # exact arithmetic has no such form
+        with engine.exact_fp32():
+            engine.gemm(100, 256, 256, A, 256, W, 256, h, 256, bias=b, act=1, sign_bits=sb)
+    assert int(_lib.load().clift_sign_bits_bytes(33)) == 2048
+
+
 # ============================================================================ first two layers' backward, fp32x6
 @pytest.mark.parametrize("M", [1, 31, 32, 33, 64, 4097, 62003, 249000])
 def test_first2_x6_bwd_against_fp64_and_the_exact_kernel(M):

@@ -11,6 +11,8 @@ instructions stay in flight.  Variants (template arguments of k_layer_x6) and wh
   forward, OUTV=1   forward + P              P = store of the output layer's partial sums of the previous tile (step 2, gap 4)
   forward, OUTV=2   D0 P D1 D2 D3            hidden activation not written
   dgrad, K3W        p D0 D1 D2 D3            p = load of this tile's row positions (step 0, gap 2), needed at the end of the tile; no stores
+  dgrad, BM         b + forward              b = load of this tile's sign byte (step 0, gap 2) instead of m0 m1
+  forward, BM       forward + B              B = store of the previous tile's sign byte (step 2, gap 4): the table of OUTV=1
 
 (GEN, the generated-input forward, has its own one-line argument in the source: vmcnt(2) everywhere.)
 Prints the tables the kernel hard-codes as X8_VM[variant][i] and the end-of-tile waits.  The (step, gap) of every instruction below is
@@ -19,8 +21,8 @@ what the source does -- change both together."""
 
 def schedule(variant):
     ops = []                                        # (step, gap, name)
-    dgrad = variant in ("dgrad", "k3w")
-    stores = variant in ("forward", "dgrad", "outv1")
+    dgrad = variant in ("dgrad", "k3w", "dgrad_bm")
+    stores = variant in ("forward", "dgrad", "outv1", "fwd_bm", "dgrad_bm")
     ops += [(2, 3, "D0"), (4, 3, "D1"), (6, 3, "D2"), (7, 5, "D3")]
     if stores:
         ops += [(4, 4, "S0"), (6, 4, "S1")]
@@ -30,7 +32,11 @@ def schedule(variant):
         ops += [(0, 2, "p")]
     if variant in ("outv1", "outv2"):
         ops += [(2, 4, "P")]
-    assert dgrad or variant in ("forward", "outv1", "outv2")
+    if variant == "fwd_bm":                         # forward that also writes the sign bytes: one byte store where P goes
+        ops += [(2, 4, "B")]
+    if variant == "dgrad_bm":                       # dgrad that reads sign bytes: one load instead of the two mask loads
+        ops += [(0, 2, "b")]
+    assert dgrad or variant in ("forward", "outv1", "outv2", "fwd_bm")
     return sorted(ops)
 
 
@@ -44,7 +50,7 @@ def counts(variant):
         younger = [x for x in stream[idx + 1:] if (x[0], x[1], x[2]) < (2, 2 * i, 0)]
         waits.append(len(younger))
     tail = None
-    last_needed = {"dgrad": "m1", "k3w": "p"}.get(variant)
+    last_needed = {"dgrad": "m1", "k3w": "p", "dgrad_bm": "b"}.get(variant)
     if last_needed:                                 # needed after step 7 of its own tile: everything of the tile issued after it may stay in flight
         idx = next(k for k, x in enumerate(stream) if x[0] == 1 and x[3] == last_needed)
         tail = len([x for x in stream[idx + 1:] if x[0] == 1])
@@ -52,7 +58,7 @@ def counts(variant):
 
 
 if __name__ == "__main__":
-    for row, variant in enumerate(("forward", "dgrad", "outv1", "outv2", "k3w")):
+    for row, variant in enumerate(("forward", "dgrad", "outv1", "outv2", "k3w", "dgrad_bm", "fwd_bm")):
         w, tail = counts(variant)
         print(f"X8_VM[{row}] {variant:8s} stream per tile: {' '.join(n for (_, _, n) in schedule(variant)):28s} waits {w}"
               + (f"   end-of-tile wait vmcnt({tail})" if tail is not None else ""))
