@@ -244,6 +244,8 @@ def main():
         def recorded_first2_x6(M, *args):                  # fp32x6 mode: the same fusion on the split kernel (clift_xyz_head_first2_x6_fwd)
             return bracket("fwd_gen", M, 256, 256, 2.0 * M * 256 * 3, M * 1040.0 + WB, lambda: real_first2_x6(M, *args))
         engine.first2_x6 = recorded_first2_x6
+        real_out_fwd = engine.out_layer_fwd               # E <= 32 output layer + row softmax as one stream (clift_out_layer_fwd)
+        engine.out_layer_fwd = lambda M, h, W, *args: bracket("fwd", M, W.shape[0], 256, 0.0, M * (1024.0 + 4.0 * W.shape[0]), lambda: real_out_fwd(M, h, W, *args))
         # ... and the other fused ends of the mode (ABI 14)
         engine.last2_x6 = lambda M, h, W, b, Wo, bo, hidden, *args: bracket("fwd_out", M, 256, 256, 2.0 * M * 256 * Wo.shape[0], out_bytes(M, Wo.shape[0], hidden, True),
                                                                             lambda: real_last2_x6(M, h, W, b, Wo, bo, hidden, *args))
@@ -257,6 +259,7 @@ def main():
             engine.gemm, engine.first2, engine.last2, engine.app_last2 = real_gemm, real_first2, real_last2, real_app_last2
             engine.first2_bwd, engine.first2_wgrad, engine.first2_x6 = real_first2_bwd, real_first2_wgrad, real_first2_x6
             engine.last2_x6, engine.first2_x6_bwd, engine.first2_x6_wgrad = real_last2_x6, real_first2_x6_bwd, real_first2_x6_wgrad
+            engine.out_layer_fwd = real_out_fwd
         return out
     # pass 1: only the dominant kernel's launches (k_layer_f32 forward: the 11 256 x 256 forward layers of a step, in its three
     # instantiations -- plain, K = 3 input generated in-kernel, narrow output layer fused) -- few enough events that the step stays

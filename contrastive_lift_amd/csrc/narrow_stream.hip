@@ -424,3 +424,133 @@ int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
 #undef CLIFT_DN
     return clift_check_launch("clift_gemm(narrow dgrad stream)");
 }
+
+// ============================================================================ forward of a narrow output layer (+ row softmax)
+// out[m][0..no) = act( H[m][0..256) W^T + b ),  no <= 32 (22 semantic classes), act 0 = none, 2 = softmax over the row (tensoRF.py:591-594,37):
+// ONE read of the 256-wide hidden activation -- an HBM stream -- instead of the tiled 256 x 32 GEMM (which re-streams it at < half the
+// stream rate) followed by a row-activation launch over the logits.  Persistent blocks, 32-row tiles by LDS-DMA two tiles ahead (source-side
+// bank swizzle as in layer_f32.hip: 16-byte chunk c of row r sits in slot c ^ (r & 15)); wave w contracts k = 32 w .. +31 for all 32 rows x
+// 32 (padded) classes: weights first, so a lane owns one row -- 4 ds_read_b128 + 16 v_mfma_f32_32x32x2_f32 per tile and wave, its 16 weights in
+// registers; the eight k-slices meet through LDS (4 KB per wave), 16 threads per row add them in slice order + bias, fold max / sum of the
+// softmax with xor shuffles inside the 16 lanes (the association of clift_rows_act_fwd's tree) and store two classes each: a tile's outputs
+// are one contiguous run of 32 x no floats.  Two barriers per tile.
+constexpr int OF_ROWS = 32, OF_STAGE = OF_ROWS * 1024, OF_STAGES = 3, OF_PART = OF_STAGES * OF_STAGE;      // bytes
+
+__global__ __launch_bounds__(512, 2) void k_out_narrow_fwd(const float* __restrict__ H, int ldh, const float* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, int no, int M, int rows_per_block, float* __restrict__ out,
+                                                           int ldo, int act) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[OF_PART + 8 * 4096];            // 128 KB, the only LDS object
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    if (rows_limited()) {
+        M = limit_rows(M);
+        rows_per_block = ((M + (int)gridDim.x - 1) / (int)gridDim.x + OF_ROWS - 1) / OF_ROWS * OF_ROWS;
+    }
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
+    if (rbeg >= rend) return;
+    const int ntiles = (rend - rbeg + OF_ROWS - 1) / OF_ROWS;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    auto dma = [&](int t) {                             // this wave: rows 4 wave .. +3 of tile t, one 1 KB row per instruction
+        unsigned char* st = lds + (t % OF_STAGES) * OF_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 4 + i, gr = min(rbeg + t * OF_ROWS + row, rend - 1);
+            __builtin_amdgcn_global_load_lds(H + (size_t)gr * ldh + ((lane ^ (row & 15)) << 2), (lds_ptr_t)(st + row * 1024), 16, 0, 0);
+        }
+    };
+    // weights of class li, k = 32 wave + 8 j + 4 lh + i (classes past `no` read as zero)
+    f32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (li < no) wv[j] = *reinterpret_cast<const f32x4*>(W + (size_t)li * ldw + 32 * wave + 8 * j + 4 * lh);
+    }
+    // reduce phase: thread (row rm, class pair 2 rg, 2 rg + 1)
+    const int rm = tid >> 4, rg = tid & 15, c0 = 2 * rg;
+    const float b0 = c0 < no ? bias[c0] : 0.f, b1 = c0 + 1 < no ? bias[c0 + 1] : 0.f;
+    const unsigned pread = lds0 + (unsigned)(OF_PART + ((c0 >> 3) * 64 + rm + 32 * ((c0 >> 2) & 1)) * 16 + (c0 & 3) * 4);
+    const unsigned pwrite = lds0 + (unsigned)(OF_PART + wave * 4096 + lane * 16);
+    const unsigned fbase = lds0 + (unsigned)(li * 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the weight loads: from here on the only vector-memory loads in flight are the DMAs
+
+    for (int t = 0; t < OF_STAGES - 1 && t < ntiles; ++t) dma(t);
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t has landed when at most the younger tiles' DMAs (4 per tile) and this wave's output stores of earlier tiles are outstanding:
+        // stores are older than every DMA that may stay in flight, so counting the DMAs alone is exact
+        ns_wait_vm(4 * (min(t + OF_STAGES - 2, ntiles - 1) - t));
+        __builtin_amdgcn_s_barrier();                   // A: tile t visible to every wave; every wave is done with tile t - 1's partials and stage
+        asm volatile("" ::: "memory");
+        if (t + OF_STAGES - 1 < ntiles) dma(t + OF_STAGES - 1);
+        const unsigned sb = fbase + (unsigned)((t % OF_STAGES) * OF_STAGE);
+        f32x4 xb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned a = sb + (unsigned)((((2 * (4 * wave + j) + lh) ^ (li & 15))) << 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(xb[j]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]) : : "memory");
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][i], xb[j][i], acc, 0, 0, 0);
+        // lane (li = row, lh) holds classes 8 q + 4 lh + e in acc[4 q + e]: park the slice.  The writes are inline asm, which the compiler's hazard
+        // recogniser does not look into: an LDS instruction that reads the destination of a 16-pass MFMA needs 18 wait states the hardware does
+        // NOT interlock (without them the slice leaves before the last MFMAs have landed -- seen as a few per cent error in every output)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc) : : "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            if (q == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(pwrite), "v"(v) : "memory");
+            if (q == 1) asm volatile("ds_write_b128 %0, %1 offset:1024" : : "v"(pwrite), "v"(v) : "memory");
+            if (q == 2) asm volatile("ds_write_b128 %0, %1 offset:2048" : : "v"(pwrite), "v"(v) : "memory");
+            if (q == 3) asm volatile("ds_write_b128 %0, %1 offset:3072" : : "v"(pwrite), "v"(v) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // B: all eight slices parked
+        asm volatile("" ::: "memory");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 s[8];
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) asm volatile("ds_read_b64 %0, %1" : "=v"(s[w8]) : "v"(pread + (unsigned)(w8 * 4096)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : : "memory");
+        float x0 = s[0][0], x1 = s[0][1];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) { x0 += s[w8][0]; x1 += s[w8][1]; }
+        x0 += b0; x1 += b1;
+        const bool on0 = c0 < no, on1 = c0 + 1 < no;
+        if (act == 2) {
+            float mx = fmaxf(on0 ? x0 : -INFINITY, on1 ? x1 : -INFINITY);
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+            const float e0 = on0 ? expf(x0 - mx) : 0.f, e1 = on1 ? expf(x1 - mx) : 0.f;
+            float sum = e0 + e1;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d);
+            const float inv = 1.f / sum;
+            x0 = e0 * inv; x1 = e1 * inv;
+        }
+        const int m = rbeg + t * OF_ROWS + rm;
+        if (m < rend) {
+            float* o = out + (size_t)m * ldo + c0;
+            if (on0) o[0] = x0;
+            if (on1) o[1] = x1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+extern "C" int clift_out_layer_fwd(const float* H, int ldh, const float* W, int ldw, const float* b, int no, int M, float* out, int ldo, int act,
+                                   clift_stream_t s) {
+    CLIFT_REQUIRE(no >= 1 && no <= 32, "clift_out_layer_fwd: out_features must be in [1,32] (got %d)", no);
+    CLIFT_REQUIRE(act == 0 || act == 2, "clift_out_layer_fwd: act must be 0 (none) or 2 (softmax over the row)");
+    CLIFT_REQUIRE((((uintptr_t)H) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && ldh % 4 == 0 && ldh >= 256 && ldw % 4 == 0 && ldw >= 256 && ldo >= no && b != nullptr,
+                  "clift_out_layer_fwd: H / W must be 16-byte aligned with pitches >= 256 that are multiples of 4, ldo >= out_features, bias required");
+    if (M <= 0) return 0;
+    const int tiles = cdiv(M, OF_ROWS);
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
+    const int rpb = cdiv(cdiv(M, blocks), OF_ROWS) * OF_ROWS;
+    k_out_narrow_fwd<<<cdiv(M, rpb), 512, 0, as_stream(s)>>>(H, ldh, W, ldw, b, no, M, rpb, out, ldo, act);
+    return clift_check_launch("clift_out_layer_fwd");
+}

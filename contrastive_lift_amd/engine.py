@@ -351,9 +351,20 @@ def first2_wgrad(M, d, W0, b0, xa, gW1, gb1):
     call("clift_xyz_head_first2_wgrad", ptr(d), d.shape[1], ptr(W0), _pitch(W0), ptr(b0), ptr(xa), M, ptr(gW1), _pitch(gW1), ptr(gb1), stream())
 
 
-def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
-    """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written (no
-    activation) into out[:, col_off:col_off+n_out] with row pitch ldo.
+def _row_softmax_inplace(out, M, n_out, ldo, col_off):
+    o = C.c_void_p(out.data_ptr() + 4 * col_off)
+    call("clift_rows_act_fwd", o, ldo, M, n_out, 2, o, ldo, stream())
+
+
+def out_layer_fwd(M, h, W, b, out, ldo, col_off, act):
+    """One clift_out_layer_fwd launch: out[:, col_off:col_off+no] = act(h W^T + b), no <= 32, act 0 / 2 (row softmax) -- one read of h."""
+    call("clift_out_layer_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), W.shape[0], M, C.c_void_p(out.data_ptr() + 4 * col_off), ldo, act, stream())
+
+
+def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True, out_act=0):
+    """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written into
+    out[:, col_off:col_off+n_out] with row pitch ldo -- as logits (``out_act`` 0) or after a softmax over the row (2: the semantic head,
+    tensoRF.py:37,593; applied inside the output layer's kernel where that exists, else in place by a row-activation launch).
     ``keep_first`` = False: the caller will not run a backward through this head, so the first (K = 3) layer's activation is
     never materialised (acts[0] is None) -- fp32 path, 256-wide heads."""
     dev = xa.device
@@ -373,6 +384,8 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         head_bf16(M, xa, layers[0], layers[1], layers[2], (Wo, bo) if with_out else None, h1, h2, h3, out, ldo, col_off)
         acts += [h1, h2, h3]
         if with_out:
+            if out_act == 2:
+                _row_softmax_inplace(out, M, Wo.shape[0], ldo, col_off)
             return acts if keep_first else [None]
         h = h3
         rest = layers[3:-1]
@@ -413,6 +426,8 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
             hn = torch.empty((M, 256), dtype=torch.float32, device=dev) if keep_first else None
             (last2_x6 if MLP_PRECISION == 2 else last2)(M, h, W, b, Wo, bo, hn, out, ldo, col_off)
             acts.append(hn)
+            if out_act == 2:
+                _row_softmax_inplace(out, M, Wo.shape[0], ldo, col_off)
             return acts if keep_first else [None]
         hn = torch.empty((M, W.shape[0]), dtype=hdt, device=dev)
         # (fp32x6, a backward will run, and this is not the last hidden layer -- whose output the output layer's backward reads as values: sign bytes too)
@@ -424,7 +439,14 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True):
         acts.append(hn)
         h = hn
     W, b = Wo, bo
+    if (MLP_PRECISION in (0, 2) and W.shape[0] <= 32 and W.shape[1] == 256 and h.dtype == torch.float32 and h.shape[1] == 256 and out.dtype == torch.float32
+            and _pitch(W) % 4 == 0 and b is not None and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+        # the E <= 32 output layer (+ the row softmax) as one stream over the hidden activation
+        out_layer_fwd(M, h, W, b, out, ldo, col_off, out_act)
+        return acts if keep_first else [None]
     gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), out, ldo, bias=b, c_off=col_off)
+    if out_act == 2:
+        _row_softmax_inplace(out, M, W.shape[0], ldo, col_off)
     # no backward through this head: nothing is retained, every hidden activation goes back to the (stream-ordered) allocator as soon
     # as the next layer has been enqueued -- a frame render at 65536 rays per chunk holds ~9 GiB per hidden layer otherwise
     return acts if keep_first else [None]
@@ -661,14 +683,8 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
 
         def sem_chain(keep):
             sem_layers = _lin_params(None, "render_semantic_mlp.mlp", views)
-            logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, logits, Ccls, keep_first="sem" in grad_heads)
-            if model.render_semantic_mlp.softmax:
-                sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(sem_s), Ccls, stream())
-                keep.append(logits)
-            else:
-                sem_s = logits
+            sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, sem_s, Ccls, keep_first="sem" in grad_heads, out_act=2 if model.render_semantic_mlp.softmax else 0)
             ctx.sem_s = sem_s
 
         br = Branches()
@@ -877,13 +893,8 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
         call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
         if head == "semantic":
             layers = _lin_params(None, "render_semantic_mlp.mlp", views)
-            logits = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, logits, Ccls, keep_first="sem" in grad_heads)
-            if model.render_semantic_mlp.softmax:
-                ctx.sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-                call("clift_rows_act_fwd", ptr(logits), Ccls, M, Ccls, 2, ptr(ctx.sem_s), Ccls, st)
-            else:
-                ctx.sem_s = logits
+            ctx.sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
+            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, ctx.sem_s, Ccls, keep_first="sem" in grad_heads, out_act=2 if model.render_semantic_mlp.softmax else 0)
         else:
             E = model.render_instance_mlp.output_channels
             ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)

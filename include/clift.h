@@ -227,6 +227,12 @@ long clift_sign_bits_bytes(int M);
  * one masked clift_gemm(b_trans) call, which each stream H from memory. */
 int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
                         float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
+/* Forward of a narrow output layer over a 256-wide hidden activation, with the row activation that follows it, in ONE pass over H (ABI 15;
+ * tensoRF.py:591-594 with :37 for the semantic head):  out[m][0..no) = act( H[m][0..256) W^T + b ),  no <= 32, act 0 = none, 2 = softmax over
+ * the row.  H (M, ldh) fp32, W (no, 256) pitch ldw, b (no), out (M, ldo) -- columns [no, ldo) untouched.  Replaces clift_gemm (which streams H at
+ * less than half the rate for so narrow an output) + clift_rows_act_fwd; results differ from that pair by fp32 summation order only. */
+int clift_out_layer_fwd(const float* H, int ldh, const float* W, int ldw, const float* b, int no, int M, float* out, int ldo, int act,
+                        clift_stream_t s);
 int clift_gemm(const clift_gemm_t* h_g, clift_stream_t s);
 
 /* First layer of the xyz heads (in_features == 3): out (M, Nout) = act(x[:, :3] W^T + b); x is (M, 4), W (Nout, 3)

@@ -97,6 +97,65 @@ def test_last2_x6_under_a_device_side_row_limit_and_bad_arguments():
     assert int(_lib.load().clift_xyz_head_last2_x6_workspace_bytes(100)) == 25600
 
 
+# ============================================================================ narrow output layer + row softmax as one stream (ABI 15)
+@pytest.mark.parametrize("M,no,act", [(1, 22, 2), (31, 22, 2), (33, 3, 0), (4097, 22, 2), (4099, 32, 2), (62003, 1, 2), (249001, 22, 2), (249001, 22, 0)])
+def test_out_layer_fwd_against_fp64_and_the_unfused_pair(M, no, act):
+    """clift_out_layer_fwd: out = act(H W^T + b) for no <= 32 outputs over a 256-wide hidden activation, act = none / row softmax, against
+    float64 (logits to 2e-6 of the sum's term scale, probabilities to 2e-6 absolute) and against clift_gemm + clift_rows_act_fwd; written with a
+    column offset into a wider row whose other columns stay untouched; ragged row counts."""
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(90 + M + no)
+    H = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)
+    W = (torch.randn(no, 256, generator=g) / 8).to(DEV); b = torch.randn(no, generator=g).to(DEV)
+    ldo = no + 5
+    out = torch.full((M, ldo), -7.0, device=DEV)
+    engine.out_layer_fwd(M, H, W, b, out, ldo, 2, act)
+    ref = H.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    scale = (H.double().cpu().abs() @ W.double().cpu().abs().t() + b.double().cpu().abs()).clamp_min(1e-30)
+    pair = torch.empty(M, no, device=DEV)
+    with engine.exact_fp32():
+        engine.gemm(M, no, 256, H, 256, W, 256, pair, no, bias=b)
+    if act == 2:
+        ref = torch.softmax(ref, -1)
+        call("clift_rows_act_fwd", ptr(pair), no, M, no, 2, ptr(pair), no, stream())
+    torch.cuda.synchronize()
+    got = out[:, 2:2 + no].double().cpu()
+    assert bool((out[:, :2] == -7.0).all()) and bool((out[:, 2 + no:] == -7.0).all())
+    if act == 2:
+        assert float((got - ref).abs().max()) <= 2e-6
+        assert float((got.sum(-1) - 1).abs().max()) <= 1e-5
+        assert float((got - pair.double().cpu()).abs().max()) <= 2e-6
+    else:
+        assert float(((got - ref).abs() / scale).max()) <= 2e-6
+        assert float(((got - pair.double().cpu()).abs() / scale).max()) <= 2e-6
+
+
+def test_out_layer_fwd_row_limit_padded_pitches_and_bad_arguments():
+    from contrastive_lift_amd import _lib, engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    cap, M, no = 9000, 5003, 22
+    g = torch.Generator().manual_seed(12)
+    Hp = torch.full((cap, 260), float("nan"), device=DEV); Hp[:M, :256] = torch.relu(torch.randn(M, 256, generator=g)).to(DEV)
+    Wp = torch.full((no, 264), float("nan"), device=DEV); Wp[:, :256] = (torch.randn(no, 256, generator=g) / 8).to(DEV)
+    b = torch.randn(no, generator=g).to(DEV)
+    out = torch.full((cap, 24), -7.0, device=DEV)
+    lim = engine.rows_limit(out.device)
+    lim[0:1].fill_(M)
+    try:
+        call("clift_out_layer_fwd", ptr(Hp), 260, ptr(Wp), 264, ptr(b), no, cap, ptr(out), 24, 2, stream())
+        torch.cuda.synchronize()
+    finally:
+        engine.reset_rows_limit(out.device)
+    ref = torch.softmax(Hp[:M, :256].double().cpu() @ Wp[:, :256].double().cpu().t() + b.double().cpu(), -1)
+    assert bool((out[M:] == -7.0).all()) and bool((out[:, no:] == -7.0).all())
+    assert float((out[:M, :no].double().cpu() - ref).abs().max()) <= 2e-6
+    with pytest.raises(_lib.CliftError, match="out_features"):
+        call("clift_out_layer_fwd", ptr(Hp), 260, ptr(Wp), 264, ptr(b), 33, 100, ptr(out), 40, 0, stream())
+    with pytest.raises(_lib.CliftError, match="act must be"):
+        call("clift_out_layer_fwd", ptr(Hp), 260, ptr(Wp), 264, ptr(b), 22, 100, ptr(out), 24, 1, stream())
+
+
 # ============================================================================ sign bytes instead of the fp32 mask (ABI 15)
 @pytest.mark.parametrize("M", [1, 31, 33, 4097, 62003, 249000])
 def test_fp32x6_dgrad_from_sign_bytes_is_the_masked_dgrad_bit_for_bit(M):

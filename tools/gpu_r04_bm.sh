@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/${1:-r04_bm}
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_round4.py -q -x --timeout 600 > $out/pytest_round4.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_round4.py -q --timeout 600 > $out/pytest_round4.log 2>&1
 echo "round4 tests rc=$?" | tee -a $out/summary.txt
 tail -n 4 $out/pytest_round4.log >> $out/summary.txt
 timeout 2400 python -m pytest tests -q -m gpu --timeout 900 > $out/pytest_gpu.log 2>&1
