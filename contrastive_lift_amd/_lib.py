@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "clift_gemm_workspace_bytes": ([_I, _I], C.c_long),
     "clift_out_layer_fwd": ([_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_out_layer_bwd": ([_P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_out_layer_bwd_nh": ([_P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_last_error": ([], C.c_char_p),
     "clift_gen_rays": ([_I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
     "clift_density_fwd": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),
@@ -93,6 +94,8 @@ _SIGNATURES = {
     "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_app_encode_bwd": ([_P, _I, _I, _I, _P, _I, _I, _P, _I, _P], C.c_int),
+    "clift_app_gather_bwd_basis": ([_P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_app_front_fwd": ([_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_gemm": ([_P, _P], C.c_int),
     "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_linear_k3_bwd": ([_P, _P, _I, _I, _I, _P, _I, _P, _I, _P], C.c_int),

@@ -20,7 +20,7 @@ int clift_check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int clift_version(void) { return 15; }
+extern "C" int clift_version(void) { return 16; }
 
 // Data-parallel runs: while an asynchronous RCCL all-reduce is in flight the persistent launches (one block per CU, held for the whole
 // launch) leave `k` CUs to the collective's kernels.  Host state of the calling process; takes effect at the next launch.

@@ -4,6 +4,7 @@
 CLIFT_ROWS_LIMIT_BINDER(heads_io)
 #include <stdlib.h>
 #include <string.h>
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // ============================================================================ appearance gather
 // Thread = (active sample, 4-channel group).  The 3*comps/4 threads of one sample write one contiguous row of
@@ -244,9 +245,46 @@ struct alignas(16) WalkRec {
     int pad[3];
 };
 
-template <bool LDS_LINES>
-__global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
-                                                              int seg_len) {
+// BASIS (ABI 16): the gradient arrives as dfeat (M, lddf <= 28: the gradient of the basis Linear's OUTPUT, tensoRF.py:65,134) instead of dF, and
+// the basis Linear's backward runs inside the walk: a lane (= one channel of one plane) keeps its column of Wb (28 registers) and forms
+// dF = sum_j dfeat[s][j] Wb[j][c] itself -- the dfeat row of a step is wave-uniform: scalar loads, one SGPR operand per FMA --, and since it also
+// holds the product P L = F[s][c] of the step it adds dfeat[s][j] F[s][c] into 28 running sums: the weight gradient of the basis matrix, folded
+// over the block's waves in LDS and added to memory once per block.  Every wave then keeps ONE plane for the whole launch (items strided by a
+// multiple of 3).  Neither dF (M x 144 floats written by a GEMM and read here) nor F (written by the forward, read by a weight-gradient launch)
+// exists any more.
+constexpr int AB_NF = 28;
+// one row of dfeat (28 floats, wave-uniform address) into SGPRs.  Inline asm: with the atomics in the kernel the compiler does not prove the row
+// unclobbered and loads it per lane (28 VGPRs per step: the kernel spilled).
+typedef float f32x8s __attribute__((ext_vector_type(8)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+struct DfRow { f32x8s a, b, c; f32x4s d; };
+// issue / wait as two statements: the row of the NEXT step is requested before the current step's FMAs and awaited after them.  Between the two
+// the registers are named only as outputs of the first and in-outs of the second, so the compiler has no value to read early.
+// `seed` (in-out of the issue) and `done` (inputs of the wait) are values of the FMA chains that are to run between the two: the compiler may move
+// arithmetic across an asm statement, and without them it scheduled every FMA of the step outside the issue .. wait window.
+// `lds0` / `lds1`: values of the step's LDS reads -- the issue must come after their wait, or that wait (same counter) waits for the row as well.
+__device__ __forceinline__ void sload_row28_issue(DfRow& r, const float* p, float& seed0, float& seed1, float lds0, float lds1) {
+    asm volatile("s_load_dwordx8 %0, %6, 0x0\n\ts_load_dwordx8 %1, %6, 0x20\n\ts_load_dwordx8 %2, %6, 0x40\n\ts_load_dwordx4 %3, %6, 0x60"
+                 : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c), "=&s"(r.d), "+v"(seed0), "+v"(seed1) : "s"(p), "v"(lds0), "v"(lds1) : "memory");
+}
+__device__ __forceinline__ void sload_row28_wait(DfRow& r, const float (&g)[28]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c), "+s"(r.d)
+                 : "v"(g[0]), "v"(g[2]), "v"(g[4]), "v"(g[6]), "v"(g[8]), "v"(g[10]), "v"(g[12]), "v"(g[14]), "v"(g[16]), "v"(g[18]), "v"(g[20]), "v"(g[22]),
+                   "v"(g[24]), "v"(g[26]) : "memory");
+}
+__device__ __forceinline__ void sload_row28_now(DfRow& r, const float* p) {
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx4 %3, %4, 0x60\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c), "=&s"(r.d) : "s"(p) : "memory");
+}
+__device__ __forceinline__ float dfrow_at(const DfRow& r, int j) { return j < 8 ? r.a[j] : j < 16 ? r.b[j - 8] : j < 24 ? r.c[j - 16] : r.d[j - 24]; }
+constexpr int AB_THREADS = 1024;
+constexpr int AB_U = 2;                // (the 56 registers of the basis column and its gradient leave room for two steps' loads)
+template <bool LDS_LINES, bool BASIS = false>
+__global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
+                                                              int seg_len, const float* __restrict__ dfeat = nullptr, int lddf = 0, int nf = 0,
+                                                              const float* __restrict__ Wb = nullptr, int ldb = 0, float* __restrict__ gWb = nullptr,
+                                                              int ldg = 0) {
+    constexpr int UU = BASIS ? AB_U : AU_U;              // steps whose loads are issued together
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = LDS_LINES ? line_lds_floats(t.res, t.comps) : 0;
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
@@ -259,12 +297,22 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
     const bool live = lane < C;
     M = limit_rows(M);
     const long items = 3L * ((M + seg_len - 1) / seg_len);
-    for (long it = (long)blockIdx.x * nwaves + wave; it < items; it += (long)gridDim.x * nwaves) {
+    const long tw = (long)gridDim.x * nwaves;
+    const long stride = BASIS ? tw / 3 * 3 : tw;                 // BASIS: a multiple of 3 -- (item % 3), the plane, never changes for a wave
+    const long first = (long)blockIdx.x * nwaves + wave;
+    float wb[AB_NF], gacc[AB_NF];
+    if (BASIS) {
+        const int ib = (int)(first % 3);
+#pragma unroll
+        for (int j = 0; j < AB_NF; ++j) { wb[j] = j < nf ? Wb[(size_t)j * ldb + ib * C + c] : 0.f; gacc[j] = 0.f; }
+    }
+    for (long it = (BASIS && first >= stride) ? items : first; it < items; it += stride) {
         const int seg = (int)(it / 3), i = (int)(it - 3L * seg);
         int a, b, v;
         vm_axes(i, a, b, v);
         const int W = t.res[a];
-        const int s0 = seg * seg_len, n = min(seg_len, M - s0);
+        const int s0 = BASIS ? __builtin_amdgcn_readfirstlane(seg * seg_len) : seg * seg_len;
+        const int n = BASIS ? __builtin_amdgcn_readfirstlane(min(seg_len, M - s0)) : min(seg_len, M - s0);     // (the scalar row registers must not cross a branch the compiler takes for divergent)
         // ---------------- phase 1
         {
             const int p = lane;
@@ -319,7 +367,7 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
         float* gp = gr.plane[i] + xoff;
         float* ll = lds_lines + line_lds_offset(t, i);
         float* gl = gr.line[i] + xoff;
-        const float* dcol = dF + (size_t)s0 * G + i * C + c;
+        const float* dcol = BASIS ? nullptr : dF + (size_t)s0 * G + i * C + c;
         const int c4 = 4 * c;
         auto at = [](auto* base, int off) {            // (pointer arithmetic, not integer casts: the address space must stay visible)
             typedef typename std::conditional<std::is_const<typename std::remove_pointer<decltype(base)>::type>::value, const char, char>::type B;
@@ -338,25 +386,29 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
         };
         int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
         float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
-        for (int p0 = 0; p0 < n; p0 += AU_U) {
-            int4 kq[AU_U];
-            int2 kzz[AU_U];
-            float tv[AU_U][4], tl[AU_U][2], td[AU_U];
+        DfRow cur;
+        if (BASIS) {
+            sload_row28_now(cur, dfeat + (size_t)__builtin_amdgcn_readfirstlane(s0) * lddf);
+        }
+        for (int p0 = 0; p0 < n; p0 += UU) {
+            int4 kq[UU];
+            int2 kzz[UU];
+            float tv[UU][4], tl[UU][2], td[UU];
 #pragma unroll
-            for (int u = 0; u < AU_U; ++u) {
+            for (int u = 0; u < UU; ++u) {
                 const int4* src = reinterpret_cast<const int4*>(recs + min(p0 + u, n - 1));
                 kq[u] = src[0];
                 kzz[u] = *reinterpret_cast<const int2*>(src + 2);
             }
 #pragma unroll
-            for (int u = 0; u < AU_U; ++u) {
+            for (int u = 0; u < UU; ++u) {
                 tv[u][0] = *at(pp, max(kq[u].x, 0) + c4); tv[u][1] = *at(pp, max(kq[u].y, 0) + c4);
                 tv[u][2] = *at(pp, max(kq[u].z, 0) + c4); tv[u][3] = *at(pp, max(kq[u].w, 0) + c4);
                 tl[u][0] = *at(lp, max(kzz[u].x, 0) + c4); tl[u][1] = *at(lp, max(kzz[u].y, 0) + c4);
-                td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
+                if (!BASIS) td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
             }
 #pragma unroll
-            for (int u = 0; u < AU_U; ++u) {
+            for (int u = 0; u < UU; ++u) {
                 if (p0 + u >= n) break;                                        // uniform
                 const int4* src = reinterpret_cast<const int4*>(recs + (p0 + u));
                 const int4 r1 = src[1], r2 = src[2];
@@ -376,14 +428,34 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
                     if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
                     lk[sl] = kz[sl];
                 }
+                DfRow nx;
+                float a0 = 0.f, a1 = 0.f;                                      // even / odd j: two chains (packed FMAs)
+                if (BASIS)         // the dfeat row of the NEXT step is on its way while this step's table waits and 56 FMAs run.  (Issued AFTER the step's
+                                   // LDS reads were consumed: scalar loads share their counter, a wait for an LDS read would wait for the row as well)
+                    sload_row28_issue(nx, dfeat + (size_t)__builtin_amdgcn_readfirstlane(s0 + min(p0 + u + 1, n - 1)) * lddf, a0, a1, ws[3], wz[1]);
                 float P = 0.f;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], ks[sl] >= 0 ? tv[u][sl] : 0.f, P);
                 const float L = fmaf(wz[1], kz[1] >= 0 ? tl[u][1] : 0.f, wz[0] * (kz[0] >= 0 ? tl[u][0] : 0.f));
-                const float gP = td[u] * L, gL = td[u] * P;
+                float tdv;
+                if (BASIS) {
+#pragma unroll
+                    for (int j = 0; j < AB_NF; j += 2) { a0 = fmaf(dfrow_at(cur, j), wb[j], a0); a1 = fmaf(dfrow_at(cur, j + 1), wb[j + 1], a1); }
+                    tdv = a0 + a1;
+                } else {
+                    tdv = td[u];
+                }
+                const float gP = tdv * L, gL = tdv * P;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
                 lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
+                if (BASIS) {
+                    const float Fv = P * L;
+#pragma unroll
+                    for (int j = 0; j < AB_NF; ++j) gacc[j] = fmaf(dfrow_at(cur, j), Fv, gacc[j]);
+                    sload_row28_wait(nx, gacc);
+                    cur = nx;
+                }
             }
         }
 #pragma unroll
@@ -393,6 +465,26 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
         for (int q = 0; q < 4; ++q)
             if (ck[q] >= 0) plane_out(ck[q], ca[q]);
         __builtin_amdgcn_wave_barrier();               // the next item's phase 1 overwrites the records
+    }
+    if (BASIS) {
+        // the block's waves meet in LDS (over the walk records, which are dead now): gsum[j][plane * C + c], then one atomic per entry and block
+        float* const gsum = lds_lines + (nl + 3) / 4 * 4;
+        const int ng = AB_NF * 3 * C;
+        __syncthreads();
+        for (int e = threadIdx.x; e < ng; e += blockDim.x) gsum[e] = 0.f;
+        __syncthreads();
+        if (live && first < stride) {
+            const int ib = (int)(first % 3);
+#pragma unroll
+            for (int j = 0; j < AB_NF; ++j) atomicAdd(gsum + j * 3 * C + ib * C + c, gacc[j]);
+        }
+        __syncthreads();
+        float* const gdst = grad_target(gWb);
+        for (int e = threadIdx.x; e < nf * 3 * C; e += blockDim.x) {
+            const int j = e / (3 * C), cc = e - j * 3 * C;
+            const float v = gsum[e];
+            if (v != 0.f) unsafeAtomicAdd(gdst + (size_t)j * ldg + cc, v);
+        }
     }
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
@@ -439,6 +531,39 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
         k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, xa);
     }
     return clift_check_launch("clift_app_gather_bwd");
+}
+
+/* Backward of the appearance gather AND of the basis Linear in one launch (ABI 16): see k_app_gather_bwd_u<.., BASIS>. */
+extern "C" int clift_app_gather_bwd_basis(const clift_vm_t* h_app, const clift_vm_grad_t* h_grad, int M, const float* dfeat, int lddf, int nf,
+                                          const float* Wb, int ldb, float* gWb, int ldg, const float* xa, clift_stream_t s) {
+    CLIFT_REQUIRE(h_app->comps % 4 == 0 && h_app->comps <= 64, "clift_app_gather_bwd_basis: comps must be a multiple of 4, <= 64");
+    CLIFT_REQUIRE(nf >= 1 && nf <= AB_NF && lddf == AB_NF, "clift_app_gather_bwd_basis: n_features <= %d and lddf == %d (pad columns zero) required", AB_NF, AB_NF);
+    CLIFT_REQUIRE(xa != nullptr && dfeat != nullptr && Wb != nullptr && gWb != nullptr, "clift_app_gather_bwd_basis: xa, dfeat, Wb, gWb must not be NULL");
+    CLIFT_REQUIRE(ldb >= 3 * h_app->comps && ldg >= 3 * h_app->comps, "clift_app_gather_bwd_basis: basis pitches smaller than 3 * comps");
+    if (M <= 0) return 0;
+    const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
+    const int rec_bytes = AU_SEG * (int)sizeof(WalkRec);
+    const int slab = (lds_bytes + 15) / 16 * 16;
+    const int gsum_bytes = AB_NF * 3 * h_app->comps * 4;                // the end-of-launch fold of the basis gradient lives over the records
+    int wpb = 16, bpc = 1;
+    bool lds_l = true;
+    if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 16; bpc = 2; }
+    else if (2 * (slab + 8 * rec_bytes) <= 160 * 1024 - 1024 && 8 * rec_bytes >= gsum_bytes) { wpb = 8; bpc = 2; }
+    CLIFT_REQUIRE(wpb * rec_bytes >= gsum_bytes, "clift_app_gather_bwd_basis: record area smaller than the basis-gradient fold");
+    const long items = 3L * cdiv(M, AU_SEG);
+    const int want = cdiv(items, wpb);
+    const int blocks = want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc;
+    const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
+    if (lds_l) {
+        if (dyn > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd_u<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+        k_app_gather_bwd_u<true, true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, nullptr, xa, AU_SEG, dfeat, lddf, nf, Wb, ldb,
+                                                                                gWb, ldg);
+    } else {
+        k_app_gather_bwd_u<false, true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, nullptr, xa, AU_SEG, dfeat, lddf, nf, Wb, ldb,
+                                                                                 gWb, ldg);
+    }
+    return clift_check_launch("clift_app_gather_bwd_basis");
 }
 
 // ============================================================================ appearance MLP input
@@ -525,6 +650,227 @@ extern "C" int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_f
     const long total = (long)M * lddf;
     k_app_encode_bwd<<<cdiv(total, 256), 256, 0, as_stream(s)>>>(feat, ldf, nf, pe_feat, dX, ldx, total, dfeat, lddf);
     return clift_check_launch("clift_app_encode_bwd");
+}
+
+// ============================================================================ appearance front end, forward, ONE launch
+// gather (plane x line products, a9) -> basis Linear(3 comps -> nf, no bias; tensoRF.py:65,127-134) -> MLP input row [feat | dir | PE] (a10
+// input assembly) for a tile of AF_TS = 64 consecutive active samples, the products and the features never leaving the CU.  512 threads:
+//   phase 0:  64 threads set up the tile's samples (ray slab, z, normalised position) once -- the unfused gather redid that, six divisions and
+//             all, in each of the 36 threads of a sample; positions + view directions go to LDS, xa to memory;
+//   phase 0b: thread = (plane, sample): the tap geometry ONCE per pair -- four texel offsets and bilinear weights, two line offsets and weights,
+//             a 48-byte record in LDS.  (Timing probes of the first form of this kernel, AF_ABL: the per-thread tap arithmetic, repeated in the 12
+//             channel groups of a pair, was 75 of its 190 us -- it is what bounds the unfused gather, too);
+//   phase 1:  thread = (plane, sample, 4-channel group), plane wave-uniform: record + six 16-byte table reads -> product into the F tile in LDS
+//             (and to memory only when the caller wants F).  64 consecutive samples of the compacted order are one or two rays: their taps
+//             overlap, so most of these reads hit the L1;
+//   phase 2:  feat = F Wb^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: rows = 32 samples, columns = the <= 28 features padded to 32),
+//             waves 0..3 = (sample half, k half); a lane's 36 weights live in registers (loaded at kernel start), its F values come as
+//             ds_read_b128 (row stride 4 x odd: conflict-free); the two k halves meet in LDS (upper half stores, barrier, lower half adds);
+//   phase 3:  thread = (sample, source element): one sincosf per (element, frequency) as in k_app_encode_fwd, the row assembled in LDS (over the F
+//             tile, which is dead by then; odd row stride: a wave writes one column of 64 rows);
+//   phase 4:  the tile's rows of X are ONE contiguous run of memory: a wave stores 256 consecutive bytes per instruction.
+// Against the three launches it replaces (gather 96 us, 144 -> 27 GEMM 60 us, encode 75 us at 287 k samples) it neither writes and re-reads the
+// products (2 x 165 MB) nor re-reads the features.
+#ifndef AF_ABL
+#define AF_ABL 0           // timing probes (tools/app_probe.sh): bit 0 no gather loads, 1 no contraction, 2 no sincos, 3 no X store (results garbage)
+#endif
+constexpr int AF_TS = 64;
+constexpr int AF_FT = 29;              // floats between the feature rows of the tile (odd: a wave's column accesses are conflict-free)
+constexpr int AF_NF = 28;              // feature columns in memory (ldf) = the most features the kernel takes
+struct alignas(16) AfRec {
+    int o[4];              // texel offsets (floats) into the channels-last plane: corners (x0,y0) (x1,y0) (x0,y1) (x1,y1), clamped
+    float w[4];            // bilinear weights (0 where the tap is out of range)
+    int z[2];              // line entries
+    float wz[2];
+};
+
+template <int COMPS>
+__global__ __launch_bounds__(512) void k_app_front_fwd(MarchP m, VmP t, const float* __restrict__ rays, const float* __restrict__ jitter,
+                                                        const int* __restrict__ act, int M, const float* __restrict__ Wb, int ldb, int nf,
+                                                        int pef, int pev, float* __restrict__ xa, float* __restrict__ feat,
+                                                        float* __restrict__ X, int ldx, float* __restrict__ F) {
+    constexpr int C = COMPS, NC = 3 * C, G4 = C / 4, FS = 4 * ((NC / 4) | 1), KS = NC / 4;      // KS: MFMA steps (= weights) per lane
+    static_assert(C % 16 == 0 && KS % 4 == 0, "the k quarters of phase 2 are read 16 bytes at a time");
+    extern __shared__ __attribute__((aligned(16))) float af_lds[];
+    float* const pos = af_lds;                                   // [64][8]: xn.xyz, valid flag, dir.xyz, 0
+    AfRec* const recs = reinterpret_cast<AfRec*>(pos + AF_TS * 8);   // [3][64]; dead after phase 1:
+    float* const ft = pos + AF_TS * 8;                           // feature tile [64][AF_FT] (phase 2 on)
+    float* const big = ft + AF_TS * 3 * (int)(sizeof(AfRec) / 4);    // F tile [64][FS], later the X tile [64][ldx | 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    M = limit_rows(M);
+    const int s0 = blockIdx.x * AF_TS;
+    if (s0 >= M) return;
+    // (waves 0..3) this lane's KS basis weights: row j = li, k = (NC / 2) (wave >> 1) + KS lh + 0 .. KS-1
+    float4 bw[KS / 4];
+    const int li = lane & 31, lh = lane >> 5;
+    const int kbase = (NC / 2) * (wave >> 1) + KS * lh;
+    if (wave < 4) {
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q)
+            bw[q] = (li < nf && !(AF_ABL & 2)) ? *reinterpret_cast<const float4*>(Wb + (size_t)li * ldb + kbase + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---------------- phase 0
+    if (tid < AF_TS) {
+        const int s = s0 + tid;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < M) {
+            const int sid = act[s];
+            const int r = sid / m.S, k = sid - r * m.S;
+            const RayG g = load_ray(rays, r, m);
+            float xn[3];
+            sample_xn(g, m, sample_z(g, m, k, jitter ? jitter[r] : 0.f), xn);
+            p = make_float4(xn[0], xn[1], xn[2], 1.f);
+            d = make_float4(g.d[0], g.d[1], g.d[2], 0.f);
+            if (xa) *reinterpret_cast<float4*>(xa + (size_t)s * 4) = make_float4(xn[0], xn[1], xn[2], 0.f);
+        }
+        *reinterpret_cast<float4*>(pos + tid * 8) = p;
+        *reinterpret_cast<float4*>(pos + tid * 8 + 4) = d;
+    }
+    __syncthreads();
+    // ---------------- phase 0b
+    if (tid < 3 * AF_TS) {
+        const int i = wave, sl = lane;
+        const float4 p = *reinterpret_cast<const float4*>(pos + sl * 8);
+        const float xn[3] = {p.x, p.y, p.z};
+        const VmTaps tp = vm_taps(t, i, xn);
+        int a_, b_, v_;
+        vm_axes(i, a_, b_, v_);
+        const int W = t.res[a_];
+        int4* dst = reinterpret_cast<int4*>(recs + i * AF_TS + sl);
+        dst[0] = make_int4((tp.ty.i0 * W + tp.tx.i0) * C, (tp.ty.i0 * W + tp.tx.i1) * C, (tp.ty.i1 * W + tp.tx.i0) * C, (tp.ty.i1 * W + tp.tx.i1) * C);
+        dst[1] = make_int4(__float_as_int(tp.tx.w0 * tp.ty.w0), __float_as_int(tp.tx.w1 * tp.ty.w0), __float_as_int(tp.tx.w0 * tp.ty.w1),
+                           __float_as_int(tp.tx.w1 * tp.ty.w1));
+        dst[2] = make_int4(tp.tz.i0 * C, tp.tz.i1 * C, __float_as_int(tp.tz.w0), __float_as_int(tp.tz.w1));
+    }
+    __syncthreads();
+    // ---------------- phase 1: items in plane-major order (64 x G4 = a whole number of waves per plane: the plane is wave-uniform)
+    constexpr int PER_PLANE = AF_TS * G4;
+    for (int e = tid; e < 3 * PER_PLANE; e += 512) {
+        const int i = __builtin_amdgcn_readfirstlane(e / PER_PLANE);
+        const int r_ = e - i * PER_PLANE, sl = r_ / G4, c4 = (r_ - sl * G4) * 4;
+        const int4* rp = reinterpret_cast<const int4*>(recs + i * AF_TS + sl);
+        const int4 o = rp[0], wi = rp[1], zi = rp[2];
+        const float* pp = t.plane[i] + c4;
+        const float* lp = t.line[i] + c4;
+        float4 v;
+        if (AF_ABL & 1) {
+            v = make_float4(__int_as_float(wi.x), __int_as_float(wi.y), __int_as_float(wi.z), __int_as_float(zi.z));
+        } else {
+            float4 acc = f4_scale(__int_as_float(wi.x), ld4(pp + (unsigned)o.x));
+            acc = f4_fma(__int_as_float(wi.y), ld4(pp + (unsigned)o.y), acc);
+            acc = f4_fma(__int_as_float(wi.z), ld4(pp + (unsigned)o.z), acc);
+            acc = f4_fma(__int_as_float(wi.w), ld4(pp + (unsigned)o.w), acc);
+            float4 ln = f4_scale(__int_as_float(zi.z), ld4(lp + (unsigned)zi.x));
+            ln = f4_fma(__int_as_float(zi.w), ld4(lp + (unsigned)zi.y), ln);
+            v = f4_mul(acc, ln);
+        }
+        *reinterpret_cast<float4*>(big + sl * FS + i * C + c4) = v;
+        if (F && s0 + sl < M) *reinterpret_cast<float4*>(F + (size_t)(s0 + sl) * NC + i * C + c4) = v;
+    }
+    __syncthreads();
+    // ---------------- phase 2
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (wave < 4) {
+        const float* frow = big + (32 * (wave & 1) + li) * FS + kbase;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const float4 f = *reinterpret_cast<const float4*>(frow + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, bw[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, bw[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, bw[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, bw[q].w, acc, 0, 0, 0);
+        }
+    }
+    // acc[r]: sample 32 (wave & 1) + 8 (r >> 2) + 4 lh + (r & 3), feature li.  (the records under `ft` are dead: every wave passed the barrier above)
+    if (wave >= 2 && wave < 4 && li < AF_NF) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ft[(32 * (wave & 1) + 8 * (r >> 2) + 4 * lh + (r & 3)) * AF_FT + li] = acc[r];
+    }
+    __syncthreads();
+    if (wave < 2 && li < AF_NF) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* q = ft + (32 * (wave & 1) + 8 * (r >> 2) + 4 * lh + (r & 3)) * AF_FT + li;
+            *q = acc[r] + *q;
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 3 (the X tile overwrites the F tile)
+    const int rows = min(AF_TS, M - s0);
+    for (int e = tid; e < rows * AF_NF; e += 512) {                     // the features themselves (the encode backward reads them), pad columns zero
+        const int sl = e / AF_NF, j = e - sl * AF_NF;
+        feat[(size_t)s0 * AF_NF + e] = j < nf ? ft[sl * AF_FT + j] : 0.f;
+    }
+    const int XS = ldx | 1;
+    {
+        const int sl = lane;
+        float* xr = big + sl * XS;
+        const int J = nf + 3;
+        const int b0 = nf, b1 = b0 + 3, b2 = b1 + nf * pef, b3 = b2 + nf * pef, b4 = b3 + 3 * pev, b5 = b4 + 3 * pev;
+        for (int j = wave; j < J; j += 8) {                              // (wave-uniform j: no divergence between the feature and direction forms)
+            if (j < nf) {
+                const float v = ft[sl * AF_FT + j];
+                xr[j] = v;
+                for (int p = 0; p < pef; ++p) {
+                    float sn, cs;
+                    if (AF_ABL & 4) { sn = v; cs = v + 1.f; } else
+                    sincosf(v * (float)(1 << p), &sn, &cs);
+                    xr[b1 + j * pef + p] = sn;
+                    xr[b2 + j * pef + p] = cs;
+                }
+            } else {
+                const int a = j - nf;
+                const float v = pos[sl * 8 + 4 + a];
+                xr[b0 + a] = v;
+                for (int p = 0; p < pev; ++p) {
+                    float sn, cs;
+                    if (AF_ABL & 4) { sn = v; cs = v + 1.f; } else
+                    sincosf(v * (float)(1 << p), &sn, &cs);
+                    xr[b3 + a * pev + p] = sn;
+                    xr[b4 + a * pev + p] = cs;
+                }
+            }
+        }
+        for (int c = b5 + wave; c < ldx; c += 8) xr[c] = 0.f;           // alignment padding of the GEMM operand row stays zero
+    }
+    __syncthreads();
+    // ---------------- phase 4
+    for (int r = wave; r < ((AF_ABL & 8) ? 1 : rows); r += 8) {
+        float* dst = X + (size_t)(s0 + r) * ldx;
+        const float* src = big + r * XS;
+        for (int c = lane; c < ldx; c += 64) dst[c] = src[c];
+    }
+}
+
+extern "C" int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
+                                   int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, float* X,
+                                   int ldx, float* F, clift_stream_t s) {
+    const int C = h_app->comps, nc = 3 * C;
+    CLIFT_REQUIRE(C == 16 || C == 32 || C == 48, "clift_app_front_fwd: comps must be 16, 32 or 48 (got %d)", C);
+    CLIFT_REQUIRE(nf >= 1 && nf <= AF_NF && ldf == AF_NF, "clift_app_front_fwd: 1 <= n_features <= %d, ldf == %d", AF_NF, AF_NF);
+    CLIFT_REQUIRE(pe_feat >= 1 && pe_view >= 1, "clift_app_front_fwd: pe_feat/pe_view must be >= 1");
+    CLIFT_REQUIRE(ldx % 4 == 0 && ldx >= nf + 3 + 2 * pe_feat * nf + 2 * pe_view * 3, "clift_app_front_fwd: ldx %d too small or not a multiple of 4", ldx);
+    CLIFT_REQUIRE(ldb % 4 == 0 && ldb >= nc && (((uintptr_t)Wb) & 15) == 0, "clift_app_front_fwd: the basis matrix needs 16-byte aligned rows of >= 3 * comps floats");
+    if (M <= 0) return 0;
+    const int fs = 4 * ((nc / 4) | 1), xs = ldx | 1;
+    const int dyn = (AF_TS * 8 + AF_TS * 3 * (int)(sizeof(AfRec) / 4) + AF_TS * (fs > xs ? fs : xs)) * 4;
+    CLIFT_REQUIRE(dyn <= 160 * 1024 - 512, "clift_app_front_fwd: tile does not fit in LDS (ldx %d)", ldx);
+    const dim3 grid(cdiv(M, AF_TS));
+    hipStream_t st = as_stream(s);
+#define CLIFT_AF(CC)                                                                                                                            \
+    do {                                                                                                                                        \
+        if (dyn > 48 * 1024)                                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_front_fwd<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);    \
+        k_app_front_fwd<CC><<<grid, 512, dyn, st>>>(to_dev(h_m), to_dev(h_app), rays, jitter, act_idx, M, Wb, ldb, nf, pe_feat, pe_view, xa,  \
+                                                    feat, X, ldx, F);                                                                           \
+    } while (0)
+    if (C == 48) CLIFT_AF(48);
+    else if (C == 32) CLIFT_AF(32);
+    else CLIFT_AF(16);
+#undef CLIFT_AF
+    return clift_check_launch("clift_app_front_fwd");
 }
 
 // ============================================================================ compositing forward

@@ -177,7 +177,7 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
 // MASK = false (fp32 only): plain dX = dOut W with N = g.N <= 256 output columns (a multiple of 4): the dgrad of the appearance basis
 // (27 -> 144, tensoRF.py:65,127-134), which the tiled kernel ran at 1.4 TB/s.  Waves whose 32 columns lie past N only help with the DMA.
-// WG (fp32, masked, N = 256): the output layer's WEIGHT gradient in the same pass -- gW[c][n] += sum_m dOut[m][c] h[m][n], gb[c] += sum_m dOut[m][c] --
+// WG (fp32, masked, N = 256 or a smaller multiple of 32 -- the 128-wide appearance head; waves past N only help with the DMA): the output layer's WEIGHT gradient in the same pass -- gW[c][n] += sum_m dOut[m][c] h[m][n], gb[c] += sum_m dOut[m][c] --
 // where h IS the mask tensor (the post-ReLU activation): the separate k_wgrad_narrow_stream launch streams the M x 256 activation from
 // memory a second time.  A lane holds its row's 16 mask values; the wave turns its 32 x 32 block through a private padded LDS buffer
 // (4 ds_write_b128, 16 ds_read_b32 per lane) so that rows become the MFMA reduction index, reads dOut column-wise from the tile that is
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 #pragma unroll
             for (int q = 0; q < 4; ++q) { mk[q] = nk[q]; mh[q] = nh[q]; }
         }
-        if (WG) {
+        if (WG && wave_on) {
             // the wave's 32 x 32 block of h: row-per-lane registers -> LDS [row][36] -> column-per-lane registers (rows 2 s + lh)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 8 * (r >> 2) + 4 * lh + (r & 3);
-            if (c < no) unsafeAtomicAdd(gW + (size_t)c * ldgw + 32 * wave + li, accw[r]);
+            if (c < no && wave_on) unsafeAtomicAdd(gW + (size_t)c * ldgw + 32 * wave + li, accw[r]);
         }
         if (gb && wave == 0) {       // every wave read the same dOut; wave 0 folds the two row parities and adds the bias gradient
             const unsigned u = __float_as_uint(bsum);
@@ -383,12 +383,19 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 // W (no, 256) pitch ldw, H (M, 256) pitch ldh, dX (M, 256) pitch ldx; no <= ldd <= 32, ldd % 4 == 0, M >= 1, 16-byte-aligned rows.
 extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
                                    float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s) {
+    return clift_out_layer_bwd_nh(dOut, ldd, no, W, ldw, H, ldh, 256, M, dX, ldx, gW, ldgw, gb, s);
+}
+
+// The same over a hidden layer of nh <= 256 units, nh % 32 == 0 (ABI 16: the 128-wide appearance head, tensoRF.py:393-397 backward).
+extern "C" int clift_out_layer_bwd_nh(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int nh, int M,
+                                      float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s) {
     if (M <= 0) return 0;
     CLIFT_REQUIRE(no >= 1 && no <= ldd && ldd <= 32 && ldd % 4 == 0, "clift_out_layer_bwd: need no <= ldd <= 32, ldd %% 4 == 0 (got no=%d ldd=%d)", no, ldd);
-    CLIFT_REQUIRE(ldh % 4 == 0 && ldx % 4 == 0 && ldh >= 256 && ldx >= 256 && ldw >= 256 && ldgw >= 256 && (((uintptr_t)dOut) & 15) == 0 &&
-                  (((uintptr_t)H) & 15) == 0 && (((uintptr_t)dX) & 15) == 0, "clift_out_layer_bwd: 16-byte aligned rows with pitches >= 256 required");
+    CLIFT_REQUIRE(nh >= 32 && nh <= 256 && nh % 32 == 0, "clift_out_layer_bwd: hidden width must be a multiple of 32 in [32, 256] (got %d)", nh);
+    CLIFT_REQUIRE(ldh % 4 == 0 && ldx % 4 == 0 && ldh >= nh && ldx >= nh && ldw >= nh && ldgw >= nh && (((uintptr_t)dOut) & 15) == 0 &&
+                  (((uintptr_t)H) & 15) == 0 && (((uintptr_t)dX) & 15) == 0, "clift_out_layer_bwd: 16-byte aligned rows with pitches >= the hidden width required");
     GemmP p = {};
-    p.M = M; p.N = 256; p.K = no; p.A = dOut; p.lda = ldd; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx; p.mask = H; p.ldmask = ldh;
+    p.M = M; p.N = nh; p.K = no; p.A = dOut; p.lda = ldd; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx; p.mask = H; p.ldmask = ldh;
     const int tiles = cdiv(M, 32);
     const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
     const int rpb = cdiv(cdiv(M, blocks), 32) * 32;

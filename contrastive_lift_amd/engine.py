@@ -307,8 +307,19 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
 # the independent tiled kernels for every layer instead (the cross-check the tests use).
 APP_SCATTER_XA = True       # tests clear it: clift_app_gather_bwd without the forward's positions (xa = NULL: the lane-per-(plane, channel) walk)
 DENS_BWD_SIGMA = True       # tests clear it: clift_density_bwd without the forward's sigma (sigma = NULL: the softplus derivative re-summed)
+APP_OUT_BWD_FUSED = True    # tests clear it: the appearance output layer's weight gradient and masked input gradient as two passes over the hidden activation
+# basis Linear's backward inside the table-scatter walk (clift_app_gather_bwd_basis): correct and tested, but its 56 FMAs per lane and step make the
+# walk VALU-bound -- 300 us against 179 + 58 + 51 us of the three launches at the bench shape (profiles/r04_ab_app_front.txt) -- so it is OFF
+APP_BWD_BASIS_FUSED = False
+APP_FRONT_FUSED = True      # tests clear it: appearance gather, basis GEMM and input encoding as three launches (the form the fused front end replaced)
 KEEP_FIRST_ACT = False      # tests set this to compare against the stored-activation backward (masked dgrad + K = 3 weight gradient)
 FUSE_HEAD_BF16 = True       # bf16 mode: first three layers (+ E <= 4 output layer) of an xyz head in one launch; tests clear it to compare with the per-layer launches
+
+
+def app_bwd_basis_fused(ctx, va, ldf, nf):
+    """Does the appearance backward of this context run the basis Linear's backward inside the scatter walk (clift_app_gather_bwd_basis)?
+    Then the forward need not have kept the plane x line products."""
+    return (APP_BWD_BASIS_FUSED and APP_SCATTER_XA and va.comps <= 64 and ldf == 28 and nf <= 28 and os.environ.get("CLIFT_NO_PERSISTENT") is None)
 
 
 def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
@@ -635,11 +646,27 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
     if M > 0:
         xa = torch.empty((M, 4), dtype=torch.float32, device=dev)
         ctx.xa = xa
+        front = None
         if want_rgb:       # the gather also produces xa, which every other head reads: it stays on the main stream
             va = vm_struct(views, "appearance", ctx.res)
             nc = 3 * va.comps
-            F = torch.empty((M, nc), dtype=torch.float32, device=dev)
-            call("clift_app_gather_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(F), ptr(xa), st)
+            Wb = views["appearance_basis_mat.weight"]
+            W1 = views["render_appearance_mlp.mlp.0.weight"]
+            nf, ldx = Wb.shape[0], _pitch(W1)
+            if (APP_FRONT_FUSED and nf <= 28 and va.comps in (16, 32, 48) and Wb.shape[1] == nc and _pitch(Wb) % 4 == 0 and ldx % 4 == 0 and ldx <= 512
+                    and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+                # the appearance front end as one launch: gather -> basis -> MLP input rows (the products are written only for a backward)
+                ldf = 28
+                F = (torch.empty((M, nc), dtype=torch.float32, device=dev)
+                     if ("app" in grad_heads and not app_bwd_basis_fused(None, va, ldf, nf)) else None)
+                feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
+                X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
+                call("clift_app_front_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(Wb), _pitch(Wb), nf,
+                     model.pe_feat, model.pe_view, ptr(xa), ptr(feat), ldf, ptr(X), ldx, ptr(F), st)
+                front = (feat, ldf, X)
+            else:
+                F = torch.empty((M, nc), dtype=torch.float32, device=dev)
+                call("clift_app_gather_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(F), ptr(xa), st)
             ctx.F = F
         else:
             call("clift_active_xyz", C.byref(ctx.ms), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(xa), st)
@@ -651,15 +678,18 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
         def _app_chain_fwd(keep):
             Wb = views["appearance_basis_mat.weight"]
             nf, nc = Wb.shape
-            ldf = (nf + 3) // 4 * 4
-            feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-            gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
             (W1, b1), (W2, b2), (W3, b3) = _lin_params(None, "render_appearance_mlp.mlp", views)
             ldx = _pitch(W1)
             hdt = act_dtype() if ldx % 8 == 0 else torch.float32      # bf16 mode: encoded input and hidden activations bf16-stored
-            X = torch.empty((M, ldx), dtype=hdt, device=dev)
-            call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
-                 ptr(X), ldx, int(hdt == torch.bfloat16), stream())
+            if front is not None:
+                feat, ldf, X = front
+            else:
+                ldf = (nf + 3) // 4 * 4
+                feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
+                gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
+                X = torch.empty((M, ldx), dtype=hdt, device=dev)
+                call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
+                     ptr(X), ldx, int(hdt == torch.bfloat16), stream())
             H1 = torch.empty((M, W1.shape[0]), dtype=hdt, device=dev)
             gemm(M, W1.shape[0], ldx, X, ldx, W1, ldx, H1, H1.shape[1], bias=b1, act=1)
             rgb_s = torch.empty((M, 3), dtype=torch.float32, device=dev)
@@ -783,9 +813,15 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, stream())
             H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
             n2 = W3.shape[1]
-            wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
             dH2 = torch.empty((M, n2), dtype=H2.dtype, device=dev)
-            gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
+            if (APP_OUT_BWD_FUSED and H2.dtype == torch.float32 and n2 % 32 == 0 and n2 <= 256 and W3.shape[0] <= 4 and M >= 4096
+                    and _pitch(W3) >= n2 and _pitch(gW3) >= n2 and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+                # output layer: weight gradient and masked input gradient in one pass over the hidden activation (as in the xyz heads)
+                call("clift_out_layer_bwd_nh", ptr(dpre), 4, W3.shape[0], ptr(W3), _pitch(W3), ptr(H2), n2, n2, M, ptr(dH2), n2, ptr(gW3), _pitch(gW3),
+                     ptr(gb3), stream())
+            else:
+                wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
+                gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
             n1 = W2.shape[1]
             wgrad(n2, n1, M, dH2, n2, H1, n1, gW2, gb2)
             dH1 = torch.empty((M, n1), dtype=H1.dtype, device=dev)
@@ -798,13 +834,19 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
-            call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
-            dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
-            gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
-            call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
+            if app_bwd_basis_fused(ctx, va, ldf, nf):
+                # the basis Linear's backward (weight gradient and 27 -> 144 input gradient) inside the scatter walk: neither dF nor F exists
+                call("clift_app_gather_bwd_basis", C.byref(va), C.byref(ga), M, ptr(dfeat), ldf, nf, ptr(Wb), _pitch(Wb), ptr(gWb), _pitch(gWb),
+                     ptr(ctx.xa), stream())
+                dF = None
+            else:
+                call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
+                dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
+                gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
+                call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
+                     ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 

@@ -177,6 +177,21 @@ int clift_app_encode_fwd(const float* feat, int ldf, int nf, int pe_feat, int pe
                          const int* act_idx, int S, int M, float* X, int ldx, int x_bf16 /* X is bf16-stored */, clift_stream_t s);
 int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const float* dX, int ldx, int M,
                          float* dfeat, int lddf, clift_stream_t s);
+/* The appearance head's front end in ONE launch (ABI 16): clift_app_gather_fwd, the basis Linear (tensoRF.py:65,127-134: feat = F Wb^T,
+ * Wb (nf, 3*comps) with row pitch ldb, no bias) and clift_app_encode_fwd for tiles of 64 active samples, the products and the features
+ * staying on the CU.  Writes xa (M, 4; nullable), feat (M, ldf; pad columns zero -- the encode backward reads it), X (M, ldx) fp32 and --
+ * only when F is not NULL (a backward pass will want the products) -- F (M, 3*comps).  feat_j is one fmaf chain over k = 0 .. 3*comps-1
+ * (fp32 round-off apart from the matrix-core GEMM of the unfused path).  nf <= 28, nf <= ldf <= 28, ldx % 4 == 0, ldb % 4 == 0. */
+/* Backward of the appearance gather AND of the basis Linear in one launch (ABI 16; needs the forward's xa, comps <= 64): dfeat (M, 28) is the
+ * gradient of the basis Linear's output (pad columns zero, as clift_app_encode_bwd writes it), Wb (nf, 3*comps) the basis matrix.  A lane of
+ * the scatter walk forms dF[s][c] = sum_j dfeat[s][j] Wb[j][c] itself (fmaf chain over j) and, holding F[s][c] = plane x line of its step, adds
+ * dfeat[s][j] F[s][c] into the basis matrix's gradient gWb (nf, ldg) += dfeat^T F.  Replaces clift_wgrad_narrow over the stored products, the
+ * 27 -> 144 dgrad GEMM and clift_app_gather_bwd; the table gradients are the same per-sample terms in the same walk order. */
+int clift_app_gather_bwd_basis(const clift_vm_t* h_app, const clift_vm_grad_t* h_grad, int M, const float* dfeat, int lddf, int nf,
+                               const float* Wb, int ldb, float* gWb, int ldg, const float* xa, clift_stream_t s);
+int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
+                        int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, float* X,
+                        int ldx, float* F, clift_stream_t s);
 
 /* ---- nn.Linear building block on the matrix cores (tensoRF.py:65,393-397,475-491,576-582 and their
  * backward).  C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] ) * (mask[m][n] > 0)
@@ -227,6 +242,10 @@ long clift_sign_bits_bytes(int M);
  * one masked clift_gemm(b_trans) call, which each stream H from memory. */
 int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
                         float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
+/* ... over a hidden layer of nh units, nh % 32 == 0, nh <= 256 (ABI 16: the 128-wide appearance head, tensoRF.py:393-397 backward; its
+ * dOut is the gradient of the pre-sigmoid colours, (M, 4) with a zero pad column).  Pitches >= nh. */
+int clift_out_layer_bwd_nh(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int nh, int M,
+                           float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
 /* Forward of a narrow output layer over a 256-wide hidden activation, with the row activation that follows it, in ONE pass over H (ABI 15;
  * tensoRF.py:591-594 with :37 for the semantic head):  out[m][0..no) = act( H[m][0..256) W^T + b ),  no <= 32, act 0 = none, 2 = softmax over
  * the row.  H (M, ldh) fp32, W (no, 256) pitch ldw, b (no), out (M, ldo) -- columns [no, ldo) untouched.  Replaces clift_gemm (which streams H at

@@ -1,0 +1,183 @@
+"""Round 4, second half: the appearance head's front end as one launch each way (ABI 16).
+
+Reference: model/radiance_field/tensoRF.py:127-137 (plane x line products, basis Linear) and :400-418 (MLP input assembly with the
+positional encodings); model/renderer/panopli_tensoRF_renderer.py:103-110 (the call site on the active samples).
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import DEV, _import, build_model, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_ctx(fused, n_rays=700, res=(40, 48, 56), grad=True, cap=None, seed=31, bwd_basis=False):
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd import engine
+    C_, E = 5, 3
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, seed, res, C_, E, n_rays, amp=2.2, sg=0.4)
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    m = build_model(cl, P, res, C_, E, -3.0, "softmax")
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    prev = engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED
+    engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED = fused, bwd_basis      # (bwd_basis False: the forward keeps the products for the backward)
+    try:
+        out, ctx = engine.render_forward(m, r, rays.to(DEV), jitter.to(DEV), False, grad_heads=("app", "sem") if grad else (), cap=cap)
+        torch.cuda.synchronize()
+    finally:
+        engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED = prev
+        engine.reset_rows_limit(torch.device(DEV, torch.cuda.current_device()))
+    return m, out, ctx
+
+
+@pytest.mark.parametrize("n_rays", [3, 700, 2500])
+def test_app_front_fwd_against_the_three_launches_and_fp64(n_rays):
+    """clift_app_front_fwd = gather + basis Linear + input encoding: positions and products bit-identical to clift_app_gather_fwd, features within
+    fp32 round-off of float64 (fp32 matrix cores, two k halves; the unfused GEMM is held to the same bound), the encoded rows within the sine's
+    conditioning of that, pad columns zero, rendered colours equal to 1e-5."""
+    m, o_f, c_f = _render_ctx(True, n_rays)
+    _, o_u, c_u = _render_ctx(False, n_rays)
+    M = c_f.M
+    assert M == c_u.M and M > 0 and (n_rays < 100 or M % 64 != 0)
+    assert torch.equal(c_f.xa, c_u.xa)
+    assert torch.equal(c_f.F, c_u.F)
+    Wb = m.named_views()["appearance_basis_mat.weight"]
+    F64 = c_u.F.double().cpu()
+    ref = F64 @ Wb.double().cpu().t()
+    scale = (F64.abs() @ Wb.double().cpu().abs().t()).clamp_min(1e-30)
+    nf = Wb.shape[0]
+    for c in (c_f, c_u):
+        err = ((c.feat[:, :nf].double().cpu() - ref).abs() / scale).max()
+        assert float(err) <= 1e-6, float(err)
+    assert bool((c_f.feat[:, nf:] == 0).all())
+    assert c_f.X.shape == c_u.X.shape and c_f.ldx == c_u.ldx
+    # |d sin(2 f)| <= 2 |d f|: the encodings differ by at most twice the features' difference (+ one rounding)
+    df = float((c_f.feat[:, :nf] - c_u.feat[:, :nf]).abs().max())
+    assert float((c_f.X - c_u.X).abs().max()) <= 2 * df + 2e-7
+    b5 = nf + 3 + 4 * nf + 12
+    assert bool((c_f.X[:, b5:] == 0).all())
+    assert float((o_f["rgb"] - o_u["rgb"]).abs().max()) <= 1e-5
+    assert torch.equal(o_f["depth"], o_u["depth"])
+
+
+def test_app_front_fwd_without_products_row_limit_and_bad_arguments():
+    """No backward wanted: the products are not written (ctx.F is None) and the colours are the same; under a device-side row limit (sync-free
+    step: buffers sized by a capacity) rows past the true count are not touched; argument checks raise."""
+    from contrastive_lift_amd import _lib, engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    import ctypes as C
+    m, o_g, c_g = _render_ctx(True, 700, grad=True)
+    _, o_n, c_n = _render_ctx(True, 700, grad=False)
+    assert c_n.F is None and c_g.F is not None
+    assert torch.equal(o_g["rgb"], o_n["rgb"])
+    # capped: same rows, the tail of the capacity-sized buffers untouched
+    cap = c_g.M + 777
+    _, o_c, c_c = _render_ctx(True, 700, grad=True, cap=cap)
+    assert torch.equal(o_c["rgb"], o_g["rgb"])
+    assert torch.equal(c_c.X[:c_g.M], c_g.X) and torch.equal(c_c.feat[:c_g.M], c_g.feat) and torch.equal(c_c.F[:c_g.M], c_g.F)
+    # direct call on poisoned buffers under a limit
+    views = m.named_views()
+    va = engine.vm_struct(views, "appearance", c_g.res)
+    Wb = views["appearance_basis_mat.weight"]
+    nf, ldx = Wb.shape[0], c_g.ldx
+    Mtrue = c_g.M
+    X = torch.full((cap, ldx), -3.0, device=DEV); feat = torch.full((cap, 28), -3.0, device=DEV); xa = torch.full((cap, 4), -3.0, device=DEV)
+    act = torch.zeros(cap, dtype=torch.int32, device=DEV); act[:Mtrue] = c_g.act_idx[:Mtrue]
+    lim = engine.rows_limit(X.device)
+    lim[0:1].fill_(Mtrue)
+    try:
+        call("clift_app_front_fwd", C.byref(c_g.ms), C.byref(va), ptr(c_g.rays), ptr(c_g.jitter), ptr(act), cap, ptr(Wb), engine._pitch(Wb), nf,
+             m.pe_feat, m.pe_view, ptr(xa), ptr(feat), 28, ptr(X), ldx, None, stream())
+        torch.cuda.synchronize()
+    finally:
+        engine.reset_rows_limit(X.device)
+    assert bool((X[Mtrue:] == -3.0).all()) and bool((feat[Mtrue:] == -3.0).all()) and bool((xa[Mtrue:] == -3.0).all())
+    assert torch.equal(X[:Mtrue], c_g.X) and torch.equal(xa[:Mtrue], c_g.xa)
+    with pytest.raises(_lib.CliftError, match="n_features"):
+        call("clift_app_front_fwd", C.byref(c_g.ms), C.byref(va), ptr(c_g.rays), ptr(c_g.jitter), ptr(act), 10, ptr(Wb), engine._pitch(Wb), 29,
+             m.pe_feat, m.pe_view, ptr(xa), ptr(feat), 28, ptr(X), ldx, None, stream())
+    with pytest.raises(_lib.CliftError, match="ldx"):
+        call("clift_app_front_fwd", C.byref(c_g.ms), C.byref(va), ptr(c_g.rays), ptr(c_g.jitter), ptr(act), 10, ptr(Wb), engine._pitch(Wb), nf,
+             m.pe_feat, m.pe_view, ptr(xa), ptr(feat), 28, ptr(X), 100, None, stream())
+
+
+def _app_backward(fused_bwd, n_rays=700, res=(40, 48, 56), seed=31):
+    """Gradients of sum(rgb * cot) through the appearance head with the basis backward inside the scatter walk (True) or as separate launches."""
+    from contrastive_lift_amd import engine
+    m, out, ctx = _render_ctx(True, n_rays, res, seed=seed, bwd_basis=fused_bwd)
+    assert (ctx.F is None) == fused_bwd
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(out["rgb"].shape, generator=g).to(DEV)
+    m.zero_grad_arena()
+    gv = m.named_grad_views()
+    prev = engine.APP_BWD_BASIS_FUSED
+    engine.APP_BWD_BASIS_FUSED = fused_bwd
+    try:
+        engine.render_backward(m, ctx, gv, g_rgb=cot, density_grad=False)
+        torch.cuda.synchronize()
+    finally:
+        engine.APP_BWD_BASIS_FUSED = prev
+    keys = ["appearance_basis_mat.weight"] + [f"appearance_plane.{i}" for i in range(3)] + [f"appearance_line.{i}" for i in range(3)] + \
+           ["render_appearance_mlp.mlp.0.weight", "render_appearance_mlp.mlp.4.weight", "render_appearance_mlp.mlp.4.bias", "render_appearance_mlp.mlp.2.weight"]
+    return m, ctx, cot, {k: gv[k].detach().clone() for k in keys}
+
+
+@pytest.mark.parametrize("n_rays,res", [(3, (40, 48, 56)), (700, (40, 48, 56)), (2500, (40, 48, 56)), (900, (128, 128, 128))])
+def test_app_gather_bwd_basis_against_the_separate_launches(n_rays, res):
+    """clift_app_gather_bwd_basis = basis weight gradient + 27 -> 144 dgrad + table scatter in one walk, against the three separate launches: the
+    basis matrix's gradient and the table gradients to fp32 summation round-off (1e-4 relative + 2e-6 of
+    the tensor's scale, no outliers allowed)."""
+    from conftest import grad_close
+    m, ctx, cot, g_f = _app_backward(True, n_rays, res)
+    _, _, _, g_u = _app_backward(False, n_rays, res)
+    for k in g_f:
+        grad_close(g_f[k].cpu(), g_u[k].cpu(), what=k, rtol=1e-4, scale_atol=2e-6, outlier_frac=0.0, outlier_cap=1e-4)
+    assert float(g_f["appearance_basis_mat.weight"].abs().max()) > 0 and float(g_f["appearance_plane.1"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,no,ldd,nh", [(4096, 3, 4, 128), (4099, 3, 4, 128), (249003, 3, 4, 128), (33, 3, 4, 128), (5000, 22, 24, 32), (8191, 6, 8, 224)])
+def test_output_layer_backward_in_one_pass_over_a_narrower_hidden_layer(M, no, ldd, nh):
+    """clift_out_layer_bwd_nh (the appearance head: 128 hidden units, 3 outputs): dX = (H > 0) . (dOut W), gW += dOut^T H, gb += column sums of
+    dOut from ONE pass over H, against fp64 -- accumulating onto existing gW / gb, ragged row counts, padded pitches whose pad columns stay
+    untouched (the waves past the hidden width must neither store nor add)."""
+    from conftest import rel_close
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + no + nh)
+    dOut = torch.zeros((M, ldd))
+    dOut[:, :no] = torch.randn((M, no), generator=g)
+    W = torch.randn((no, nh), generator=g) * 0.1
+    H = torch.relu(torch.randn((M, nh), generator=g))
+    ldh, ldw = nh + 4, nh + 8
+    Hd = torch.full((M, ldh), float("nan"), device=DEV); Hd[:, :nh] = H.to(DEV)
+    Wd = torch.full((no, ldw), float("nan"), device=DEV); Wd[:, :nh] = W.to(DEV)
+    dX = torch.full((M, ldh), -7.0, device=DEV)
+    gW = torch.full((no, ldw), 0.25, device=DEV)
+    gb = torch.full((no,), -1.0, device=DEV)
+    engine.call("clift_out_layer_bwd_nh", engine.ptr(dOut.to(DEV)), ldd, no, engine.ptr(Wd), ldw, engine.ptr(Hd), ldh, nh, M, engine.ptr(dX), ldh,
+                engine.ptr(gW), ldw, engine.ptr(gb), engine.stream())
+    torch.cuda.synchronize()
+    ref_dx = (dOut[:, :no].double() @ W.double()) * (H > 0)
+    ref_w = dOut[:, :no].double().T @ H.double() + 0.25
+    ref_b = dOut[:, :no].double().sum(0) - 1.0
+    rel_close(dX[:, :nh], ref_dx, 2e-5, atol=2e-5 * float(ref_dx.abs().max()), what="fused dX")
+    rel_close(gW[:, :nh], ref_w, 2e-5, atol=2e-5 * float(ref_w.abs().max()), what="fused gW")
+    rel_close(gb, ref_b, 2e-5, atol=2e-5 * M ** 0.5, what="fused gb")
+    assert bool((dX[:, nh:] == -7.0).all()) and bool((gW[:, nh:] == 0.25).all())
+
+
+def test_appearance_output_layer_backward_fused_matches_the_two_passes():
+    """The appearance chain with clift_out_layer_bwd_nh against the weight-gradient + masked-dgrad pair, through render_backward."""
+    from conftest import grad_close
+    from contrastive_lift_amd import engine
+    outs = []
+    for fused in (True, False):
+        prev = engine.APP_OUT_BWD_FUSED
+        engine.APP_OUT_BWD_FUSED = fused
+        try:
+            outs.append(_app_backward(False, 2500)[3])
+        finally:
+            engine.APP_OUT_BWD_FUSED = prev
+    for k in outs[0]:
+        grad_close(outs[0][k].cpu(), outs[1][k].cpu(), what=k, rtol=1e-4, scale_atol=2e-6, outlier_frac=0.0, outlier_cap=1e-4)
