@@ -94,7 +94,6 @@ _SIGNATURES = {
     "clift_app_gather_bwd": ([_P, _P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "clift_app_encode_fwd": ([_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_app_encode_bwd": ([_P, _I, _I, _I, _P, _I, _I, _P, _I, _P], C.c_int),
-    "clift_app_gather_bwd_basis": ([_P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_app_front_fwd": ([_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_gemm": ([_P, _P], C.c_int),
     "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P], C.c_int),
@@ -106,6 +105,8 @@ _SIGNATURES = {
     "clift_composite_fwd": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], C.c_int),
     "clift_composite_bwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P,
                              _P, _P, _P], C.c_int),
+    "clift_composite_bwd_act": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P],
+                                C.c_int),
     "clift_tv_fwd_bwd": ([_P, _I, _I, _I, _F, _P, _P, _P], C.c_int),
     "clift_tv_fwd_bwd_multi": ([_P, _P, _P], C.c_int),
     "clift_pixel_losses": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),

@@ -245,46 +245,9 @@ struct alignas(16) WalkRec {
     int pad[3];
 };
 
-// BASIS (ABI 16): the gradient arrives as dfeat (M, lddf <= 28: the gradient of the basis Linear's OUTPUT, tensoRF.py:65,134) instead of dF, and
-// the basis Linear's backward runs inside the walk: a lane (= one channel of one plane) keeps its column of Wb (28 registers) and forms
-// dF = sum_j dfeat[s][j] Wb[j][c] itself -- the dfeat row of a step is wave-uniform: scalar loads, one SGPR operand per FMA --, and since it also
-// holds the product P L = F[s][c] of the step it adds dfeat[s][j] F[s][c] into 28 running sums: the weight gradient of the basis matrix, folded
-// over the block's waves in LDS and added to memory once per block.  Every wave then keeps ONE plane for the whole launch (items strided by a
-// multiple of 3).  Neither dF (M x 144 floats written by a GEMM and read here) nor F (written by the forward, read by a weight-gradient launch)
-// exists any more.
-constexpr int AB_NF = 28;
-// one row of dfeat (28 floats, wave-uniform address) into SGPRs.  Inline asm: with the atomics in the kernel the compiler does not prove the row
-// unclobbered and loads it per lane (28 VGPRs per step: the kernel spilled).
-typedef float f32x8s __attribute__((ext_vector_type(8)));
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-struct DfRow { f32x8s a, b, c; f32x4s d; };
-// issue / wait as two statements: the row of the NEXT step is requested before the current step's FMAs and awaited after them.  Between the two
-// the registers are named only as outputs of the first and in-outs of the second, so the compiler has no value to read early.
-// `seed` (in-out of the issue) and `done` (inputs of the wait) are values of the FMA chains that are to run between the two: the compiler may move
-// arithmetic across an asm statement, and without them it scheduled every FMA of the step outside the issue .. wait window.
-// `lds0` / `lds1`: values of the step's LDS reads -- the issue must come after their wait, or that wait (same counter) waits for the row as well.
-__device__ __forceinline__ void sload_row28_issue(DfRow& r, const float* p, float& seed0, float& seed1, float lds0, float lds1) {
-    asm volatile("s_load_dwordx8 %0, %6, 0x0\n\ts_load_dwordx8 %1, %6, 0x20\n\ts_load_dwordx8 %2, %6, 0x40\n\ts_load_dwordx4 %3, %6, 0x60"
-                 : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c), "=&s"(r.d), "+v"(seed0), "+v"(seed1) : "s"(p), "v"(lds0), "v"(lds1) : "memory");
-}
-__device__ __forceinline__ void sload_row28_wait(DfRow& r, const float (&g)[28]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c), "+s"(r.d)
-                 : "v"(g[0]), "v"(g[2]), "v"(g[4]), "v"(g[6]), "v"(g[8]), "v"(g[10]), "v"(g[12]), "v"(g[14]), "v"(g[16]), "v"(g[18]), "v"(g[20]), "v"(g[22]),
-                   "v"(g[24]), "v"(g[26]) : "memory");
-}
-__device__ __forceinline__ void sload_row28_now(DfRow& r, const float* p) {
-    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx4 %3, %4, 0x60\n\t"
-                 "s_waitcnt lgkmcnt(0)" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c), "=&s"(r.d) : "s"(p) : "memory");
-}
-__device__ __forceinline__ float dfrow_at(const DfRow& r, int j) { return j < 8 ? r.a[j] : j < 16 ? r.b[j - 8] : j < 24 ? r.c[j - 16] : r.d[j - 24]; }
-constexpr int AB_THREADS = 1024;
-constexpr int AB_U = 2;                // (the 56 registers of the basis column and its gradient leave room for two steps' loads)
-template <bool LDS_LINES, bool BASIS = false>
-__global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
-                                                              int seg_len, const float* __restrict__ dfeat = nullptr, int lddf = 0, int nf = 0,
-                                                              const float* __restrict__ Wb = nullptr, int ldb = 0, float* __restrict__ gWb = nullptr,
-                                                              int ldg = 0) {
-    constexpr int UU = BASIS ? AB_U : AU_U;              // steps whose loads are issued together
+template <bool LDS_LINES>
+__global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
+                                                              int seg_len) {
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     const int nl = LDS_LINES ? line_lds_floats(t.res, t.comps) : 0;
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
@@ -297,22 +260,12 @@ __global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(
     const bool live = lane < C;
     M = limit_rows(M);
     const long items = 3L * ((M + seg_len - 1) / seg_len);
-    const long tw = (long)gridDim.x * nwaves;
-    const long stride = BASIS ? tw / 3 * 3 : tw;                 // BASIS: a multiple of 3 -- (item % 3), the plane, never changes for a wave
-    const long first = (long)blockIdx.x * nwaves + wave;
-    float wb[AB_NF], gacc[AB_NF];
-    if (BASIS) {
-        const int ib = (int)(first % 3);
-#pragma unroll
-        for (int j = 0; j < AB_NF; ++j) { wb[j] = j < nf ? Wb[(size_t)j * ldb + ib * C + c] : 0.f; gacc[j] = 0.f; }
-    }
-    for (long it = (BASIS && first >= stride) ? items : first; it < items; it += stride) {
+    for (long it = (long)blockIdx.x * nwaves + wave; it < items; it += (long)gridDim.x * nwaves) {
         const int seg = (int)(it / 3), i = (int)(it - 3L * seg);
         int a, b, v;
         vm_axes(i, a, b, v);
         const int W = t.res[a];
-        const int s0 = BASIS ? __builtin_amdgcn_readfirstlane(seg * seg_len) : seg * seg_len;
-        const int n = BASIS ? __builtin_amdgcn_readfirstlane(min(seg_len, M - s0)) : min(seg_len, M - s0);     // (the scalar row registers must not cross a branch the compiler takes for divergent)
+        const int s0 = seg * seg_len, n = min(seg_len, M - s0);
         // ---------------- phase 1
         {
             const int p = lane;
@@ -367,7 +320,7 @@ __global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(
         float* gp = gr.plane[i] + xoff;
         float* ll = lds_lines + line_lds_offset(t, i);
         float* gl = gr.line[i] + xoff;
-        const float* dcol = BASIS ? nullptr : dF + (size_t)s0 * G + i * C + c;
+        const float* dcol = dF + (size_t)s0 * G + i * C + c;
         const int c4 = 4 * c;
         auto at = [](auto* base, int off) {            // (pointer arithmetic, not integer casts: the address space must stay visible)
             typedef typename std::conditional<std::is_const<typename std::remove_pointer<decltype(base)>::type>::value, const char, char>::type B;
@@ -386,29 +339,25 @@ __global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(
         };
         int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
         float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
-        DfRow cur;
-        if (BASIS) {
-            sload_row28_now(cur, dfeat + (size_t)__builtin_amdgcn_readfirstlane(s0) * lddf);
-        }
-        for (int p0 = 0; p0 < n; p0 += UU) {
-            int4 kq[UU];
-            int2 kzz[UU];
-            float tv[UU][4], tl[UU][2], td[UU];
+        for (int p0 = 0; p0 < n; p0 += AU_U) {
+            int4 kq[AU_U];
+            int2 kzz[AU_U];
+            float tv[AU_U][4], tl[AU_U][2], td[AU_U];
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
+            for (int u = 0; u < AU_U; ++u) {
                 const int4* src = reinterpret_cast<const int4*>(recs + min(p0 + u, n - 1));
                 kq[u] = src[0];
                 kzz[u] = *reinterpret_cast<const int2*>(src + 2);
             }
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
+            for (int u = 0; u < AU_U; ++u) {
                 tv[u][0] = *at(pp, max(kq[u].x, 0) + c4); tv[u][1] = *at(pp, max(kq[u].y, 0) + c4);
                 tv[u][2] = *at(pp, max(kq[u].z, 0) + c4); tv[u][3] = *at(pp, max(kq[u].w, 0) + c4);
                 tl[u][0] = *at(lp, max(kzz[u].x, 0) + c4); tl[u][1] = *at(lp, max(kzz[u].y, 0) + c4);
-                if (!BASIS) td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
+                td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
             }
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
+            for (int u = 0; u < AU_U; ++u) {
                 if (p0 + u >= n) break;                                        // uniform
                 const int4* src = reinterpret_cast<const int4*>(recs + (p0 + u));
                 const int4 r1 = src[1], r2 = src[2];
@@ -428,34 +377,14 @@ __global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(
                     if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
                     lk[sl] = kz[sl];
                 }
-                DfRow nx;
-                float a0 = 0.f, a1 = 0.f;                                      // even / odd j: two chains (packed FMAs)
-                if (BASIS)         // the dfeat row of the NEXT step is on its way while this step's table waits and 56 FMAs run.  (Issued AFTER the step's
-                                   // LDS reads were consumed: scalar loads share their counter, a wait for an LDS read would wait for the row as well)
-                    sload_row28_issue(nx, dfeat + (size_t)__builtin_amdgcn_readfirstlane(s0 + min(p0 + u + 1, n - 1)) * lddf, a0, a1, ws[3], wz[1]);
                 float P = 0.f;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], ks[sl] >= 0 ? tv[u][sl] : 0.f, P);
                 const float L = fmaf(wz[1], kz[1] >= 0 ? tl[u][1] : 0.f, wz[0] * (kz[0] >= 0 ? tl[u][0] : 0.f));
-                float tdv;
-                if (BASIS) {
-#pragma unroll
-                    for (int j = 0; j < AB_NF; j += 2) { a0 = fmaf(dfrow_at(cur, j), wb[j], a0); a1 = fmaf(dfrow_at(cur, j + 1), wb[j + 1], a1); }
-                    tdv = a0 + a1;
-                } else {
-                    tdv = td[u];
-                }
-                const float gP = tdv * L, gL = tdv * P;
+                const float gP = td[u] * L, gL = td[u] * P;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
                 lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
-                if (BASIS) {
-                    const float Fv = P * L;
-#pragma unroll
-                    for (int j = 0; j < AB_NF; ++j) gacc[j] = fmaf(dfrow_at(cur, j), Fv, gacc[j]);
-                    sload_row28_wait(nx, gacc);
-                    cur = nx;
-                }
             }
         }
 #pragma unroll
@@ -465,26 +394,6 @@ __global__ __launch_bounds__(BASIS ? AB_THREADS : 1024) void k_app_gather_bwd_u(
         for (int q = 0; q < 4; ++q)
             if (ck[q] >= 0) plane_out(ck[q], ca[q]);
         __builtin_amdgcn_wave_barrier();               // the next item's phase 1 overwrites the records
-    }
-    if (BASIS) {
-        // the block's waves meet in LDS (over the walk records, which are dead now): gsum[j][plane * C + c], then one atomic per entry and block
-        float* const gsum = lds_lines + (nl + 3) / 4 * 4;
-        const int ng = AB_NF * 3 * C;
-        __syncthreads();
-        for (int e = threadIdx.x; e < ng; e += blockDim.x) gsum[e] = 0.f;
-        __syncthreads();
-        if (live && first < stride) {
-            const int ib = (int)(first % 3);
-#pragma unroll
-            for (int j = 0; j < AB_NF; ++j) atomicAdd(gsum + j * 3 * C + ib * C + c, gacc[j]);
-        }
-        __syncthreads();
-        float* const gdst = grad_target(gWb);
-        for (int e = threadIdx.x; e < nf * 3 * C; e += blockDim.x) {
-            const int j = e / (3 * C), cc = e - j * 3 * C;
-            const float v = gsum[e];
-            if (v != 0.f) unsafeAtomicAdd(gdst + (size_t)j * ldg + cc, v);
-        }
     }
     if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
 }
@@ -531,39 +440,6 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
         k_app_gather_bwd<false><<<blocks, threads, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_app), to_dev(h_grad), rays, jitter, act_idx, M, dF, seg, xa);
     }
     return clift_check_launch("clift_app_gather_bwd");
-}
-
-/* Backward of the appearance gather AND of the basis Linear in one launch (ABI 16): see k_app_gather_bwd_u<.., BASIS>. */
-extern "C" int clift_app_gather_bwd_basis(const clift_vm_t* h_app, const clift_vm_grad_t* h_grad, int M, const float* dfeat, int lddf, int nf,
-                                          const float* Wb, int ldb, float* gWb, int ldg, const float* xa, clift_stream_t s) {
-    CLIFT_REQUIRE(h_app->comps % 4 == 0 && h_app->comps <= 64, "clift_app_gather_bwd_basis: comps must be a multiple of 4, <= 64");
-    CLIFT_REQUIRE(nf >= 1 && nf <= AB_NF && lddf == AB_NF, "clift_app_gather_bwd_basis: n_features <= %d and lddf == %d (pad columns zero) required", AB_NF, AB_NF);
-    CLIFT_REQUIRE(xa != nullptr && dfeat != nullptr && Wb != nullptr && gWb != nullptr, "clift_app_gather_bwd_basis: xa, dfeat, Wb, gWb must not be NULL");
-    CLIFT_REQUIRE(ldb >= 3 * h_app->comps && ldg >= 3 * h_app->comps, "clift_app_gather_bwd_basis: basis pitches smaller than 3 * comps");
-    if (M <= 0) return 0;
-    const int lds_bytes = line_lds_floats(h_app->res, h_app->comps) * 4;
-    const int rec_bytes = AU_SEG * (int)sizeof(WalkRec);
-    const int slab = (lds_bytes + 15) / 16 * 16;
-    const int gsum_bytes = AB_NF * 3 * h_app->comps * 4;                // the end-of-launch fold of the basis gradient lives over the records
-    int wpb = 16, bpc = 1;
-    bool lds_l = true;
-    if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 16; bpc = 2; }
-    else if (2 * (slab + 8 * rec_bytes) <= 160 * 1024 - 1024 && 8 * rec_bytes >= gsum_bytes) { wpb = 8; bpc = 2; }
-    CLIFT_REQUIRE(wpb * rec_bytes >= gsum_bytes, "clift_app_gather_bwd_basis: record area smaller than the basis-gradient fold");
-    const long items = 3L * cdiv(M, AU_SEG);
-    const int want = cdiv(items, wpb);
-    const int blocks = want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc;
-    const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
-    if (lds_l) {
-        if (dyn > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_gather_bwd_u<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-        k_app_gather_bwd_u<true, true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, nullptr, xa, AU_SEG, dfeat, lddf, nf, Wb, ldb,
-                                                                                gWb, ldg);
-    } else {
-        k_app_gather_bwd_u<false, true><<<blocks, wpb * 64, dyn, as_stream(s)>>>(to_dev(h_app), to_dev(h_grad), M, nullptr, xa, AU_SEG, dfeat, lddf, nf, Wb, ldb,
-                                                                                 gWb, ldg);
-    }
-    return clift_check_launch("clift_app_gather_bwd_basis");
 }
 
 // ============================================================================ appearance MLP input
@@ -892,8 +768,22 @@ __global__ __launch_bounds__(256) void k_composite_sum(const float* __restrict__
     else if (c < 3 + C) { src = sem_s; ld = C; cc = c - 3; dst = sem_raw ? sem_raw + (size_t)r * C + cc : nullptr; }
     else { src = inst_s; ld = D; cc = c - 3 - C; dst = inst_map ? inst_map + (size_t)r * D + cc : nullptr; }
     if (!src || !dst) return;
+    // the sum stays sequential (one fmaf chain in sample order), but eight samples' loads are in flight together: the walk is a chain of
+    // dependent loads (act -> w) ~60 long per ray, and one at a time it took 35 us for 1024 rays (41 us for 4096: latency, not work)
     float acc = 0.f;
-    for (int i = start[r], e = start[r + 1]; i < e; ++i) acc = fmaf(w[act[i]], src[(size_t)i * ld + cc], acc);
+    int i = start[r];
+    const int e = start[r + 1];
+    for (; i + 8 <= e; i += 8) {
+        int a[8];
+        float wv[8], sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = act[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wv[u] = w[a[u]]; sv[u] = src[(size_t)(i + u) * ld + cc]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(wv[u], sv[u], acc);
+    }
+    for (; i < e; ++i) acc = fmaf(w[act[i]], src[(size_t)i * ld + cc], acc);
     *dst = acc;
 }
 
@@ -1010,6 +900,79 @@ __global__ __launch_bounds__(256) void k_composite_bwd_sample(const float* __res
         }
     }
     if (g_w) g_w[sid] = gw;
+}
+
+// Stage 2 with the heads' output activations folded in (ABI 16): what leaves is the gradient w.r.t. the PRE-activation outputs of the last
+// layers, in the zero-padded rows their backward kernels take (row pitches ld_*, multiples of 4) -- the separate clift_rows_act_bwd launches (one
+// per head: a read of the head output and of these gradients, a write of the same rows again) are gone.  rgb: sigmoid (d o (1 - o)); semantics:
+// sem_kind 2 = softmax over the row (o (g - <g, o>), the dot product summed in class order), 0 = identity; instances: identity, columns
+// [0, E) to dpre_i0 and [E, 2 E) to dpre_i1 (each nullable: the slow half is detached in training, T:268).  A thread owns a sample's whole row.
+__global__ __launch_bounds__(256) void k_composite_bwd_sample_act(const float* __restrict__ w, const int* __restrict__ act, int S, int M, int C, int D,
+                                                                   const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                                   const float* __restrict__ inst_s, const float* __restrict__ ge, int stop_grad,
+                                                                   int sem_kind, float* __restrict__ dpre_rgb, int ld_rgb, float* __restrict__ dpre_sem,
+                                                                   int ld_sem, float* __restrict__ dpre_i0, float* __restrict__ dpre_i1, int ld_inst,
+                                                                   int E, float* __restrict__ g_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= limit_rows(M)) return;
+    const int sid = act[i];
+    const int r = sid / S;
+    const float wv = w[sid];
+    const float* e = ge + (size_t)r * (3 + C + D);
+    float gw = 0.f;
+    if (rgb_s) {
+        float* dr = dpre_rgb ? dpre_rgb + (size_t)i * ld_rgb : nullptr;
+        for (int c = 0; c < 3; ++c) {
+            const float o = rgb_s[(size_t)i * 3 + c];
+            if (dr) { const float g = wv * e[c]; dr[c] = g * o * (1.f - o); }
+            gw = fmaf(o, e[c], gw);
+        }
+        if (dr) for (int c = 3; c < ld_rgb; ++c) dr[c] = 0.f;
+    }
+    if (sem_s) {
+        const float* so = sem_s + (size_t)i * C;
+        float* ds = dpre_sem ? dpre_sem + (size_t)i * ld_sem : nullptr;
+        float dot = 0.f;
+        if (ds && sem_kind == 2)
+            for (int c = 0; c < C; ++c) dot += (wv * e[3 + c]) * so[c];
+        for (int c = 0; c < C; ++c) {
+            const float o = so[c];
+            if (ds) { const float g = wv * e[3 + c]; ds[c] = sem_kind == 2 ? o * (g - dot) : g; }
+            if (!stop_grad) gw = fmaf(o, e[3 + c], gw);
+        }
+        if (ds) for (int c = C; c < ld_sem; ++c) ds[c] = 0.f;
+    }
+    if (inst_s) {
+        float* d0 = dpre_i0 ? dpre_i0 + (size_t)i * ld_inst : nullptr;
+        float* d1 = dpre_i1 ? dpre_i1 + (size_t)i * ld_inst : nullptr;
+        for (int c = 0; c < D; ++c) {
+            const float g = wv * e[3 + C + c];
+            if (c < E) { if (d0) d0[c] = g; }
+            else if (c < 2 * E) { if (d1) d1[c - E] = g; }
+            if (!stop_grad) gw = fmaf(inst_s[(size_t)i * D + c], e[3 + C + c], gw);
+        }
+        for (int c = E; c < ld_inst; ++c) { if (d0) d0[c] = 0.f; if (d1) d1[c] = 0.f; }
+    }
+    if (g_w) g_w[sid] = gw;
+}
+
+extern "C" int clift_composite_bwd_act(const float* w, const int* act_idx, int N, int S, int M, int C, int D, const float* rgb_s, const float* sem_s,
+                                       const float* inst_s, const float* rgb_raw, const float* sem_raw, int softmax_mode, int white_bg, int stop_grad,
+                                       const float* g_rgb, const float* g_sem, const float* g_inst, float* ge_work, int sem_kind, float* dpre_rgb,
+                                       int ld_rgb, float* dpre_sem, int ld_sem, float* dpre_i0, float* dpre_i1, int ld_inst, int E, float* g_w,
+                                       float* g_opacity, clift_stream_t s) {
+    CLIFT_REQUIRE(sem_kind == 0 || sem_kind == 2, "clift_composite_bwd_act: sem_kind must be 0 (identity) or 2 (softmax)");
+    CLIFT_REQUIRE((!dpre_rgb || ld_rgb >= 3) && (!dpre_sem || ld_sem >= C) && ((!dpre_i0 && !dpre_i1) || (ld_inst >= E && E >= 1 && 2 * E >= D) || D == 0),
+                  "clift_composite_bwd_act: row pitches smaller than the rows (ld_rgb %d, ld_sem %d / C %d, ld_inst %d / E %d / D %d)", ld_rgb, ld_sem, C,
+                  ld_inst, E, D);
+    if (N <= 0) return 0;
+    k_composite_bwd_ray<<<cdiv(N, 256), 256, 0, as_stream(s)>>>(N, C, D, rgb_raw, sem_raw, softmax_mode, white_bg, g_rgb, g_sem, g_inst,
+                                                                 ge_work, g_opacity);
+    int rc = clift_check_launch("clift_composite_bwd_act(ray)");
+    if (rc || M <= 0) return rc;
+    k_composite_bwd_sample_act<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(w, act_idx, S, M, C, D, rgb_s, sem_s, inst_s, ge_work, stop_grad, sem_kind, dpre_rgb,
+                                                                        ld_rgb, dpre_sem, ld_sem, dpre_i0, dpre_i1, ld_inst, E, g_w);
+    return clift_check_launch("clift_composite_bwd_act(sample)");
 }
 
 extern "C" int clift_composite_bwd(const float* w, const int* ray_start, const int* act_idx, int N, int S, int M, int C, int D,

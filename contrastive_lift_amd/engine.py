@@ -307,19 +307,11 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
 # the independent tiled kernels for every layer instead (the cross-check the tests use).
 APP_SCATTER_XA = True       # tests clear it: clift_app_gather_bwd without the forward's positions (xa = NULL: the lane-per-(plane, channel) walk)
 DENS_BWD_SIGMA = True       # tests clear it: clift_density_bwd without the forward's sigma (sigma = NULL: the softplus derivative re-summed)
+COMPOSITE_ACT_FUSED = True  # tests clear it: the heads' output activations taken back by clift_rows_act_bwd launches after the compositing backward
 APP_OUT_BWD_FUSED = True    # tests clear it: the appearance output layer's weight gradient and masked input gradient as two passes over the hidden activation
-# basis Linear's backward inside the table-scatter walk (clift_app_gather_bwd_basis): correct and tested, but its 56 FMAs per lane and step make the
-# walk VALU-bound -- 300 us against 179 + 58 + 51 us of the three launches at the bench shape (profiles/r04_ab_app_front.txt) -- so it is OFF
-APP_BWD_BASIS_FUSED = False
 APP_FRONT_FUSED = True      # tests clear it: appearance gather, basis GEMM and input encoding as three launches (the form the fused front end replaced)
 KEEP_FIRST_ACT = False      # tests set this to compare against the stored-activation backward (masked dgrad + K = 3 weight gradient)
 FUSE_HEAD_BF16 = True       # bf16 mode: first three layers (+ E <= 4 output layer) of an xyz head in one launch; tests clear it to compare with the per-layer launches
-
-
-def app_bwd_basis_fused(ctx, va, ldf, nf):
-    """Does the appearance backward of this context run the basis Linear's backward inside the scatter walk (clift_app_gather_bwd_basis)?
-    Then the forward need not have kept the plane x line products."""
-    return (APP_BWD_BASIS_FUSED and APP_SCATTER_XA and va.comps <= 64 and ldf == 28 and nf <= 28 and os.environ.get("CLIFT_NO_PERSISTENT") is None)
 
 
 def first2_bwd(M, d, W1, W0, b0, xa, gW0, gb0):
@@ -657,8 +649,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                     and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # the appearance front end as one launch: gather -> basis -> MLP input rows (the products are written only for a backward)
                 ldf = 28
-                F = (torch.empty((M, nc), dtype=torch.float32, device=dev)
-                     if ("app" in grad_heads and not app_bwd_basis_fused(None, va, ldf, nf)) else None)
+                F = torch.empty((M, nc), dtype=torch.float32, device=dev) if "app" in grad_heads else None
                 feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
                 X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
                 call("clift_app_front_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(Wb), _pitch(Wb), nf,
@@ -786,13 +777,30 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
     g_op = torch.zeros((N,), dtype=torch.float32, device=dev)
     if M > 0 and (g_rgb is not None or g_sem is not None or g_inst is not None):
         ge = torch.empty((N, 3 + Ccls + D), dtype=torch.float32, device=dev)
-        d_rgb = torch.empty((M, 3), dtype=torch.float32, device=dev) if g_rgb is not None else None
-        d_sem = torch.empty((M, Ccls), dtype=torch.float32, device=dev) if g_sem is not None else None
-        d_inst = torch.empty((M, D), dtype=torch.float32, device=dev) if g_inst is not None else None
-        call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
-             ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
-             ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
-             ptr(g_w), ptr(g_op), st)
+        E_inst = model.render_instance_mlp.output_channels if (D > 0 and model.render_instance_mlp is not None) else 0
+        act_fused = COMPOSITE_ACT_FUSED and (D == 0 or (E_inst >= 1 and 2 * E_inst >= D))
+        if act_fused:
+            # the heads' output activations (sigmoid / softmax / identity) are taken back inside the compositing backward: what it writes are the
+            # zero-padded pre-activation gradient rows the heads' backward kernels start from
+            ldp_sem, ldp_inst = (Ccls + 3) // 4 * 4, (E_inst + 3) // 4 * 4
+            d_rgb = torch.empty((M, 4), dtype=torch.float32, device=dev) if g_rgb is not None else None
+            d_sem = torch.empty((M, ldp_sem), dtype=torch.float32, device=dev) if g_sem is not None else None
+            d_inst = torch.empty((M, ldp_inst), dtype=torch.float32, device=dev) if g_inst is not None else None
+            d_inst_slow = (torch.empty((M, ldp_inst), dtype=torch.float32, device=dev)
+                           if (g_inst is not None and model.slow_fast_mode and slow_grad) else None)
+            call("clift_composite_bwd_act", ptr(ctx.w), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
+                 ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
+                 ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge),
+                 2 if (model.render_semantic_mlp is not None and model.render_semantic_mlp.softmax) else 0, ptr(d_rgb), 4, ptr(d_sem), ldp_sem,
+                 ptr(d_inst), ptr(d_inst_slow), ldp_inst, E_inst, ptr(g_w), ptr(g_op), st)
+        else:
+            d_rgb = torch.empty((M, 3), dtype=torch.float32, device=dev) if g_rgb is not None else None
+            d_sem = torch.empty((M, Ccls), dtype=torch.float32, device=dev) if g_sem is not None else None
+            d_inst = torch.empty((M, D), dtype=torch.float32, device=dev) if g_inst is not None else None
+            call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
+                 ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
+                 ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
+                 ptr(g_w), ptr(g_op), st)
         br = Branches()
         if density_grad:
             model.xcd_workspace_for("density")
@@ -809,8 +817,11 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             gapp = _lin_params(None, "render_appearance_mlp.mlp", gviews)
             (W1, b1), (W2, b2), (W3, b3) = app
             (gW1, gb1), (gW2, gb2), (gW3, gb3) = gapp
-            dpre = torch.empty((M, 4), dtype=torch.float32, device=dev)
-            call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, stream())
+            if act_fused:
+                dpre = d_rgb
+            else:
+                dpre = torch.empty((M, 4), dtype=torch.float32, device=dev)
+                call("clift_rows_act_bwd", ptr(ctx.rgb_s), 3, ptr(d_rgb), 3, M, 3, 1, ptr(dpre), 4, stream())
             H1, H2, X, ldx = ctx.H1, ctx.H2, ctx.X, ctx.ldx
             n2 = W3.shape[1]
             dH2 = torch.empty((M, n2), dtype=H2.dtype, device=dev)
@@ -836,26 +847,23 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             nc = Wb.shape[1]
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
-            if app_bwd_basis_fused(ctx, va, ldf, nf):
-                # the basis Linear's backward (weight gradient and 27 -> 144 input gradient) inside the scatter walk: neither dF nor F exists
-                call("clift_app_gather_bwd_basis", C.byref(va), C.byref(ga), M, ptr(dfeat), ldf, nf, ptr(Wb), _pitch(Wb), ptr(gWb), _pitch(gWb),
-                     ptr(ctx.xa), stream())
-                dF = None
-            else:
-                call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
-                dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
-                gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
-                call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
-                     ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
+            call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
+            dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
+            gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
+            call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
+                 ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
             vm_grad_finish(model, gviews, "appearance", ga)
             keep.extend([dpre, dH2, dH1, dX, dfeat, dF])
 
         # ---------------- semantic head
         def sem_chain(keep):
-            ldp = (Ccls + 3) // 4 * 4
-            dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
-            kind = 2 if model.render_semantic_mlp.softmax else 0
-            call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, stream())
+            if act_fused:
+                dpre = d_sem
+            else:
+                ldp = (Ccls + 3) // 4 * 4
+                dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+                kind = 2 if model.render_semantic_mlp.softmax else 0
+                call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, stream())
             xyz_mlp_bwd(_lin_params(None, "render_semantic_mlp.mlp", views), _lin_params(None, "render_semantic_mlp.mlp", gviews),
                         ctx.xa, ctx.sem_acts, dpre, M, keep)
 
@@ -863,9 +871,12 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
         def inst_chain(prefix, acts, off):
             def run(keep):
                 E = model.render_instance_mlp.output_channels
-                ldp = (E + 3) // 4 * 4
-                dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
-                call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E, 0, ptr(dpre), ldp, stream())
+                if act_fused:
+                    dpre = d_inst if off == 0 else d_inst_slow
+                else:
+                    ldp = (E + 3) // 4 * 4
+                    dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+                    call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E, 0, ptr(dpre), ldp, stream())
                 xyz_mlp_bwd(_lin_params(None, prefix, views), _lin_params(None, prefix, gviews), ctx.xa, acts, dpre, M, keep)
             return run
 

@@ -180,15 +180,8 @@ int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const 
 /* The appearance head's front end in ONE launch (ABI 16): clift_app_gather_fwd, the basis Linear (tensoRF.py:65,127-134: feat = F Wb^T,
  * Wb (nf, 3*comps) with row pitch ldb, no bias) and clift_app_encode_fwd for tiles of 64 active samples, the products and the features
  * staying on the CU.  Writes xa (M, 4; nullable), feat (M, ldf; pad columns zero -- the encode backward reads it), X (M, ldx) fp32 and --
- * only when F is not NULL (a backward pass will want the products) -- F (M, 3*comps).  feat_j is one fmaf chain over k = 0 .. 3*comps-1
- * (fp32 round-off apart from the matrix-core GEMM of the unfused path).  nf <= 28, nf <= ldf <= 28, ldx % 4 == 0, ldb % 4 == 0. */
-/* Backward of the appearance gather AND of the basis Linear in one launch (ABI 16; needs the forward's xa, comps <= 64): dfeat (M, 28) is the
- * gradient of the basis Linear's output (pad columns zero, as clift_app_encode_bwd writes it), Wb (nf, 3*comps) the basis matrix.  A lane of
- * the scatter walk forms dF[s][c] = sum_j dfeat[s][j] Wb[j][c] itself (fmaf chain over j) and, holding F[s][c] = plane x line of its step, adds
- * dfeat[s][j] F[s][c] into the basis matrix's gradient gWb (nf, ldg) += dfeat^T F.  Replaces clift_wgrad_narrow over the stored products, the
- * 27 -> 144 dgrad GEMM and clift_app_gather_bwd; the table gradients are the same per-sample terms in the same walk order. */
-int clift_app_gather_bwd_basis(const clift_vm_t* h_app, const clift_vm_grad_t* h_grad, int M, const float* dfeat, int lddf, int nf,
-                               const float* Wb, int ldb, float* gWb, int ldg, const float* xa, clift_stream_t s);
+ * only when F is not NULL (a backward pass will want the products) -- F (M, 3*comps).  feat = F Wb^T runs on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32, two k halves added: fp32 round-off apart from the GEMM of the unfused path).  nf <= 28, nf <= ldf <= 28, ldx % 4 == 0, ldb % 4 == 0. */
 int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
                         int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, float* X,
                         int ldx, float* F, clift_stream_t s);
@@ -360,6 +353,16 @@ int clift_composite_bwd(const float* w, const int* ray_start, const int* act_idx
                         const float* sem_raw, int softmax_mode, int white_bg, int stop_grad, const float* g_rgb,
                         const float* g_sem, const float* g_inst, float* ge_work, float* d_rgb_s, float* d_sem_s,
                         float* d_inst_s, float* g_w, float* g_opacity, clift_stream_t s);
+/* The same with the heads' output activations folded in (ABI 16): instead of d_rgb_s / d_sem_s / d_inst_s it writes the gradients w.r.t. the
+ * PRE-activation outputs of the heads' last layers, in the zero-padded rows their backward kernels take -- dpre_rgb (M, ld_rgb): sigmoid backward
+ * (tensoRF.py:398); dpre_sem (M, ld_sem): sem_kind 2 = softmax backward over the row (tensoRF.py:37,593), 0 = identity; dpre_i0 / dpre_i1
+ * (M, ld_inst): instance columns [0, E) / [E, 2E) (fast / slow half, tensoRF.py:505-511; each nullable) -- so no clift_rows_act_bwd launch
+ * follows.  The head buffers rgb_s / sem_s / inst_s must be given for the heads whose gradient is wanted. */
+int clift_composite_bwd_act(const float* w, const int* act_idx, int N, int S, int M, int C, int D, const float* rgb_s, const float* sem_s,
+                            const float* inst_s, const float* rgb_raw, const float* sem_raw, int softmax_mode, int white_bg, int stop_grad,
+                            const float* g_rgb, const float* g_sem, const float* g_inst, float* ge_work, int sem_kind, float* dpre_rgb,
+                            int ld_rgb, float* dpre_sem, int ld_sem, float* dpre_i0, float* dpre_i1, int ld_inst, int E, float* g_w,
+                            float* g_opacity, clift_stream_t s);
 
 /* ---- a18: model/loss/loss.py:14-22 on one channels-last plane (H,W,C); loss_accum[0] += weight*TV(x);
  * grad (nullable) += weight * dTV/dx. */

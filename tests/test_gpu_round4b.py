@@ -12,22 +12,22 @@ from test_gpu_parity import DEV, _import, build_model, scene
 pytestmark = pytest.mark.gpu
 
 
-def _render_ctx(fused, n_rays=700, res=(40, 48, 56), grad=True, cap=None, seed=31, bwd_basis=False):
+def _render_ctx(fused, n_rays=700, res=(40, 48, 56), grad=True, cap=None, seed=31, heads=("app", "sem"), mode="softmax"):
     cl, op, orender, ofld, olosses, orays = _import()
     from contrastive_lift_amd import engine
     C_, E = 5, 3
     aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
     P, rays, rng = scene(op, orays, seed, res, C_, E, n_rays, amp=2.2, sg=0.4)
     jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
-    m = build_model(cl, P, res, C_, E, -3.0, "softmax")
-    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
-    prev = engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED
-    engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED = fused, bwd_basis      # (bwd_basis False: the forward keeps the products for the backward)
+    m = build_model(cl, P, res, C_, E, -3.0, mode)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode=mode).to(DEV)
+    prev = engine.APP_FRONT_FUSED
+    engine.APP_FRONT_FUSED = fused
     try:
-        out, ctx = engine.render_forward(m, r, rays.to(DEV), jitter.to(DEV), False, grad_heads=("app", "sem") if grad else (), cap=cap)
+        out, ctx = engine.render_forward(m, r, rays.to(DEV), jitter.to(DEV), False, grad_heads=heads if grad else (), cap=cap)
         torch.cuda.synchronize()
     finally:
-        engine.APP_FRONT_FUSED, engine.APP_BWD_BASIS_FUSED = prev
+        engine.APP_FRONT_FUSED = prev
         engine.reset_rows_limit(torch.device(DEV, torch.cuda.current_device()))
     return m, out, ctx
 
@@ -103,38 +103,19 @@ def test_app_front_fwd_without_products_row_limit_and_bad_arguments():
              m.pe_feat, m.pe_view, ptr(xa), ptr(feat), 28, ptr(X), 100, None, stream())
 
 
-def _app_backward(fused_bwd, n_rays=700, res=(40, 48, 56), seed=31):
-    """Gradients of sum(rgb * cot) through the appearance head with the basis backward inside the scatter walk (True) or as separate launches."""
+def _app_backward(n_rays=700, res=(40, 48, 56), seed=31):
+    """Gradients of sum(rgb * cot) through the appearance head."""
     from contrastive_lift_amd import engine
-    m, out, ctx = _render_ctx(True, n_rays, res, seed=seed, bwd_basis=fused_bwd)
-    assert (ctx.F is None) == fused_bwd
+    m, out, ctx = _render_ctx(True, n_rays, res, seed=seed)
     g = torch.Generator().manual_seed(5)
     cot = torch.randn(out["rgb"].shape, generator=g).to(DEV)
     m.zero_grad_arena()
     gv = m.named_grad_views()
-    prev = engine.APP_BWD_BASIS_FUSED
-    engine.APP_BWD_BASIS_FUSED = fused_bwd
-    try:
-        engine.render_backward(m, ctx, gv, g_rgb=cot, density_grad=False)
-        torch.cuda.synchronize()
-    finally:
-        engine.APP_BWD_BASIS_FUSED = prev
+    engine.render_backward(m, ctx, gv, g_rgb=cot, density_grad=False)
+    torch.cuda.synchronize()
     keys = ["appearance_basis_mat.weight"] + [f"appearance_plane.{i}" for i in range(3)] + [f"appearance_line.{i}" for i in range(3)] + \
            ["render_appearance_mlp.mlp.0.weight", "render_appearance_mlp.mlp.4.weight", "render_appearance_mlp.mlp.4.bias", "render_appearance_mlp.mlp.2.weight"]
     return m, ctx, cot, {k: gv[k].detach().clone() for k in keys}
-
-
-@pytest.mark.parametrize("n_rays,res", [(3, (40, 48, 56)), (700, (40, 48, 56)), (2500, (40, 48, 56)), (900, (128, 128, 128))])
-def test_app_gather_bwd_basis_against_the_separate_launches(n_rays, res):
-    """clift_app_gather_bwd_basis = basis weight gradient + 27 -> 144 dgrad + table scatter in one walk, against the three separate launches: the
-    basis matrix's gradient and the table gradients to fp32 summation round-off (1e-4 relative + 2e-6 of
-    the tensor's scale, no outliers allowed)."""
-    from conftest import grad_close
-    m, ctx, cot, g_f = _app_backward(True, n_rays, res)
-    _, _, _, g_u = _app_backward(False, n_rays, res)
-    for k in g_f:
-        grad_close(g_f[k].cpu(), g_u[k].cpu(), what=k, rtol=1e-4, scale_atol=2e-6, outlier_frac=0.0, outlier_cap=1e-4)
-    assert float(g_f["appearance_basis_mat.weight"].abs().max()) > 0 and float(g_f["appearance_plane.1"].abs().max()) > 0
 
 
 @pytest.mark.parametrize("M,no,ldd,nh", [(4096, 3, 4, 128), (4099, 3, 4, 128), (249003, 3, 4, 128), (33, 3, 4, 128), (5000, 22, 24, 32), (8191, 6, 8, 224)])
@@ -176,8 +157,36 @@ def test_appearance_output_layer_backward_fused_matches_the_two_passes():
         prev = engine.APP_OUT_BWD_FUSED
         engine.APP_OUT_BWD_FUSED = fused
         try:
-            outs.append(_app_backward(False, 2500)[3])
+            outs.append(_app_backward(2500)[3])
         finally:
             engine.APP_OUT_BWD_FUSED = prev
     for k in outs[0]:
         grad_close(outs[0][k].cpu(), outs[1][k].cpu(), what=k, rtol=1e-4, scale_atol=2e-6, outlier_frac=0.0, outlier_cap=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["softmax", "none"])
+@pytest.mark.parametrize("n_rays", [5, 1500])
+def test_composite_backward_with_the_output_activations_folded_in(mode, n_rays):
+    """clift_composite_bwd_act against clift_composite_bwd + one clift_rows_act_bwd per head: every parameter gradient of a backward through all
+    four heads (colours, semantics, fast and slow instance halves) -- sigmoid and identity rows are the same arithmetic (the weight gradients
+    differ only by the order of their atomics), the softmax row's dot product is summed in class order instead of a shuffle tree."""
+    from conftest import grad_close
+    from contrastive_lift_amd import engine
+    res = []
+    for fused in (True, False):
+        m, out, ctx = _render_ctx(True, n_rays, heads=("app", "sem", "fast", "slow"), mode=mode)
+        g = torch.Generator().manual_seed(9)
+        cots = [torch.randn(out[k].shape, generator=g).to(DEV) for k in ("rgb", "semantics", "instances")]
+        m.zero_grad_arena()
+        gv = m.named_grad_views()
+        prev = engine.COMPOSITE_ACT_FUSED
+        engine.COMPOSITE_ACT_FUSED = fused
+        try:
+            engine.render_backward(m, ctx, gv, g_rgb=cots[0], g_sem=cots[1], g_inst=cots[2], density_grad=True, slow_grad=True)
+            torch.cuda.synchronize()
+        finally:
+            engine.COMPOSITE_ACT_FUSED = prev
+        res.append({k: v.detach().clone() for k, v in gv.items()})
+    assert float(res[0]["render_instance_mlp.slow_mlp.2.weight"].abs().max()) > 0 and float(res[0]["render_semantic_mlp.mlp.2.weight"].abs().max()) > 0
+    for k in res[0]:
+        grad_close(res[0][k].cpu(), res[1][k].cpu(), what=k, rtol=1e-4, scale_atol=3e-6, outlier_frac=0.0, outlier_cap=1e-4)

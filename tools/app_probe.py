@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch times of the appearance head's front end (forward: gather / basis / encode vs clift_app_front_fwd; backward: encode_bwd / basis
-weight gradient / dF GEMM / scatter vs clift_app_gather_bwd_basis) on the bench scene (128^3, 4096 rays).
+weight gradient / dF GEMM / scatter) on the bench scene (128^3, 4096 rays).
    python tools/app_probe.py [path of an alternative libclift.so]"""
 import ctypes as C
 import os
@@ -65,7 +65,4 @@ with engine.exact_fp32():
     t_df = timeit(lambda: engine.gemm(M, nc, nf, dfeat, 28, Wb, ldb, dF, nc, b_trans=1))
 t_sc = timeit(lambda: call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(rays), ptr(jit), ptr(ctx.act_idx), M, ptr(dF), ptr(xa), stream()))
 line = f"backward: encode_bwd {t_eb:6.1f}  basis wgrad {t_wb:6.1f} + dF gemm {t_df:6.1f} + scatter {t_sc:6.1f} = {t_wb + t_df + t_sc:6.1f} us"
-if hasattr(_lib.load(), "clift_app_gather_bwd_basis"):
-    t_sb = timeit(lambda: call("clift_app_gather_bwd_basis", C.byref(va), C.byref(ga), M, ptr(dfeat), 28, nf, ptr(Wb), ldb, ptr(gWb), ldb, ptr(xa), stream()))
-    line += f"   scatter + basis backward in one {t_sb:6.1f} us"
 print(line, flush=True)
