@@ -956,6 +956,78 @@ __global__ __launch_bounds__(256) void k_composite_bwd_sample_act(const float* _
     if (g_w) g_w[sid] = gw;
 }
 
+// The same, SIXTEEN lanes per sample (C <= 48, D <= 8): lane 0 = the colours, lanes 1 .. 12 = four semantic classes each, lanes 13 / 14 = four
+// instance dimensions each; the row's two sums (the softmax dot product, g_w) fold over the 16 lanes with xor shuffles.  A wave covers four
+// consecutive samples: its loads and stores are runs of whole rows.  (The one-thread-per-sample form above walks a 100-byte row per lane, every
+// access of a wave 44 cache lines wide: 63 us per launch where this data moves in ~15.)
+__global__ __launch_bounds__(256) void k_composite_bwd_sample_act16(const float* __restrict__ w, const int* __restrict__ act, int S, int M, int C, int D,
+                                                                     const float* __restrict__ rgb_s, const float* __restrict__ sem_s,
+                                                                     const float* __restrict__ inst_s, const float* __restrict__ ge, int stop_grad,
+                                                                     int sem_kind, float* __restrict__ dpre_rgb, int ld_rgb, float* __restrict__ dpre_sem,
+                                                                     int ld_sem, float* __restrict__ dpre_i0, float* __restrict__ dpre_i1, int ld_inst,
+                                                                     int E, float* __restrict__ g_w) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(gid >> 4), l = (int)(gid & 15);
+    const bool row = i < limit_rows(M);              // (whole 16-lane groups: the shuffles below stay inside a group)
+    const int ii = row ? i : 0;
+    const int sid = act[ii];
+    const int r = sid / S;
+    const float wv = w[sid];
+    const float* e = ge + (size_t)r * (3 + C + D);
+    float gw = 0.f, dot = 0.f;
+    float o[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+    int c0 = 0, n = 0;                                // this lane's channels [c0, c0 + n) of its head
+    if (l == 0) {
+        if (rgb_s) {
+            n = 3;
+            for (int k = 0; k < 3; ++k) { o[k] = rgb_s[(size_t)ii * 3 + k]; g[k] = wv * e[k]; gw = fmaf(o[k], e[k], gw); }
+        }
+    } else if (l <= 12) {
+        c0 = 4 * (l - 1);
+        if (sem_s && c0 < C) {
+            n = min(4, C - c0);
+            for (int k = 0; k < n; ++k) {
+                o[k] = sem_s[(size_t)ii * C + c0 + k]; g[k] = wv * e[3 + c0 + k];
+                dot += g[k] * o[k];
+                if (!stop_grad) gw = fmaf(o[k], e[3 + c0 + k], gw);
+            }
+        }
+    } else if (l <= 14) {
+        c0 = 4 * (l - 13);
+        if (inst_s && c0 < D) {
+            n = min(4, D - c0);
+            for (int k = 0; k < n; ++k) {
+                g[k] = wv * e[3 + C + c0 + k];
+                if (!stop_grad) gw = fmaf(inst_s[(size_t)ii * D + c0 + k], e[3 + C + c0 + k], gw);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) { gw += __shfl_xor(gw, d); dot += __shfl_xor(dot, d); }
+    if (!row) return;
+    if (l == 0) {
+        if (dpre_rgb && rgb_s) {
+            float* dr = dpre_rgb + (size_t)i * ld_rgb;
+            for (int k = 0; k < ld_rgb; ++k) dr[k] = k < 3 ? g[k] * o[k] * (1.f - o[k]) : 0.f;
+        }
+        if (g_w) g_w[sid] = gw;
+    } else if (l <= 12) {
+        if (dpre_sem && sem_s && c0 < ld_sem) {
+            float* ds = dpre_sem + (size_t)i * ld_sem + c0;
+            for (int k = 0; k < min(4, ld_sem - c0); ++k) ds[k] = k < n ? (sem_kind == 2 ? o[k] * (g[k] - dot) : g[k]) : 0.f;
+        }
+    } else if (l <= 14) {
+        if (inst_s)
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;                 // instance column: [0, E) -> dpre_i0, [E, 2E) -> dpre_i1, pads zero
+                if (c < E) { if (dpre_i0) dpre_i0[(size_t)i * ld_inst + c] = g[k]; }
+                else if (c < 2 * E && c < D) { if (dpre_i1) dpre_i1[(size_t)i * ld_inst + c - E] = g[k]; }
+            }
+        if (l == 13 && inst_s)
+            for (int c = E; c < ld_inst; ++c) { if (dpre_i0) dpre_i0[(size_t)i * ld_inst + c] = 0.f; if (dpre_i1) dpre_i1[(size_t)i * ld_inst + c] = 0.f; }
+    }
+}
+
 extern "C" int clift_composite_bwd_act(const float* w, const int* act_idx, int N, int S, int M, int C, int D, const float* rgb_s, const float* sem_s,
                                        const float* inst_s, const float* rgb_raw, const float* sem_raw, int softmax_mode, int white_bg, int stop_grad,
                                        const float* g_rgb, const float* g_sem, const float* g_inst, float* ge_work, int sem_kind, float* dpre_rgb,
@@ -970,8 +1042,12 @@ extern "C" int clift_composite_bwd_act(const float* w, const int* act_idx, int N
                                                                  ge_work, g_opacity);
     int rc = clift_check_launch("clift_composite_bwd_act(ray)");
     if (rc || M <= 0) return rc;
-    k_composite_bwd_sample_act<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(w, act_idx, S, M, C, D, rgb_s, sem_s, inst_s, ge_work, stop_grad, sem_kind, dpre_rgb,
-                                                                        ld_rgb, dpre_sem, ld_sem, dpre_i0, dpre_i1, ld_inst, E, g_w);
+    if (C <= 48 && D <= 8 && ld_sem <= 48)
+        k_composite_bwd_sample_act16<<<cdiv(16L * M, 256), 256, 0, as_stream(s)>>>(w, act_idx, S, M, C, D, rgb_s, sem_s, inst_s, ge_work, stop_grad, sem_kind,
+                                                                                    dpre_rgb, ld_rgb, dpre_sem, ld_sem, dpre_i0, dpre_i1, ld_inst, E, g_w);
+    else
+        k_composite_bwd_sample_act<<<cdiv(M, 256), 256, 0, as_stream(s)>>>(w, act_idx, S, M, C, D, rgb_s, sem_s, inst_s, ge_work, stop_grad, sem_kind, dpre_rgb,
+                                                                            ld_rgb, dpre_sem, ld_sem, dpre_i0, dpre_i1, ld_inst, E, g_w);
     return clift_check_launch("clift_composite_bwd_act(sample)");
 }
 
