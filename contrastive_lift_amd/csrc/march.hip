@@ -42,12 +42,114 @@ __global__ __launch_bounds__(256) void k_density_fwd(MarchP m, VmP t, const floa
     }
 }
 
+// The same values (bit for bit: same taps, same FMA order, same quad sum) from ONE WAVE PER SWEEP of 64 consecutive samples of a ray.  The per-thread form above is bound by its
+// index arithmetic, not by the table reads: every one of the four lanes of a sample redoes the ray's slab set-up (six IEEE divisions) and the tap
+// geometry of all three planes, and samples behind the box exit pay for the set-up too.  Here the ray is set up once per lane and sweep; lane =
+// sample computes position and tap records (four texel offsets + weights, two line offsets + weights per plane: 48
+// bytes) into the wave's LDS slot, then four passes of 16 samples x 4 lanes read the records back (broadcast inside a quad) and do nothing but
+// the 18 table reads and their FMAs.  In-box samples of a ray are a prefix (the march starts at the slab entry): a sweep with no sample in the
+// box stores zeros and ends.  56 -> see profiles/r04_density_fwd.txt.
+struct alignas(16) DfRec {
+    int o[4];
+    float w[4];
+    int z[2];
+    float wz[2];
+};
+constexpr int DFR_WAVES = 4;
+
+__global__ __launch_bounds__(64 * DFR_WAVES) void k_density_fwd_ray(MarchP m, VmP t, const float* __restrict__ rays, const float* __restrict__ jitter, int N,
+                                                                    float* __restrict__ sigma) {
+    __shared__ DfRec recs_all[DFR_WAVES][3][64];
+    __shared__ float sig_all[DFR_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsw = (m.S + 63) / 64;                         // sweeps per ray
+    const long item = (long)blockIdx.x * DFR_WAVES + wave;
+    if (item >= (long)N * nsw) return;
+    const int r = (int)(item / nsw);
+    DfRec (*recs)[64] = recs_all[wave];
+    float* sig = sig_all[wave];
+    const RayG g = load_ray(rays, r, m);
+    const float jit = jitter ? jitter[r] : 0.f;
+    const int C = t.comps;
+    float* out = sigma + (size_t)r * m.S;
+    {
+        const int k0 = (int)(item - (long)r * nsw) * 64;
+        const int k = k0 + lane;
+        float xn[3];
+        const bool in = k < m.S && sample_xn(g, m, sample_z(g, m, k, jit), xn);
+        if (__ballot(in) == 0) {                          // wave-uniform
+            if (k < m.S) out[k] = 0.f;
+            return;
+        }
+        if (in) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const VmTaps tp = vm_taps(t, i, xn);
+                int a_, b_, v_;
+                vm_axes(i, a_, b_, v_);
+                const int W = t.res[a_];
+                int4* dst = reinterpret_cast<int4*>(&recs[i][lane]);
+                dst[0] = make_int4((tp.ty.i0 * W + tp.tx.i0) * C, (tp.ty.i0 * W + tp.tx.i1) * C, (tp.ty.i1 * W + tp.tx.i0) * C, (tp.ty.i1 * W + tp.tx.i1) * C);
+                dst[1] = make_int4(__float_as_int(tp.tx.w0 * tp.ty.w0), __float_as_int(tp.tx.w1 * tp.ty.w0), __float_as_int(tp.tx.w0 * tp.ty.w1),
+                                   __float_as_int(tp.tx.w1 * tp.ty.w1));
+                dst[2] = make_int4(tp.tz.i0 * C, tp.tz.i1 * C, __float_as_int(tp.tz.w0), __float_as_int(tp.tz.w1));
+            }
+        }
+        sig[lane] = 0.f;
+        const unsigned long long inmask = __ballot(in);
+        __builtin_amdgcn_wave_barrier();
+        const int q = lane & 3;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int sl = pass * 16 + (lane >> 2);
+            const bool on = (inmask >> sl) & 1ull;
+            if ((inmask >> (pass * 16)) & 0xffffull) {                     // wave-uniform: some sample of this pass is in the box
+                float acc = 0.f;
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int4* rp = reinterpret_cast<const int4*>(&recs[i][sl]);
+                        const int4 o = rp[0], wi = rp[1], zi = rp[2];
+                        for (int c4 = q * 4; c4 < C; c4 += 16) {
+                            const float* pp = t.plane[i] + c4;
+                            const float* lp = t.line[i] + c4;
+                            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+                            pa = f4_fma(__int_as_float(wi.x), ld4(pp + (unsigned)o.x), pa);
+                            pa = f4_fma(__int_as_float(wi.y), ld4(pp + (unsigned)o.y), pa);
+                            pa = f4_fma(__int_as_float(wi.z), ld4(pp + (unsigned)o.z), pa);
+                            pa = f4_fma(__int_as_float(wi.w), ld4(pp + (unsigned)o.w), pa);
+                            float4 la = make_float4(0.f, 0.f, 0.f, 0.f);
+                            la = f4_fma(__int_as_float(zi.z), ld4(lp + (unsigned)zi.x), la);
+                            la = f4_fma(__int_as_float(zi.w), ld4(lp + (unsigned)zi.y), la);
+                            acc += f4_hsum(f4_mul(pa, la));
+                        }
+                    }
+                }
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (q == 0 && on) {
+                    const float x = acc + m.shift;
+                    sig[sl] = (x > 20.f) ? x : log1pf(expf(x));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k < m.S) out[k] = sig[lane];
+    }
+}
+
 extern "C" int clift_density_fwd(const clift_march_t* h_m, const clift_vm_t* h_dens, const float* rays,
                                  const float* jitter, int N, float* sigma, clift_stream_t s) {
     CLIFT_REQUIRE(h_dens->comps % 4 == 0, "clift_density_fwd: comps must be a multiple of 4 (got %d)", h_dens->comps);
     if (N <= 0) return 0;
-    const long total = (long)N * h_m->n_samples;
-    k_density_fwd<<<cdiv(total * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), rays, jitter, total, sigma);
+    const char* form = getenv("CLIFT_DENS_FWD");                         // test hook: "thread" = the per-thread form
+    const bool per_thread = form && !strcmp(form, "thread");
+    if (per_thread) {
+        const long total = (long)N * h_m->n_samples;
+        k_density_fwd<<<cdiv(total * 4, 256), 256, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), rays, jitter, total, sigma);
+    } else {
+        k_density_fwd_ray<<<cdiv((long)N * cdiv(h_m->n_samples, 64), DFR_WAVES), 64 * DFR_WAVES, 0, as_stream(s)>>>(to_dev(h_m), to_dev(h_dens), rays, jitter, N, sigma);
+    }
     return clift_check_launch("clift_density_fwd");
 }
 

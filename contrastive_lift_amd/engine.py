@@ -841,12 +841,12 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             dX = torch.empty((M, ldx), dtype=torch.float32, device=dev)
             gemm(M, ldx, n1, dH1, n1, W1, ldx, dX, ldx, b_trans=1)
             nf, ldf = ctx.nf, ctx.ldf
-            dfeat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-            call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             Wb, gWb = views["appearance_basis_mat.weight"], gviews["appearance_basis_mat.weight"]
             nc = Wb.shape[1]
             va = vm_struct(views, "appearance", ctx.res)
             ga = vm_grad_struct(model, gviews, "appearance")
+            dfeat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
+            call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
             gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)

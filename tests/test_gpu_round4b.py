@@ -190,3 +190,35 @@ def test_composite_backward_with_the_output_activations_folded_in(mode, n_rays):
     assert float(res[0]["render_instance_mlp.slow_mlp.2.weight"].abs().max()) > 0 and float(res[0]["render_semantic_mlp.mlp.2.weight"].abs().max()) > 0
     for k in res[0]:
         grad_close(res[0][k].cpu(), res[1][k].cpu(), what=k, rtol=1e-4, scale_atol=3e-6, outlier_frac=0.0, outlier_cap=1e-4)
+
+
+@pytest.mark.parametrize("res,n_rays", [((40, 48, 56), 700), ((128, 128, 128), 2049), ((24, 28, 32), 3)])
+def test_density_forward_one_wave_per_ray_is_the_per_thread_kernel_bit_for_bit(res, n_rays, monkeypatch):
+    """clift_density_fwd, wave-per-ray form (tap records through LDS, ray set-up once) against the per-thread form it replaced: identical sigma
+    (same taps, same FMA order, same quad sum), incl. rays that miss the box and partial last sweeps (S not a multiple of 64)."""
+    import ctypes as C
+    cl, op, orender, ofld, olosses, orays = _import()
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = scene(op, orays, 77, res, 5, 3, n_rays, amp=2.2, sg=0.4)
+    rays = rays.clone()
+    rays[0, 3:6] = torch.tensor([0.0, 1.0, 0.0]); rays[0, 0:3] = torch.tensor([5.0, -0.5, 5.0])        # a ray that never meets the box
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32)).to(DEV)
+    m = build_model(cl, P, res, 5, 3, -3.0, "softmax")
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    rd = rays.to(DEV)
+    ms = engine.march_struct(r, m)
+    views = m.named_views()
+    vd = engine.vm_struct(views, "density", engine.grid_res(views))
+    S = int(r.n_samples)
+    assert S % 64 != 0
+    out = []
+    for form in ("ray", "thread"):
+        monkeypatch.setenv("CLIFT_DENS_FWD", form)
+        sg = torch.full((n_rays, S), -1.0, device=DEV)
+        call("clift_density_fwd", C.byref(ms), C.byref(vd), ptr(rd), ptr(jitter), n_rays, ptr(sg), stream())
+        torch.cuda.synchronize()
+        out.append(sg)
+    assert torch.equal(out[0], out[1])
+    assert float(out[0].max()) > 0 and bool((out[0][0] == 0).all())
