@@ -159,6 +159,14 @@ def main():
     _ = tr._rng_state()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record(); torch.zeros(8, device=dev).cpu(); ev[1].record(); torch.cuda.synchronize(); _ = ev[0].elapsed_time(ev[1])
+    # ... and so are the buffers of the state snapshot and the per-step events of the timed loop: allocated / created (and recorded once) HERE, so
+    # that the caching allocator and the runtime's event pool are in the same state during the warm-up as during the timed steps (a snapshot
+    # cloned between the two made the first timed step's allocations miss the cache: 36 - 39 ms in step 1 of two runs out of three)
+    snap_bufs = [torch.empty_like(model.param_flat) for _ in range(5)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    for m_ in marks:
+        m_.record()
+    torch.cuda.synchronize()
     if world > 1 and tr.overlap_allreduce == "auto":
         # data-parallel: the trainer decides by measurement whether the asynchronous exchange (early range all-reduced under the density
         # backward, CUs reserved for RCCL) beats the synchronous one -- its 2 + 2 x 4 calibration passes synchronise the device, so
@@ -169,11 +177,13 @@ def main():
         tr.training_step(batches[i % n_batches], lean=a.lean)
     # snapshot of the training state at the start of the timed region (parameters + both Adam states): the roofline pass below
     # replays exactly these steps with per-launch events
-    snap = (model.param_flat.clone(), tr.opt_main.state_dict(), tr.opt_inst.state_dict(), tr._rng_state())
+    for buf, src in zip(snap_bufs, (model.param_flat, tr.opt_main.m, tr.opt_main.v, tr.opt_inst.m, tr.opt_inst.v)):
+        buf.copy_(src)
+    snap = (snap_bufs[0], {"m": snap_bufs[1], "v": snap_bufs[2], "t": dict(tr.opt_main.t), "lr_scale": tr.opt_main.lr_scale},
+            {"m": snap_bufs[3], "v": snap_bufs[4], "t": dict(tr.opt_inst.t), "lr_scale": tr.opt_inst.lr_scale}, tr._rng_state())
     sync_all()
     # one event per step boundary (recorded, never waited on inside the loop): the per-step GPU times afterwards show whether the K steps were
     # uniform or whether one of them carried a one-off stall (seen: ~40 ms once in the first GPU process on a fresh box)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
