@@ -57,7 +57,7 @@ _SIGNATURES = {
     "clift_gemm_workspace_bytes": ([_I, _I], C.c_long),
     "clift_out_layer_fwd": ([_P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P], C.c_int),
     "clift_out_layer_bwd": ([_P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
-    "clift_out_layer_bwd_nh": ([_P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
+    "clift_out_layer_bwd_nh": ([_P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_last_error": ([], C.c_char_p),
     "clift_gen_rays": ([_I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
     "clift_density_fwd": ([_P, _P, _P, _P, _I, _P, _P], C.c_int),

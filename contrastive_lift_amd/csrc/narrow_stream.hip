@@ -186,7 +186,7 @@ constexpr int DN_TPITCH = 36;            // floats per row of the transposition 
 template <int KJ, bool HB, bool MASK, bool WG = false, bool PF = WG>
 __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int rows_per_block, float* __restrict__ gW = nullptr, int ldgw = 0,
                                                                 float* __restrict__ gb = nullptr, int no = 0) {
-    static_assert(!WG || (MASK && !HB), "the fused weight gradient exists for the fp32 masked form");
+    static_assert(!WG || MASK, "the fused weight gradient exists for the masked forms");
     constexpr int ROWS = 32, TILEB = ROWS * 32 * 4;                          // stage: up to 32 rows x 32 floats
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILEB + (WG ? 8 * ROWS * DN_TPITCH * 4 : 0)];   // the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -316,8 +316,15 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
         if (WG && wave_on) {
             // the wave's 32 x 32 block of h: row-per-lane registers -> LDS [row][36] -> column-per-lane registers (rows 2 s + lh)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                asm volatile("ds_write_b128 %0, %1" : : "v"(tb0 + (unsigned)((li * DN_TPITCH + 8 * q + 4 * lh) * 4)), "v"(mk[q]) : "memory");
+            for (int q = 0; q < 4; ++q) {
+                f32x4 hv = mk[q];
+                if (HB) {                    // bf16-stored h: widened in the register (exact), so the products are fp32 as in k_wgrad_narrow_stream<true>
+                    const unsigned m0 = mh[q][0], m1 = mh[q][1];
+                    hv[0] = __uint_as_float(m0 << 16); hv[1] = __uint_as_float(m0 & 0xffff0000u);
+                    hv[2] = __uint_as_float(m1 << 16); hv[3] = __uint_as_float(m1 & 0xffff0000u);
+                }
+                asm volatile("ds_write_b128 %0, %1" : : "v"(tb0 + (unsigned)((li * DN_TPITCH + 8 * q + 4 * lh) * 4)), "v"(hv) : "memory");
+            }
             float hb[16], da[16];
 #pragma unroll
             for (int s_ = 0; s_ < 16; ++s_) {
@@ -383,15 +390,17 @@ __global__ __launch_bounds__(512, 2) void k_dgrad_narrow_stream(GemmP g, int row
 // W (no, 256) pitch ldw, H (M, 256) pitch ldh, dX (M, 256) pitch ldx; no <= ldd <= 32, ldd % 4 == 0, M >= 1, 16-byte-aligned rows.
 extern "C" int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int M,
                                    float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s) {
-    return clift_out_layer_bwd_nh(dOut, ldd, no, W, ldw, H, ldh, 256, M, dX, ldx, gW, ldgw, gb, s);
+    return clift_out_layer_bwd_nh(dOut, ldd, no, W, ldw, H, ldh, 256, M, dX, ldx, gW, ldgw, gb, 0, s);
 }
 
-// The same over a hidden layer of nh <= 256 units, nh % 32 == 0 (ABI 16: the 128-wide appearance head, tensoRF.py:393-397 backward).
+// The same over a hidden layer of nh <= 256 units, nh % 32 == 0 (ABI 16: the 128-wide appearance head, tensoRF.py:393-397 backward), and --
+// h_bf16 -- over a bf16-STORED hidden activation with a bf16-stored input gradient (bf16 mode; pitches in elements; nh = 256).
 extern "C" int clift_out_layer_bwd_nh(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int nh, int M,
-                                      float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s) {
+                                      float* dX, int ldx, float* gW, int ldgw, float* gb, int h_bf16, clift_stream_t s) {
     if (M <= 0) return 0;
     CLIFT_REQUIRE(no >= 1 && no <= ldd && ldd <= 32 && ldd % 4 == 0, "clift_out_layer_bwd: need no <= ldd <= 32, ldd %% 4 == 0 (got no=%d ldd=%d)", no, ldd);
     CLIFT_REQUIRE(nh >= 32 && nh <= 256 && nh % 32 == 0, "clift_out_layer_bwd: hidden width must be a multiple of 32 in [32, 256] (got %d)", nh);
+    CLIFT_REQUIRE(!h_bf16 || nh == 256, "clift_out_layer_bwd: the bf16-stored form takes a 256-wide hidden layer (got %d)", nh);
     CLIFT_REQUIRE(ldh % 4 == 0 && ldx % 4 == 0 && ldh >= nh && ldx >= nh && ldw >= nh && ldgw >= nh && (((uintptr_t)dOut) & 15) == 0 &&
                   (((uintptr_t)H) & 15) == 0 && (((uintptr_t)dX) & 15) == 0, "clift_out_layer_bwd: 16-byte aligned rows with pitches >= the hidden width required");
     GemmP p = {};
@@ -402,7 +411,12 @@ extern "C" int clift_out_layer_bwd_nh(const float* dOut, int ldd, int no, const 
     const dim3 grid(cdiv(M, rpb));
     hipStream_t st = as_stream(s);
     const int kj = cdiv(no, 8);
-    if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    if (h_bf16) {
+        if (kj <= 1) k_dgrad_narrow_stream<1, true, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else if (kj == 2) k_dgrad_narrow_stream<2, true, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else if (kj == 3) k_dgrad_narrow_stream<3, true, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+        else k_dgrad_narrow_stream<4, true, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
+    } else if (kj <= 1) k_dgrad_narrow_stream<1, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 2) k_dgrad_narrow_stream<2, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else if (kj == 3) k_dgrad_narrow_stream<3, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);
     else k_dgrad_narrow_stream<4, false, true, true><<<grid, 512, 0, st>>>(p, rpb, gW, ldgw, gb, no);

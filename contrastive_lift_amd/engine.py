@@ -307,6 +307,7 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
 # the independent tiled kernels for every layer instead (the cross-check the tests use).
 APP_SCATTER_XA = True       # tests clear it: clift_app_gather_bwd without the forward's positions (xa = NULL: the lane-per-(plane, channel) walk)
 DENS_BWD_SIGMA = True       # tests clear it: clift_density_bwd without the forward's sigma (sigma = NULL: the softplus derivative re-summed)
+OUT_BWD_BF16_FUSED = True   # tests clear it: bf16 mode, output layer's weight gradient and masked input gradient as two passes over the hidden activation
 COMPOSITE_ACT_FUSED = True  # tests clear it: the heads' output activations taken back by clift_rows_act_bwd launches after the compositing backward
 APP_OUT_BWD_FUSED = True    # tests clear it: the appearance output layer's weight gradient and masked input gradient as two passes over the hidden activation
 APP_FRONT_FUSED = True      # tests clear it: appearance gather, basis GEMM and input encoding as three launches (the form the fused front end replaced)
@@ -490,6 +491,14 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
             # output layer: weight gradient and masked input gradient in one pass over the hidden activation
             call("clift_out_layer_bwd", ptr(d), d.shape[1], no, ptr(W), _pitch(W), ptr(h), h.shape[1], M, ptr(dn), ni, ptr(gW), _pitch(gW),
                  ptr(gb), stream())
+            d = dn
+            keep.append(d)
+            continue
+        if (li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and MLP_PRECISION == 1 and OUT_BWD_BF16_FUSED and
+                h.dtype == torch.bfloat16 and d.dtype == torch.float32 and dn.dtype == torch.bfloat16 and h.shape[1] == 256 and _pitch(W) >= 256):
+            # bf16 mode: the same one pass over the (bf16-stored) hidden activation; the input gradient leaves bf16-stored
+            call("clift_out_layer_bwd_nh", ptr(d), d.shape[1], no, ptr(W), _pitch(W), ptr(h), 256, 256, M, ptr(dn), 256, ptr(gW), _pitch(gW),
+                 ptr(gb), 1, stream())
             d = dn
             keep.append(d)
             continue
@@ -829,7 +838,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
                     and _pitch(W3) >= n2 and _pitch(gW3) >= n2 and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # output layer: weight gradient and masked input gradient in one pass over the hidden activation (as in the xyz heads)
                 call("clift_out_layer_bwd_nh", ptr(dpre), 4, W3.shape[0], ptr(W3), _pitch(W3), ptr(H2), n2, n2, M, ptr(dH2), n2, ptr(gW3), _pitch(gW3),
-                     ptr(gb3), stream())
+                     ptr(gb3), 0, stream())
             else:
                 wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
                 gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)

@@ -238,7 +238,8 @@ int clift_out_layer_bwd(const float* dOut, int ldd, int no, const float* W, int 
 /* ... over a hidden layer of nh units, nh % 32 == 0, nh <= 256 (ABI 16: the 128-wide appearance head, tensoRF.py:393-397 backward; its
  * dOut is the gradient of the pre-sigmoid colours, (M, 4) with a zero pad column).  Pitches >= nh. */
 int clift_out_layer_bwd_nh(const float* dOut, int ldd, int no, const float* W, int ldw, const float* H, int ldh, int nh, int M,
-                           float* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
+                           float* dX, int ldx, float* gW, int ldgw, float* gb,
+                           int h_bf16 /* H and dX are bf16-stored (bf16 mode, nh = 256): the products stay fp32 */, clift_stream_t s);
 /* Forward of a narrow output layer over a 256-wide hidden activation, with the row activation that follows it, in ONE pass over H (ABI 15;
  * tensoRF.py:591-594 with :37 for the semantic head):  out[m][0..no) = act( H[m][0..256) W^T + b ),  no <= 32, act 0 = none, 2 = softmax over
  * the row.  H (M, ldh) fp32, W (no, 256) pitch ldw, b (no), out (M, ldo) -- columns [no, ldo) untouched.  Replaces clift_gemm (which streams H at

@@ -137,7 +137,7 @@ def test_output_layer_backward_in_one_pass_over_a_narrower_hidden_layer(M, no, l
     gW = torch.full((no, ldw), 0.25, device=DEV)
     gb = torch.full((no,), -1.0, device=DEV)
     engine.call("clift_out_layer_bwd_nh", engine.ptr(dOut.to(DEV)), ldd, no, engine.ptr(Wd), ldw, engine.ptr(Hd), ldh, nh, M, engine.ptr(dX), ldh,
-                engine.ptr(gW), ldw, engine.ptr(gb), engine.stream())
+                engine.ptr(gW), ldw, engine.ptr(gb), 0, engine.stream())
     torch.cuda.synchronize()
     ref_dx = (dOut[:, :no].double() @ W.double()) * (H > 0)
     ref_w = dOut[:, :no].double().T @ H.double() + 0.25
@@ -222,3 +222,40 @@ def test_density_forward_one_wave_per_ray_is_the_per_thread_kernel_bit_for_bit(r
         out.append(sg)
     assert torch.equal(out[0], out[1])
     assert float(out[0].max()) > 0 and bool((out[0][0] == 0).all())
+
+
+@pytest.mark.parametrize("M,no,ldd", [(4096, 22, 24), (4099, 3, 4), (249003, 22, 24), (8191, 6, 8)])
+def test_output_layer_backward_in_one_pass_over_a_bf16_stored_hidden_layer(M, no, ldd):
+    """clift_out_layer_bwd_nh(h_bf16 = 1) (bf16 mode): H and the input gradient are bf16-stored, the products fp32.  Against fp64 over the SAME
+    bf16 values of H: weight / bias gradient to fp32 round-off, the input gradient to one bf16 rounding of the fp64 value; the mask is H > 0."""
+    from conftest import rel_close
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(M + no)
+    dOut = torch.zeros((M, ldd))
+    dOut[:, :no] = torch.randn((M, no), generator=g)
+    W = torch.randn((no, 256), generator=g) * 0.1
+    Hb = torch.relu(torch.randn((M, 256), generator=g)).to(torch.bfloat16)
+    Hd, Wd = Hb.to(DEV), W.to(DEV)
+    dX = torch.full((M, 256), -7.0, device=DEV, dtype=torch.bfloat16)
+    gW = torch.full((no, 256), 0.25, device=DEV)
+    gb = torch.full((no,), -1.0, device=DEV)
+    engine.call("clift_out_layer_bwd_nh", engine.ptr(dOut.to(DEV)), ldd, no, engine.ptr(Wd), 256, engine.ptr(Hd), 256, 256, M, engine.ptr(dX), 256,
+                engine.ptr(gW), 256, engine.ptr(gb), 1, engine.stream())
+    torch.cuda.synchronize()
+    H = Hb.double()
+    ref_dx = (dOut[:, :no].double() @ W.double()) * (H > 0)
+    ref_w = dOut[:, :no].double().T @ H + 0.25
+    ref_b = dOut[:, :no].double().sum(0) - 1.0
+    rel_close(dX.float(), ref_dx, 2.0 ** -8, atol=1e-6 * float(ref_dx.abs().max()), what="fused dX (bf16-stored)")
+    rel_close(gW, ref_w, 2e-5, atol=2e-5 * float(ref_w.abs().max()), what="fused gW")
+    rel_close(gb, ref_b, 2e-5, atol=2e-5 * M ** 0.5, what="fused gb")
+    # and the pair of launches it replaces, through the engine (bf16 mode)
+    dX2 = torch.empty((M, 256), device=DEV, dtype=torch.bfloat16)
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        engine.gemm(M, 256, no, dOut.to(DEV), ldd, Wd, 256, dX2, 256, b_trans=1, mask=Hd, ldmask=256)
+    finally:
+        engine.set_mlp_precision(prev)
+    torch.cuda.synchronize()
+    if M >= 4096:
+        assert torch.equal(dX, dX2)
