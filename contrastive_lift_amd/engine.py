@@ -782,8 +782,13 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
     g_rgb = g_rgb.contiguous() if (g_rgb is not None and want_rgb) else None
     g_sem = g_sem.contiguous() if (g_sem is not None and want_sem) else None
     g_inst = g_inst.contiguous() if (g_inst is not None and want_inst) else None
-    g_w = torch.zeros((N, S), dtype=torch.float32, device=dev)
-    g_op = torch.zeros((N,), dtype=torch.float32, device=dev)
+    if density_grad:
+        # d loss / d weight (N, S) and d loss / d opacity (N): zero except at the active samples -- one fill for both
+        gbuf = torch.zeros((N * S + N,), dtype=torch.float32, device=dev)
+        g_w, g_op = gbuf[:N * S].view(N, S), gbuf[N * S:]
+    else:       # (feature passes: the weights carry no gradient, nobody reads these)
+        g_w = torch.empty((N, S), dtype=torch.float32, device=dev)
+        g_op = torch.empty((N,), dtype=torch.float32, device=dev)
     if M > 0 and (g_rgb is not None or g_sem is not None or g_inst is not None):
         ge = torch.empty((N, 3 + Ccls + D), dtype=torch.float32, device=dev)
         E_inst = model.render_instance_mlp.output_channels if (D > 0 and model.render_instance_mlp is not None) else 0

@@ -323,7 +323,9 @@ class HotPathTrainer:
         B = rays.shape[0]
         self._pass_begin(self.main_range)
         if jitter is None and c.perturb != 0:
-            jitter = c.perturb * torch.rand(B, device=self.device)
+            jitter = torch.rand(B, device=self.device)
+            if c.perturb != 1:
+                jitter = c.perturb * jitter
         chunk = c.chunk if c.chunk and c.chunk > 0 else B
         ctxs, outs = [], []
         for i in range(0, B, chunk):
@@ -356,7 +358,10 @@ class HotPathTrainer:
             _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
                       _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
                       _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
-        g_dist = torch.full((1,), w_rgb * self.current_lambda_dist_reg / len(ctxs), dtype=torch.float32, device=self.device)
+        gd = w_rgb * self.current_lambda_dist_reg / len(ctxs)
+        if getattr(self, "_g_dist", (None, None))[0] != gd:          # (a device scalar that changes once per epoch: kept instead of refilled every step)
+            self._g_dist = (gd, torch.full((1,), gd, dtype=torch.float32, device=self.device))
+        g_dist = self._g_dist[1]
         gv = m.named_grad_views()
         seg_term = segments is not None and sem_on and float(getattr(c, "lambda_segment", 0.0)) != 0.0
         # Data-parallel runs: the TV term depends on the parameters only, so it goes FIRST (the scatter kernels accumulate on top of it),
@@ -437,7 +442,11 @@ class HotPathTrainer:
         for img in inst_batch:
             rays = img["rays"]
             n = rays.shape[0]
-            jit = jitter if jitter is not None else (c.perturb * torch.rand(n, device=self.device) if c.perturb != 0 else None)
+            jit = jitter
+            if jit is None and c.perturb != 0:
+                jit = torch.rand(n, device=self.device)
+                if c.perturb != 1:
+                    jit = c.perturb * jit
             (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",),     # slow half: detached (T:268)
                                                       cap=self._capacity("inst", n))
             self._follow("inst", n, ctx)

@@ -148,6 +148,11 @@ def main(argv):
         start_epoch, gstep, resumed_mid_epoch, last_setup_epoch = resume_from(str(cfg.resume), cfg, tr, model, renderer, dev)
         if rank == 0:
             print(f"resumed {cfg.resume}: continuing at epoch {start_epoch} (global step {gstep}), grid {renderer.grid_dim.tolist()}", flush=True)
+    # the interpreter's first full garbage collection walks everything the imports and the set-up created (35 - 60 ms, i.e. ten training steps);
+    # it is taken here, once, and the set-up's objects are frozen out of later collections (bench.py does the same before its warm-up)
+    import gc
+    gc.collect()
+    gc.freeze()
     for epoch in range(start_epoch, int(cfg.max_epoch)):
         tr.current_epoch = epoch
         tr.on_train_epoch_start()
