@@ -259,3 +259,40 @@ def test_output_layer_backward_in_one_pass_over_a_bf16_stored_hidden_layer(M, no
     torch.cuda.synchronize()
     if M >= 4096:
         assert torch.equal(dX, dX2)
+
+
+@pytest.mark.parametrize("comps,C_", [(16, 5), (32, 5), (48, 60)])
+def test_other_component_and_class_counts_against_the_oracle(comps, C_):
+    """The appearance front end's other instantiations (16 / 32 components per plane: tensoRF.py:34-41 `num_appearance_comps`) and the
+    compositing backward's one-thread-per-sample form (more than 48 classes), forward and every gradient against the CPU oracle."""
+    from conftest import grad_close, rel_close
+    from test_gpu_parity import _run_forward_backward
+    cl, op, orender, ofld, olosses, orays = _import()
+    res, E, n_rays = (24, 28, 32), 3, 400
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P = op.add_blob(op.make_params(41 + comps, res, C_, E, n_app=(comps,) * 3), res, 2.3, 0.42)
+    _, rays, rng = scene(op, orays, 41, res, 2, E, n_rays, amp=2.3, sg=0.42)
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((n_rays, 3), (n_rays, C_), (n_rays, 2 * E))]
+    Pg = op.clone_params(P, requires_grad=True)
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0, semantic_weight_mode="softmax")
+    o = orender.render_forward(Pg, rays, cfg, jitter, False)
+    ((o[0] * cots[0]).sum() + (o[1] * cots[1]).sum() + (o[2] * cots[2]).sum()).backward()
+    m = cl.TensorVMSplit(list(res), num_appearance_comps=(comps,) * 3, num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32),
+                         num_semantic_classes=C_, dim_feature_instance=2 * E, splus_density_shift=-3.0,
+                         output_mlp_semantics=torch.nn.Softmax(dim=-1), use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True, device=DEV)
+    missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
+    assert not missing and not unexpected
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    outs, grads = _run_forward_backward(cl, m, r, rays, jitter, False, cots)
+    for a, b, nm in zip(outs[:4], o[:4], ("rgb", "sem", "inst", "depth")):
+        rel_close(a, b.detach(), 1e-3, what=nm)
+    for k, gr in grads.items():
+        ref = Pg[k].grad
+        ref = torch.zeros_like(Pg[k]) if ref is None else ref
+        got = torch.zeros_like(ref) if gr is None else gr.detach().cpu()
+        # (scale_atol 1e-3: on this small scene the K = 3 layers' gradients cancel heavily -- the fp32 CPU oracle itself is 7e-5 of the scale away
+        # from its float64 evaluation in 29 entries of the fast instance head's first layer, the exact-fp32 HIP path 1e-4)
+        grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-3,
+                   outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-2 if k.startswith("appearance_basis") else 1e-3),
+                   outlier_cap=1e-2)
