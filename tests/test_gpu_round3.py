@@ -468,8 +468,18 @@ def test_fp32x6_mode_full_forward_backward_vs_oracle():
 
 # ============================================================================ bf16 mode (configs[2]) against the ORACLE at the Messy-Rooms shape
 def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
+    _bf16_against_the_oracle((32, 32, 32), 768, 512, 60, 10)
+
+
+def test_bf16_mode_against_the_oracle_at_the_bench_shape():
+    """The same at the bench shape -- 128^3 grid, 4096 + 1024 rays, S = 440 -- over six full training steps (the CPU oracle
+    needs ~5 s for one): PSNR within 0.1 dB after every second step."""
+    _bf16_against_the_oracle((128, 128, 128), 4096, 1024, 6, 2)
+
+
+def _bf16_against_the_oracle(res, B, Bi, steps, every):
     """BASELINE configs[2]: Messy-Rooms class count (C = 2: background / foreground, dataset/many_object_scenes.py:135-141), 25 instance
-    ids, slow-fast contrastive head, bf16 MLP operands.  Sixty full training steps (main pass + instance pass, both optimizers, EMA) from
+    ids, slow-fast contrastive head, bf16 MLP operands.  `steps` full training steps (main pass + instance pass, both optimizers, EMA) from
     identical weights / batches / jitter through the HIP trainer in bf16 mode and through the fp32 CPU oracle:
       * rendered rgb / semantics / instance features of the first step within 2e-2 of each tensor's scale (bf16 has 8 significant bits:
         the 1e-3 of the fp32 path is not expected, SURVEY 7 'bf16 tolerance'),
@@ -479,9 +489,10 @@ def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
     from contrastive_lift_amd import engine
     from contrastive_lift_amd.trainer import HotPathTrainer, default_config
     from oracle.train_step import CpuTrainer
-    res, C_, E, B, Bi, steps = (32, 32, 32), 2, 3, 768, 512, 60
+    C_, E = 2, 3
+    torch.set_num_threads(usable_cores())
     aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
-    P, rays, rng = scene(op, orays, 73, res, C_, E, B + Bi, amp=2.6, sg=0.4)
+    P, rays, rng = scene(op, orays, 73, res, C_, E, B + Bi, amp=2.6, sg=0.4, img=(48 if B + Bi <= 3 * 48 * 48 else 96))
     rays_main, rays_inst = rays[:B].contiguous(), rays[B:].contiguous()
     d = rays_main[:, 3:6]
     rgbs = (0.5 + 0.5 * torch.sin(3.0 * d + torch.tensor([0.0, 1.0, 2.0]))).contiguous()
@@ -527,13 +538,14 @@ def test_bf16_mode_against_the_oracle_at_the_messy_rooms_shape():
             oi = ct.instance_pass(rays_inst, labels, iconf, jit_i)
             tr.main_pass(batch0, jitter=jit.to(DEV), white_bg=white)
             tr.instance_pass(ibatch, jitter=jit_i.to(DEV))
-            if step % 10 == 9 or step == steps - 1:
+            if step % every == every - 1 or step == steps - 1:
                 p_cpu, p_gpu = psnr(oc["rgb"], rgbs), psnr(tr.last_outputs[0].cpu(), rgbs)
                 worst = max(worst, abs(p_cpu - p_gpu))
                 assert abs(p_cpu - p_gpu) < 0.1, (step, p_cpu, p_gpu)
                 rel_close(tr.losses[1], oc["loss_sem"], 5e-2, what=f"bf16 step {step} loss_sem")
                 rel_close(tr.losses[3], oi["loss"], 1e-1, atol=5e-3, what=f"bf16 step {step} slow-fast loss")
-        assert p_cpu > psnr(torch.full_like(rgbs, 0.5), rgbs) + 1.0
+        if steps >= 30:          # (the long run must also have LEARNT something: a parity of two runs that both stand still would say little)
+            assert p_cpu > psnr(torch.full_like(rgbs, 0.5), rgbs) + 1.0
         print(f"bf16 vs oracle, C = 2 / 25 ids: PSNR after {steps} steps oracle {p_cpu:.3f} dB, HIP bf16 {p_gpu:.3f} dB; worst |delta| {worst:.4f} dB")
     finally:
         engine.set_mlp_precision("fp32")
