@@ -69,6 +69,7 @@ _SIGNATURES = {
     "clift_xyz_head_first2_x6_wgrad": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_last2_x6_workspace_bytes": ([_I], C.c_long),
     "clift_xyz_head_last2_x6_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _L, _P], C.c_int),
+    "clift_xyz_head_first2_bf16_bwd": ([_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_bwd": ([_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_first2_wgrad": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_xyz_head_last2_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P], C.c_int),

@@ -19,6 +19,7 @@ CLIFT_ROWS_LIMIT_BINDER(layer_bf16)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4k __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int LY_ROWS = 64;                 // rows per streamed tile (two 32-row MFMA tiles per wave)
@@ -53,13 +54,32 @@ static __device__ __forceinline__ void wait_vm_upto(int n) {       // wave-unifo
     else wait_vm<0>();
 }
 
+// K3W (dgrad only; the bf16 counterpart of k_layer_f32<dgrad, K3W> / k_layer_x6<dgrad, K3W>): the layer is the SECOND layer of an xyz head, so its
+// input gradient dH1 = (h1 > 0) . (dH2 W1) has one consumer, the K = 3 first layer's weight gradient gW0[n][0..2] += sum_m dH1[m][n] x_m, gb0[n] +=
+// sum_m dH1[m][n] (tensoRF.py:475,576 backward).  A lane of this kernel owns one row of each 32-row half of a tile and, after the permlane
+// swap, 2 x 8 consecutive columns of it: it keeps 16 x (x, y, z, 1) running sums over ITS rows for the whole row range (64 registers -- the
+// kernel allocates the whole register file anyway, see the ballast), on the values the unfused path would have stored (rounded to bf16, masked),
+// so the products are the same and only their summation order differs.  dH1 is never written; the tile's 64 positions (16 B each) travel by one more LDS-DMA
+// instruction of wave 0 into a slot beside the tile and are read back in the epilogue.  (A first form loaded them into registers with inline asm
+// at the top of the tile and waited for them before the epilogue: between the two statements the compiler, at 256 registers, moved the not yet
+// written registers -- wrong sums in some launches of one size only.  Nothing that is still in flight may live in a compiler-visible register.)  The 32 lanes of a half-wave are folded once per block with xor shuffles; one atomic per column and
+// component into this XCD's gradient shard.  Removes the k_wgrad_narrow_stream<true> launch that re-read dH1 (53 us at 249 k rows) and the 128 MB
+// store in front of it.
+struct K3B {
+    const float* x4;      // (M, 4) normalised sample positions
+    float* gW0;           // (256, 3), row pitch ldg
+    int ldg;
+    float* gb0;           // (256)
+};
+
 // DGRAD = false: forward, weights stored [n][k], bias + ReLU;  DGRAD = true: weights stored [k][n], bf16-stored ReLU mask.
 // DEPTH = tiles in flight ahead of the multiply; the ring has DEPTH + 1 stages of 32 KB (A) [+ 32 KB (mask)].
-template <bool DGRAD, int DEPTH>
-__global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_block) {
+template <bool DGRAD, int DEPTH, bool K3W = false>
+__global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_block, K3B kb = K3B{}) {
+    static_assert(!K3W || DGRAD, "K3W is a dgrad form");
     asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast (csrc/layer_x6w.hip): nothing else is scheduled onto this SIMD beside the bf16 MFMA stream
     constexpr int NST = DEPTH + 1, STAGE = (DGRAD ? 2 : 1) * LY_TILE, PER_DMA = DGRAD ? 8 : 4;
-    __shared__ __attribute__((aligned(16))) uint4 lds[NST * STAGE];        // the only LDS object of the kernel
+    __shared__ __attribute__((aligned(16))) uint4 lds[NST * STAGE + (K3W ? NST * LY_ROWS : 0)];        // the only LDS object of the kernel (K3W: + the tiles' positions)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(g.M, rbeg + rows_per_block);
     if (rbeg >= rend) return;
@@ -101,13 +121,23 @@ __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_blo
             __builtin_amdgcn_global_load_lds(A16 + (size_t)gr * g.lda + c * 8, (lds_ptr_t)(st + inst * 64), 16, 0, 0);
             if (DGRAD) __builtin_amdgcn_global_load_lds(K16 + (size_t)gr * g.ldmask + c * 8, (lds_ptr_t)(st + LY_TILE + inst * 64), 16, 0, 0);
         }
+        if (K3W && wave == 0)           // the tile's 64 positions (16 B each): one more DMA instruction of wave 0, lane = row
+            __builtin_amdgcn_global_load_lds(kb.x4 + (size_t)min(r0 + lane, rend - 1) * 4, (lds_ptr_t)(lds + NST * STAGE + (t % NST) * LY_ROWS), 16, 0, 0);
     };
     // vector-memory instructions issued by this wave after the DMA of tile t, at the time tile t is needed (the DMA of tile
     // t + DEPTH is issued only after that wait): DMAs of tiles t+1 .. min(t+DEPTH-1, ntiles-1) and the stores (4 per tile) of
     // tiles max(0, t-DEPTH) .. t-1.  Anything counted here that was not actually issued would let the wait pass early.
+    float ks[K3W ? 2 : 1][K3W ? 8 : 1][4];      // K3W: running sums of column group qp, column c: (sum d x, sum d y, sum d z, sum d)
+    if (K3W) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { ks[a][c][0] = 0.f; ks[a][c][1] = 0.f; ks[a][c][2] = 0.f; ks[a][c][3] = 0.f; }
+    }
     for (int t = 0; t < DEPTH && t < ntiles; ++t) dma(t);
     for (int t = 0; t < ntiles; ++t) {
-        const int younger = PER_DMA * (min(t + DEPTH - 1, ntiles - 1) - t) + 4 * (t - max(0, t - DEPTH));
+        // (K3W: no stores; wave 0 issues a ninth DMA instruction per tile, the positions -- wait_vm_upto rounds down to a multiple of four, which only waits longer)
+        const int younger = (PER_DMA + ((K3W && wave == 0) ? 1 : 0)) * (min(t + DEPTH - 1, ntiles - 1) - t) + (K3W ? 0 : 4 * (t - max(0, t - DEPTH)));
         wait_vm_upto(younger);                                              // this wave's part of tile t has landed
         __builtin_amdgcn_s_barrier();                                        // ... and everyone's; everyone is done reading stage (t-1) % NST
         asm volatile("" ::: "memory");
@@ -141,6 +171,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_blo
                          : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
                          : "memory");
         }
+        f32x4k px0, px1;
+        if (K3W) {                           // this lane's two rows' positions, from the tile's position slot (inline asm for the reason given at the mask reads)
+            const unsigned pa = (unsigned)(uintptr_t)(lds_ptr_t)(lds + NST * STAGE + (t % NST) * LY_ROWS + li);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(px0), "=&v"(px1) : "v"(pa) : "memory");
+        }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int m = r0 + 32 * x + li;
@@ -167,10 +202,65 @@ __global__ __launch_bounds__(512, 2) void k_layer_bf16(GemmP g, int rows_per_blo
                     o.x = keep_positive(o.x, k4.x); o.y = keep_positive(o.y, k4.y);
                     o.z = keep_positive(o.z, k4.z); o.w = keep_positive(o.w, k4.w);
                 }
-                if (m < rend) *reinterpret_cast<uint4*>(C16 + (size_t)m * g.ldc + 32 * wave + 8 * (2 * qp + lh)) = o;
+                if (K3W) {
+                    if (m < rend) {              // rows past the range are copies of its last row: they count for nothing
+                        const f32x4k p = x ? px1 : px0;
+                        const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned u = ow[c >> 1];
+                            const float d = __uint_as_float((c & 1) ? (u & 0xffff0000u) : (u << 16));
+                            ks[qp][c][0] = fmaf(d, p[0], ks[qp][c][0]); ks[qp][c][1] = fmaf(d, p[1], ks[qp][c][1]);
+                            ks[qp][c][2] = fmaf(d, p[2], ks[qp][c][2]); ks[qp][c][3] += d;
+                        }
+                    }
+                } else if (m < rend) *reinterpret_cast<uint4*>(C16 + (size_t)m * g.ldc + 32 * wave + 8 * (2 * qp + lh)) = o;
             }
         }
     }
+    if (K3W) {
+        // fold the 32 rows (lanes li) of each half-wave; lane li == 0 of a half then holds the block's sums of its 2 x 8 columns
+        float* const gw = grad_target(kb.gW0);
+        float* const gb = grad_target(kb.gb0);
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = ks[qp][c][e];
+#pragma unroll
+                    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                    ks[qp][c][e] = v;
+                }
+                if (li == 0) {
+                    const int n = 32 * wave + 8 * (2 * qp + lh) + c;
+                    unsafeAtomicAdd(gw + (size_t)n * kb.ldg + 0, ks[qp][c][0]);
+                    unsafeAtomicAdd(gw + (size_t)n * kb.ldg + 1, ks[qp][c][1]);
+                    unsafeAtomicAdd(gw + (size_t)n * kb.ldg + 2, ks[qp][c][2]);
+                    if (gb) unsafeAtomicAdd(gb + n, ks[qp][c][3]);
+                }
+            }
+    }
+}
+
+// Backward of the first TWO layers of an xyz head in bf16 mode, the part behind the second layer's weight gradient (ABI 16): dH2 (M, ldd)
+// bf16-stored, W1 (256, 256) fp32 [k = output of layer 1 ... stored (out, in) = the dgrad's [k][n]], h1 (M, ldm) bf16-stored first activation (the
+// ReLU mask), x4 (M, 4) positions: gW0 (256, ldg) += ((h1 > 0) . bf16(dH2 W1))^T x4[:, :3], gb0 += its column sums.  dH1 is never written.
+extern "C" int clift_xyz_head_first2_bf16_bwd(const void* dH2, int ldd, const float* W1, int ldw1, const void* h1, int ldm, const float* x4, int M,
+                                              float* gW0, int ldg, float* gb0, clift_stream_t s) {
+    if (M <= 0) return 0;
+    CLIFT_REQUIRE(ldd % 8 == 0 && ldm % 8 == 0 && ldd >= 256 && ldm >= 256 && ldw1 >= 256 && ldg >= 3, "clift_xyz_head_first2_bf16_bwd: pitches (bf16 rows: multiples of 8, >= 256)");
+    CLIFT_REQUIRE(((((uintptr_t)dH2) | ((uintptr_t)h1) | ((uintptr_t)x4)) & 15) == 0, "clift_xyz_head_first2_bf16_bwd: 16-byte aligned dH2 / h1 / x4 required");
+    GemmP p = {};
+    p.M = M; p.N = 256; p.K = 256; p.A = reinterpret_cast<const float*>(dH2); p.lda = ldd; p.B = W1; p.ldb = ldw1;
+    p.mask = reinterpret_cast<const float*>(h1); p.ldmask = ldm;
+    K3B kb = {x4, gW0, ldg, gb0};
+    const int tiles = cdiv(M, LY_ROWS);
+    const int blocks = tiles < clift_persistent_cus() ? tiles : clift_persistent_cus();
+    const int rpb = cdiv(cdiv(M, blocks), 32) * 32;
+    k_layer_bf16<true, 1, true><<<blocks, 512, 0, as_stream(s)>>>(p, rpb, kb);
+    return clift_check_launch("clift_xyz_head_first2_bf16_bwd");
 }
 
 // Eligibility is decided by the caller (gemm_bf16.hip): N = K = 256, plain A, bf16-stored A / C (/ mask), 16-byte-aligned rows.

@@ -307,6 +307,7 @@ def first2(M, xa, W0, b0, W1, b1, h1, h2):
 # the independent tiled kernels for every layer instead (the cross-check the tests use).
 APP_SCATTER_XA = True       # tests clear it: clift_app_gather_bwd without the forward's positions (xa = NULL: the lane-per-(plane, channel) walk)
 DENS_BWD_SIGMA = True       # tests clear it: clift_density_bwd without the forward's sigma (sigma = NULL: the softplus derivative re-summed)
+FIRST2_BF16_BWD_FUSED = True  # tests clear it: bf16 mode, the second layer's input gradient written and the K = 3 layer's weight gradient as its own launch
 OUT_BWD_BF16_FUSED = True   # tests clear it: bf16 mode, output layer's weight gradient and masked input gradient as two passes over the hidden activation
 COMPOSITE_ACT_FUSED = True  # tests clear it: the heads' output activations taken back by clift_rows_act_bwd launches after the compositing backward
 APP_OUT_BWD_FUSED = True    # tests clear it: the appearance output layer's weight gradient and masked input gradient as two passes over the hidden activation
@@ -484,6 +485,14 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
             else:
                 wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
             (first2_x6_bwd if x6_ends else first2_bwd)(M, d, W, layers[0][0], layers[0][1], xa, *glayers[0])
+            return
+        if (li == 1 and MLP_PRECISION == 1 and FIRST2_BF16_BWD_FUSED and h is not None and h.dtype == torch.bfloat16 and d.dtype == torch.bfloat16
+                and no == 256 and ni == 256 and tuple(layers[0][0].shape) == (256, 3) and d.shape[1] == 256 and h.shape[1] == 256 and M >= 4096
+                and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+            # bf16 mode, second layer: its weight gradient, then its input gradient formed and consumed by the K = 3 layer's weight gradient in one launch
+            wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
+            call("clift_xyz_head_first2_bf16_bwd", ptr(d), 256, ptr(W), _pitch(W), ptr(h), 256, ptr(xa), M, ptr(glayers[0][0]), _pitch(glayers[0][0]),
+                 ptr(glayers[0][1]), stream())
             return
         dn = torch.empty((M, ni), dtype=act_dtype(), device=dev)        # bf16 mode: hidden gradients are bf16-stored as well
         if (li == n - 1 and ni == 256 and no <= 32 and d.shape[1] <= 32 and d.shape[1] % 4 == 0 and M >= 4096 and

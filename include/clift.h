@@ -264,6 +264,12 @@ int clift_xyz_head_first2_fwd(const float* x4, const float* W0, int ldw0, const 
 int clift_xyz_head_first2_x6_fwd(const float* x4, const float* W0, int ldw0, const float* b0, const float* W1, int ldw1,
                                  const float* b1, int M, float* h2, int ldh2, void* sign_bits /* nullable, see clift_gemm_t (ABI 15) */,
                                  clift_stream_t s);
+/* Backward of the first TWO layers of an xyz head in bf16 mode, the part behind the second layer's weight gradient (ABI 16; the bf16 counterpart
+ * of clift_xyz_head_first2_bwd, tensoRF.py:475-478, 576-579): dH2 (M, ldd) and the first activation h1 (M, ldm; the ReLU mask) bf16-STORED, W1
+ * (256, 256) and the positions x4 (M, 4) fp32.  gW0 (256, ldg) += ((h1 > 0) . bf16(dH2 W1))^T x4[:, :3], gb0 += its column sums: the second
+ * layer's input gradient is formed, rounded to bf16 and masked exactly as clift_gemm would store it, and consumed in the kernel -- never written. */
+int clift_xyz_head_first2_bf16_bwd(const void* dH2, int ldd, const float* W1, int ldw1, const void* h1, int ldm, const float* x4, int M,
+                                   float* gW0, int ldg, float* gb0, clift_stream_t s);
 /* The fp32x6 counterparts of the three fused ends of an xyz head's backward / forward (ABI 14; csrc/layer_x6.hip, csrc/layer_x6w.hip): the
  * 256 x 256 products as six bf16 products per fp32 product of exactly three-way-split operands (fp32 accumulate; within 1e-6 row-max relative
  * of the exact-fp32 entry points they mirror), everything narrow -- the K = 3 layer, the ReLU masks, the E <= 4 output layer -- in exact fp32.

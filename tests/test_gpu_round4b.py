@@ -296,3 +296,37 @@ def test_other_component_and_class_counts_against_the_oracle(comps, C_):
         grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-3,
                    outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-2 if k.startswith("appearance_basis") else 1e-3),
                    outlier_cap=1e-2)
+
+
+@pytest.mark.parametrize("M", [4096, 4101, 62003, 249001])
+def test_first2_bf16_bwd_against_the_pair_of_launches_and_fp64(M):
+    """clift_xyz_head_first2_bf16_bwd (bf16 mode): the second layer's input gradient formed, rounded to bf16, masked and consumed by the K = 3 layer's
+    weight / bias gradient in one launch, against (a) the masked bf16 dgrad launch + clift_linear_k3_bwd over its bf16-stored result -- the same
+    products, another summation order -- and (b) float64 over the same bf16-rounded dH1."""
+    from conftest import rel_close
+    from contrastive_lift_amd import engine
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(M)
+    d = (torch.randn(M, 256, generator=g) / 8).to(torch.bfloat16).to(DEV)
+    h1 = torch.relu(torch.randn(M, 256, generator=g)).to(torch.bfloat16).to(DEV)
+    W1 = (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    xa = torch.cat([torch.rand(M, 3, generator=g) * 2 - 1, torch.zeros(M, 1)], 1).contiguous().to(DEV)
+    gW, gb = torch.full((256, 4), 0.5, device=DEV), torch.full((256,), -0.25, device=DEV)
+    call("clift_xyz_head_first2_bf16_bwd", ptr(d), 256, ptr(W1), 256, ptr(h1), 256, ptr(xa), M, ptr(gW), 4, ptr(gb), stream())
+    # the pair
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        dn = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
+        engine.gemm(M, 256, 256, d, 256, W1, 256, dn, 256, b_trans=1, mask=h1, ldmask=256)
+        gW2, gb2 = torch.full((256, 4), 0.5, device=DEV), torch.full((256,), -0.25, device=DEV)
+        call("clift_linear_k3_bwd", ptr(xa), ptr(dn), 256, M, 256, ptr(gW2), 4, ptr(gb2), 1, stream())
+    finally:
+        engine.set_mlp_precision(prev)
+    torch.cuda.synchronize()
+    dn64 = dn.double().cpu()
+    ref_w = dn64.T @ xa[:, :3].double().cpu() + 0.5
+    ref_b = dn64.sum(0) - 0.25
+    for name, w_, b_ in (("fused", gW, gb), ("pair", gW2, gb2)):
+        rel_close(w_[:, :3], ref_w, 2e-5, atol=2e-5 * float((ref_w - 0.5).abs().max()) + 1e-6, what=f"{name} gW0")
+        rel_close(b_, ref_b, 2e-5, atol=2e-5 * float((ref_b + 0.25).abs().max()) + 1e-6, what=f"{name} gb0")
+    assert bool((gW[:, 3] == 0.5).all())
