@@ -637,7 +637,7 @@ def _check_rays(rays, jitter):
 
 
 def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_sem=True, want_inst=True, grad_heads=("app", "sem", "fast", "slow"),
-                   cap=None):
+                   cap=None, want_dist=True):
     """Full renderer.forward (reference renderer.py:80-176).  Returns dict of outputs and the backward context.
     ``grad_heads``: the heads a backward pass may be run through ("app", "sem", "fast", "slow"); a head that is not named retains
     no activations (the training main pass never differentiates the instance heads, T:155; inference none)."""
@@ -764,7 +764,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
     ctx.rgb_raw, ctx.sem_raw = rgb_raw, sem_raw
     ctx.want = (want_rgb, want_sem, D > 0)
     out = dict(rgb=rgb_map, semantics=sem_map, instances=inst_map, depth=ctx.ray_out[:, 1],
-               dist_reg=ctx.ray_out[:, 5].mean(), opacity=ctx.ray_out[:, 0])
+               dist_reg=ctx.ray_out[:, 5].mean() if want_dist else None, opacity=ctx.ray_out[:, 0])     # (the trainer never reads the VALUE of the regulariser)
     return out, ctx
 
 
@@ -947,7 +947,7 @@ def _density_backward(model, ctx, views, gviews, g_w, g_op, g_dist, keep):
 
 
 # ----------------------------------------------------------------------------- instance / segment feature passes
-def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem", "fast", "slow"), cap=None):
+def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem", "fast", "slow"), cap=None, want_xyz=True):
     """renderer.py:178-217 (head='instance') / :259-300 (head='semantic'): density and weights carry no gradient,
     only the head does.  ``grad_heads`` as in render_forward."""
     rays, jitter = _check_rays(rays, jitter)
@@ -996,7 +996,8 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
     ctx.sem_raw = sem_raw
     ctx.want = (False, head == "semantic", head == "instance")
     if head == "instance":
-        xyz = rays[:, 0:3] + ctx.ray_out[:, 1:2] * rays[:, 3:6]      # renderer.py:213-215
+        # renderer.py:213-215 (the trainer asks for the points only where its loss reads them: two elementwise launches otherwise unused)
+        xyz = rays[:, 0:3] + ctx.ray_out[:, 1:2] * rays[:, 3:6] if want_xyz else None
         return (inst_map, xyz), ctx
     return sem_map, ctx
 

@@ -335,7 +335,7 @@ class HotPathTrainer:
                 wb = bool(white_bg)
             n_c = min(chunk, B - i)
             o, ctx = engine.render_forward(m, r, rays[i:i + chunk], None if jitter is None else jitter[i:i + chunk], wb,
-                                           want_inst=not lean, grad_heads=("app", "sem"),        # T:155: the instance output is discarded
+                                           want_inst=not lean, grad_heads=("app", "sem"), want_dist=False,        # T:155: the instance output is discarded
                                            cap=self._capacity("main", n_c))
             self._follow("main", n_c, ctx)
             ctxs.append(ctx)
@@ -448,7 +448,8 @@ class HotPathTrainer:
                 if c.perturb != 1:
                     jit = c.perturb * jit
             (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",),     # slow half: detached (T:268)
-                                                      cap=self._capacity("inst", n))
+                                                      cap=self._capacity("inst", n),
+                                                      want_xyz=c.instance_loss_mode == "contrastive" and bool(getattr(c, "use_delta", False)))
             self._follow("inst", n, ctx)
             if c.instance_loss_mode == "slow_fast":
                 # reference order: the features (fast and slow halves) are rendered first (T:214), THEN the EMA step of the slow
@@ -469,7 +470,7 @@ class HotPathTrainer:
                     nrm = torch.linalg.norm(inst, dim=-1, keepdim=True)
                     loss = loss + 0.1 * nrm.mean()
                     g_inst = g_inst + 0.1 * inst / (nrm.clamp_min(1e-30) * inst.shape[0])
-            self.losses[3] = self.losses[3] + loss
+            self.losses[3:4].add_(loss.reshape(1))
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
         if self.nosync:
             engine.reset_rows_limit(self.device)
