@@ -185,6 +185,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     // ... and used at k-step 8 + p (after that step's lgkmcnt(0)): 4 FMAs
     auto outv_fma = [&](int p_) {
         const int q = p_ >> 2, c = p_ & 3;
+        // (a volatile statement BEHIND the k-step's lgkmcnt(0) that the fragment passes through: without it nothing orders these FMAs after the
+        // wait -- the wait names only the MFMA fragment -- and the compiler did hoist three of the four above it, where only the latency of the
+        // previous step's MFMAs stood between the ds_read and its use; tools/isa_asm_load_check.py, round 5)
+        asm volatile("" : "+v"(wv[p_ & 1]) : : "memory");
         const f32x4 wq = wv[p_ & 1];
         pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
         asm volatile("" : "+v"(pv));               // (pins the arithmetic to its k-step; otherwise it is sunk to the end of the tile and the reads pile up in registers: spills)
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     };
     // ... step 5 (k-step 28): add them up in a fixed order, add the bias, store
     auto outv_store = [&](int tile) {
+        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");          // (as in outv_fma: the shares are consumed behind the wait that publishes them)
         if (lane < 16) {
             const int c = lane & 3, mrow = rbeg + tile * LF_ROWS + 4 * wave + (lane >> 2);
             const float v = ((wv[0][0] + wv[0][1]) + (wv[0][2] + wv[0][3])) + ((wv[1][0] + wv[1][1]) + (wv[1][2] + wv[1][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);

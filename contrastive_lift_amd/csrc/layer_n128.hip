@@ -119,6 +119,9 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int p_ = 2 * s_ + u, q = p_ >> 2, c = p_ & 3;
+            // (a volatile statement BEHIND the k-step's lgkmcnt(0) that the fragment passes through: the wait itself names only the MFMA fragment, so
+            // nothing else orders these FMAs after it -- layer_f32.hip's twin of this code was found with three of four FMAs hoisted above the wait)
+            asm volatile("" : "+v"(wv[s_ & 1][u]) : : "memory");
             const f32x4 wq = wv[s_ & 1][u];
             pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
         }
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
             asm volatile("ds_read_b32 %0, %1" : "=v"(wv[0][0][w4]) : "v"(b + (unsigned)(w4 * 32 * 16)) : "memory");
     };
     auto outv_store = [&](int tile) {
+        asm volatile("" : "+v"(wv[0][0]) : : "memory");                     // (as in outv_fma: the shares are consumed behind the wait that publishes them)
         if (lane < 32) {
             const int c = lane & 3, mrow = rbeg + tile * LN_ROWS + 8 * wave + (lane >> 2);
             const float v = ((wv[0][0][0] + wv[0][0][1]) + (wv[0][0][2] + wv[0][0][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);

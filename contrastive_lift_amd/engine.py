@@ -313,6 +313,7 @@ COMPOSITE_ACT_FUSED = True  # tests clear it: the heads' output activations take
 APP_OUT_BWD_FUSED = True    # tests clear it: the appearance output layer's weight gradient and masked input gradient as two passes over the hidden activation
 APP_FRONT_FUSED = True      # tests clear it: appearance gather, basis GEMM and input encoding as three launches (the form the fused front end replaced)
 KEEP_FIRST_ACT = False      # tests set this to compare against the stored-activation backward (masked dgrad + K = 3 weight gradient)
+SOAK_KEEP = False           # tools/determinism_soak.py sets it: a forward that retains nothing still leaves REFERENCES to the appearance chain's intermediates in ctx.soak
 FUSE_HEAD_BF16 = True       # bf16 mode: first three layers (+ E <= 4 output layer) of an xyz head in one launch; tests clear it to compare with the per-layer launches
 
 
@@ -715,6 +716,8 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                 call("clift_rows_act_fwd", ptr(pre), 3, M, 3, 1, ptr(rgb_s), 3, stream())
                 keep.append(pre)
             ctx.rgb_s = rgb_s
+            if SOAK_KEEP:
+                ctx.soak = dict(feat=feat, X=X, H1=H1)
             if "app" in grad_heads:
                 ctx.feat, ctx.ldf, ctx.nf, ctx.X, ctx.ldx, ctx.H1, ctx.H2 = feat, ldf, nf, X, ldx, H1, H2
             else:

@@ -52,3 +52,25 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle"
+
+
+def test_in_flight_register_guard():
+    """tools/isa_asm_load_check.py (run by csrc/Makefile on every object's device listing; the build fails on a violation): the checker itself
+    flags a consumer scheduled above the wait that publishes a hand-issued load, and every listing of the current build is clean."""
+    import glob
+    import subprocess
+    import sys
+    import tempfile
+    tool = os.path.join(REPO, "tools", "isa_asm_load_check.py")
+    bad = "\n".join(["_Z1kv:", "\t;;#ASMSTART", "\tds_read_b128 v[4:7], v1", "\t;;#ASMEND", "\tv_fmac_f32_e32 v9, v2, v5",
+                     "\t;;#ASMSTART", "\ts_waitcnt lgkmcnt(0)", "\t;;#ASMEND", "\tv_fmac_f32_e32 v9, v2, v6", ""])
+    good = bad.replace("\tv_fmac_f32_e32 v9, v2, v5\n", "")
+    with tempfile.TemporaryDirectory() as d:
+        for name, text, rc in (("bad.s", bad, 1), ("good.s", good, 0)):
+            p = os.path.join(d, name)
+            open(p, "w").write(text)
+            r = subprocess.run([sys.executable, tool, p], capture_output=True, text=True)
+            assert r.returncode == rc, (name, r.stdout)
+    for s in glob.glob(os.path.join(REPO, "contrastive_lift_amd", "csrc", ".isa", "*.s")):
+        r = subprocess.run([sys.executable, tool, s], capture_output=True, text=True)
+        assert r.returncode == 0, (s, r.stdout[-2000:])
