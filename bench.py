@@ -89,7 +89,7 @@ def self_launch(a):
 def launch_check(a, world, rank):
     """The launcher path alone: process group + one collective, no render work (CPU-runnable)."""
     backend = os.environ.get("CLIFT_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
-    total = 1.0
+    total, check = 1.0, None
     if world > 1:
         if backend == "nccl":
             local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -101,9 +101,15 @@ def launch_check(a, world, rank):
             t = torch.ones(1)
         dist.all_reduce(t)
         total = float(t.item())
+        # the self-check's comparison across ranks (data_parallel_self_check), on tensors whose answer is known: equal on every rank / not
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        same = torch.arange(1000, dtype=torch.float32)
+        check = {"identical_tensor_delta": max_delta_across_ranks(same, cdev),
+                 "rank_dependent_tensor_delta": max_delta_across_ranks(same + (rank == world - 1) * (same == 7.0), cdev)}
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "requested_gpus": a.gpus, "dist_backend": backend if world > 1 else None,
-                          "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else 0), "allreduce_of_ones": total}))
+                          "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else 0), "allreduce_of_ones": total,
+                          "self_check_primitive": check}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -304,7 +310,7 @@ def main():
     sub = [x for x in rec_all if dom_sel(x[0], x[2])]
     if len(sub) == len(rec) and all(same(x, y) for x, y in zip(rec, sub)):
         rec = [x[:4] + (min(x[4], y[4]),) + x[5:] for x, y in zip(rec, sub)]
-    ar_ms, rank_ms = None, None
+    ar_ms, rank_ms, dp_check = None, None, None
     if world > 1:
         cdev = dev if backend == "nccl" else "cpu"
         t = torch.tensor([dt, -dt], device=cdev, dtype=torch.float64)
@@ -322,6 +328,7 @@ def main():
         e1.record(); sync_all()
         ar_ms = {"main_range_bytes": 4 * (r1 - r0), "ms": e0.elapsed_time(e1) / 5, "backend": backend,
                  "note": "one all-reduce of the main pass's gradient range alone (no compute beside it), mean of 5"}
+        dp_check = data_parallel_self_check(tr, model, batches[0], snap, a.lean, cdev, sync_all)
     ms_step = dt / a.steps * 1e3
     samples_step = world * (a.rays + a.inst_rays) * S
     value = samples_step / (dt / a.steps)
@@ -403,11 +410,63 @@ def main():
                 "devices_visible": torch.cuda.device_count(),
                 "allreduce_overlap": (tr.overlap_decision or {"overlap": tr.overlap_allreduce}) if world > 1 else None,
                 "allreduce_cu_reserve": tr.allreduce_cu_reserve if world > 1 else None,
-                "allreduce_ms": ar_ms, "rank_ms_per_step_min_max": rank_ms}
+                "allreduce_ms": ar_ms, "rank_ms_per_step_min_max": rank_ms, "data_parallel_self_check": dp_check}
         line.update(extra)
         line["step_ms_median"] = step_ms[len(step_ms) // 2]
         line["step_ms_min_max"] = [step_ms[0], step_ms[-1]]
         print(json.dumps(line))
+
+
+def max_delta_across_ranks(t, cdev):
+    """max over the elements of (MAX over ranks - MIN over ranks) of a tensor every rank holds: 0.0 iff all ranks hold the same values."""
+    import torch.distributed as dist
+    hi, lo = t.to(cdev).clone(), t.to(cdev).clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float((hi - lo).abs().max())
+
+
+def data_parallel_self_check(tr, model, batch, snap, lean, cdev, sync_all):
+    """N > 1 only: is the exchange CORRECT under the real collective, not only fast?
+    * `param_max_abs_delta_across_ranks`: after all the steps of this run, element-wise MAX and MIN of the flat parameter arena over the ranks
+      (two all-reduces); every rank applied the same all-reduced gradients to the same initial state, so the difference must be exactly 0.
+    * `overlap_grad`: from the snapshot of the timed region, the main pass of one step with the asynchronous exchange (early range all-reduced
+      beside the density backward, CUs reserved for the collective) and with the synchronous one, same batch / jitter / background; the
+      all-reduced gradients are compared.  A rank's own sums go through floating-point atomics, so two passes differ in the last bits even
+      with the same setting: the same-setting difference is measured too and `equal` means 'no further than 10 x that noise (floor 1e-6 of
+      the largest gradient entry)'.  The verdicts are MAX-reduced over the ranks."""
+    import torch.distributed as dist
+    out = {}
+    out["param_max_abs_delta_across_ranks"] = max_delta_across_ranks(model.param_flat.detach(), cdev)
+    out["params_identical_across_ranks"] = out["param_max_abs_delta_across_ranks"] == 0.0
+    r0, r1 = tr.main_range
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    jit = torch.rand(batch[0]["rays"].shape[0], generator=g).to(model.param_flat.device)
+    keep = tr.overlap_allreduce
+
+    def grads(overlap):
+        with torch.no_grad():
+            model.param_flat.copy_(snap[0])
+        tr.opt_main.load_state_dict(snap[1])
+        tr.opt_inst.load_state_dict(snap[2])
+        tr.overlap_allreduce = overlap
+        tr.main_pass(batch[0], jitter=jit, white_bg=False, lean=lean)
+        sync_all()
+        return model.grad_flat[r0:r1].detach().clone()
+    try:
+        g_sync, g_sync2, g_over = grads(False), grads(False), grads(True)
+    finally:
+        tr.overlap_allreduce = keep
+    scale = max(float(g_sync.abs().max()), 1e-30)
+    noise = float((g_sync - g_sync2).abs().max()) / scale
+    delta = float((g_sync - g_over).abs().max()) / scale
+    t = torch.tensor([noise, delta], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    noise, delta = float(t[0]), float(t[1])
+    out["overlap_grad"] = {"max_abs_delta_over_max_entry": delta, "same_setting_noise": noise, "equal": bool(delta <= max(10.0 * noise, 1e-6)),
+                           "finite": bool(torch.isfinite(g_over).all())}
+    out["overlap_grad_equal"] = out["overlap_grad"]["equal"] and out["overlap_grad"]["finite"]
+    return out
 
 
 MLP_ARITHMETIC = {

@@ -290,6 +290,21 @@ int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits,
         p.lda % 4 == 0 && p.M >= 4096 && splits == 1 && !p.accumulate && !p.c_trans && !p.bias && p.act == 0 && p.ldc % 4 == 0 && p.ldmask % 4 == 0 &&
         ((((uintptr_t)p.C) | ((uintptr_t)p.mask)) & 7) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr)
         return clift_dgrad_narrow_stream_launch(p, 1, st);          // output-layer dgrad with bf16-stored mask / result (fp32 products: exact)
+    // the 128-wide appearance MLP with bf16-stored streams (layer_nb16.hip): forward K = 160 / 128 -> 128 (bias, ReLU), masked input gradient
+    // 128 -> 128, unmasked input gradient 128 -> 160 (bf16- or fp32-stored result), weight gradients 128 x {128, 160}
+    if (!a_trans && p.a_bf16 && splits == 1 && !p.accumulate && !p.c_trans && p.lda % 8 == 0 && p.lda >= p.K && (((uintptr_t)p.A) & 15) == 0 &&
+        p.ldb % 4 == 0 && (((uintptr_t)p.B) & 15) == 0 && (((uintptr_t)p.C) & 15) == 0 && p.M >= 64 && getenv("CLIFT_NO_PERSISTENT") == nullptr) {
+        const bool fwd = !b_trans && p.N == 128 && (p.K == 128 || p.K == 160) && p.c_bf16 && p.ldc % 8 == 0 && p.ldc >= 128 && !p.mask && p.ldb >= p.K;
+        const bool dg_m = b_trans && p.N == 128 && p.K == 128 && p.c_bf16 && p.ldc % 8 == 0 && p.ldc >= 128 && p.mask && p.mask_bf16 && p.ldmask % 8 == 0 &&
+                          p.ldmask >= 128 && (((uintptr_t)p.mask) & 15) == 0 && !p.bias && p.act == 0 && p.ldb >= 128;
+        const bool dg_u = b_trans && p.N == 160 && p.K == 128 && !p.mask && !p.bias && p.act == 0 && p.ldb >= 160 && p.ldc >= 160 &&
+                          (p.c_bf16 ? p.ldc % 8 == 0 : p.ldc % 4 == 0);
+        if (fwd || dg_m || dg_u) return clift_layer_nb16_launch(p, b_trans, st);
+    }
+    if (a_trans && b_trans && p.M == 128 && (p.N == 128 || p.N == 160) && p.K >= 64 && p.a_bf16 && p.b_bf16 && p.accumulate && !p.c_trans && !p.bias && !p.mask &&
+        p.lda % 8 == 0 && p.lda >= 128 && p.ldb % 8 == 0 && p.ldb >= p.N && p.ldc >= p.N && ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) == 0 &&
+        getenv("CLIFT_NO_PERSISTENT") == nullptr)
+        return clift_wgrad_nb16_launch(p, st);
     if (p.N > 128) return launch_gemm_h<128, 256, 2, 4>(p, a_trans, b_trans, splits, st);
     if (p.N > 32) return launch_gemm_h<128, 128, 2, 2>(p, a_trans, b_trans, splits, st);
     return launch_gemm_h<256, 32, 4, 1>(p, a_trans, b_trans, splits, st);

@@ -41,6 +41,8 @@ static inline bool gemm_vector_epilogue_ok(const GemmP& p) {
 int clift_gemm_bf16_launch(const GemmP& p, int a_trans, int b_trans, int splits, hipStream_t st);   // gemm_bf16.hip
 int clift_layer_bf16_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_bf16.hip
 int clift_wgrad_bf16_stream_launch(const GemmP& p, hipStream_t st);
+int clift_layer_nb16_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_nb16.hip
+int clift_wgrad_nb16_launch(const GemmP& p, hipStream_t st);
 int clift_layer_f32_launch(const GemmP& p, int b_trans, hipStream_t st);                             // layer_f32.hip
 int clift_layer_n128_launch(const GemmP& p, int b_trans, hipStream_t st);                            // layer_n128.hip
 int clift_wgrad_n128_stream_launch(const GemmP& p, hipStream_t st);

@@ -564,7 +564,7 @@ template <int COMPS>
 __global__ __launch_bounds__(512) void k_app_front_fwd(MarchP m, VmP t, const float* __restrict__ rays, const float* __restrict__ jitter,
                                                         const int* __restrict__ act, int M, const float* __restrict__ Wb, int ldb, int nf,
                                                         int pef, int pev, float* __restrict__ xa, float* __restrict__ feat,
-                                                        float* __restrict__ X, int ldx, float* __restrict__ F) {
+                                                        float* __restrict__ X, int ldx, float* __restrict__ F, int x_bf16) {
     constexpr int C = COMPS, NC = 3 * C, G4 = C / 4, FS = 4 * ((NC / 4) | 1), KS = NC / 4;      // KS: MFMA steps (= weights) per lane
     static_assert(C % 16 == 0 && KS % 4 == 0, "the k quarters of phase 2 are read 16 bytes at a time");
     extern __shared__ __attribute__((aligned(16))) float af_lds[];
@@ -713,6 +713,15 @@ __global__ __launch_bounds__(512) void k_app_front_fwd(MarchP m, VmP t, const fl
     }
     __syncthreads();
     // ---------------- phase 4
+    if (x_bf16) {           // bf16 mode: the MLP input is bf16-STORED (ldx even: two columns per lane)
+        for (int r = wave; r < rows; r += 8) {
+            unsigned* dst = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(X) + (size_t)(s0 + r) * ldx);
+            const float* src = big + r * XS;
+            for (int c = lane; 2 * c < ldx; c += 64)
+                dst[c] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)src[2 * c]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)src[2 * c + 1]) << 16);
+        }
+        return;
+    }
     for (int r = wave; r < ((AF_ABL & 8) ? 1 : rows); r += 8) {
         float* dst = X + (size_t)(s0 + r) * ldx;
         const float* src = big + r * XS;
@@ -723,6 +732,14 @@ __global__ __launch_bounds__(512) void k_app_front_fwd(MarchP m, VmP t, const fl
 extern "C" int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
                                    int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, float* X,
                                    int ldx, float* F, clift_stream_t s) {
+    return clift_app_front_fwd_x(h_m, h_app, rays, jitter, act_idx, M, Wb, ldb, nf, pe_feat, pe_view, xa, feat, ldf, X, ldx, F, 0, s);
+}
+
+// ... with the choice of X's storage: x_bf16 = 1 writes X as (M, ldx) bf16 (bf16 mode, ABI 17); everything else as above.
+extern "C" int clift_app_front_fwd_x(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
+                                     int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, void* Xv,
+                                     int ldx, float* F, int x_bf16, clift_stream_t s) {
+    float* X = reinterpret_cast<float*>(Xv);
     const int C = h_app->comps, nc = 3 * C;
     CLIFT_REQUIRE(C == 16 || C == 32 || C == 48, "clift_app_front_fwd: comps must be 16, 32 or 48 (got %d)", C);
     CLIFT_REQUIRE(nf >= 1 && nf <= AF_NF && ldf == AF_NF, "clift_app_front_fwd: 1 <= n_features <= %d, ldf == %d", AF_NF, AF_NF);
@@ -740,7 +757,7 @@ extern "C" int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h
         if (dyn > 48 * 1024)                                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_app_front_fwd<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);    \
         k_app_front_fwd<CC><<<grid, 512, dyn, st>>>(to_dev(h_m), to_dev(h_app), rays, jitter, act_idx, M, Wb, ldb, nf, pe_feat, pe_view, xa,  \
-                                                    feat, X, ldx, F);                                                                           \
+                                                    feat, X, ldx, F, x_bf16);                                                                  \
     } while (0)
     if (C == 48) CLIFT_AF(48);
     else if (C == 32) CLIFT_AF(32);

@@ -114,19 +114,19 @@ def exact_fp32():
     return _Precision(0)
 
 
-# bf16 mode: the 128-wide appearance MLP stays on the exact-fp32 persistent kernels (layer_n128.hip) -- they are FASTER than the tiled
-# bf16 kernels on these short-K layers (fp32 persistent ~0.76 ms vs bf16 tiled ~1.0 ms per step, profiles/r02_bf16_*), and it is the
-# more accurate choice.  The 256-wide xyz heads, where the bf16 streaming / fused kernels pay, run in bf16.
-
-
-
-
+# bf16 mode and the 128-wide appearance MLP.  Rounds 2 - 4 kept it on the exact-fp32 persistent kernels (layer_n128.hip): faster than the TILED bf16
+# kernels on these short-K layers, but bound by the fp32 matrix pipe (6 launches, 635 us of a 3.4 ms step).  Round 5: streaming bf16 kernels with
+# bf16-STORED input / hidden activations / hidden gradients (csrc/layer_nb16.hip), like the xyz heads of that mode.  Tests clear APP_BF16 to get the
+# old arrangement back.
+APP_BF16 = True
 
 
 def _app_precision():
     # fp32x6 (2): only the 256 x 256 layers have persistent split kernels; the 128-wide appearance layers would fall to the TILED split kernel
     # (gemm_split.hip), which is slower than the exact persistent kernels and -- seen with two processes sharing the GPU -- the one kernel of that
     # mode whose results were disturbed by the other process's fp32x6 launches (profiles/r03_x6_notes.txt).  Exact fp32 there.
+    if MLP_PRECISION == 1 and APP_BF16 and os.environ.get("CLIFT_NO_PERSISTENT") is None:
+        return _Precision(1)
     if MLP_PRECISION in (1, 2):
         return _Precision(0)
     return _Precision(MLP_PRECISION)
@@ -670,9 +670,11 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                 ldf = 28
                 F = torch.empty((M, nc), dtype=torch.float32, device=dev) if "app" in grad_heads else None
                 feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-                X = torch.empty((M, ldx), dtype=torch.float32, device=dev)
-                call("clift_app_front_fwd", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(Wb), _pitch(Wb), nf,
-                     model.pe_feat, model.pe_view, ptr(xa), ptr(feat), ldf, ptr(X), ldx, ptr(F), st)
+                with _app_precision():              # bf16 mode: the MLP's input rows leave the front end bf16-stored
+                    x_bf16 = MLP_PRECISION == 1 and ldx % 8 == 0
+                X = torch.empty((M, ldx), dtype=torch.bfloat16 if x_bf16 else torch.float32, device=dev)
+                call("clift_app_front_fwd_x", C.byref(ctx.ms), C.byref(va), ptr(rays), ptr(jitter), ptr(ctx.act_idx), M, ptr(Wb), _pitch(Wb), nf,
+                     model.pe_feat, model.pe_view, ptr(xa), ptr(feat), ldf, ptr(X), ldx, ptr(F), int(x_bf16), st)
                 front = (feat, ldf, X)
             else:
                 F = torch.empty((M, nc), dtype=torch.float32, device=dev)
@@ -696,7 +698,8 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             else:
                 ldf = (nf + 3) // 4 * 4
                 feat = torch.empty((M, ldf), dtype=torch.float32, device=dev)
-                gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
+                with exact_fp32():          # (the basis Linear is not one of the bf16 layers in any mode)
+                    gemm(M, nf, nc, ctx.F, nc, Wb, _pitch(Wb), feat, ldf)
                 X = torch.empty((M, ldx), dtype=hdt, device=dev)
                 call("clift_app_encode_fwd", ptr(feat), ldf, nf, model.pe_feat, model.pe_view, ptr(rays), ptr(ctx.act_idx), S, M,
                      ptr(X), ldx, int(hdt == torch.bfloat16), stream())
@@ -708,6 +711,12 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                 # second hidden layer + output layer + sigmoid in one launch; H2 is written only for a backward
                 H2 = torch.empty((M, 128), dtype=torch.float32, device=dev) if "app" in grad_heads else None
                 app_last2(M, H1, W2, b2, W3, b3, H2, rgb_s)
+            elif (MLP_PRECISION == 1 and hdt == torch.bfloat16 and H1.dtype == torch.bfloat16 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4
+                    and W3.shape[1] == 128 and M >= 64 and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+                # bf16 mode: the same pair of layers over the bf16-stored activation (csrc/layer_nb16.hip)
+                H2 = torch.empty((M, 128), dtype=torch.bfloat16, device=dev) if "app" in grad_heads else None
+                call("clift_app_head_last2_bf16_fwd", ptr(H1), 128, ptr(W2), _pitch(W2), ptr(b2), ptr(W3), _pitch(W3), ptr(b3), W3.shape[0], M,
+                     ptr(H2), 128, ptr(rgb_s), 3, 1, stream())
             else:
                 H2 = torch.empty((M, W2.shape[0]), dtype=hdt, device=dev)
                 gemm(M, W2.shape[0], W2.shape[1], H1, H1.shape[1], W2, _pitch(W2), H2, H2.shape[1], bias=b2, act=1)
@@ -856,6 +865,11 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
                 # output layer: weight gradient and masked input gradient in one pass over the hidden activation (as in the xyz heads)
                 call("clift_out_layer_bwd_nh", ptr(dpre), 4, W3.shape[0], ptr(W3), _pitch(W3), ptr(H2), n2, n2, M, ptr(dH2), n2, ptr(gW3), _pitch(gW3),
                      ptr(gb3), 0, stream())
+            elif (APP_OUT_BWD_FUSED and MLP_PRECISION == 1 and H2.dtype == torch.bfloat16 and n2 == 128 and W3.shape[0] <= 4 and dpre.shape[1] == 4
+                    and _pitch(W3) >= 128 and _pitch(gW3) >= 128 and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+                # bf16 mode: the same one pass over the bf16-stored activation; the input gradient leaves bf16-stored
+                call("clift_out_layer_bwd_n128_bf16", ptr(dpre), 4, W3.shape[0], ptr(W3), _pitch(W3), ptr(H2), 128, M, ptr(dH2), 128, ptr(gW3), _pitch(gW3),
+                     ptr(gb3), stream())
             else:
                 wgrad(3, n2, M, dpre, 4, H2, n2, gW3, gb3)
                 gemm(M, n2, 3, dpre, 4, W3, _pitch(W3), dH2, n2, b_trans=1, mask=H2, ldmask=n2)
@@ -875,7 +889,8 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             call("clift_app_encode_bwd", ptr(ctx.feat), ldf, nf, model.pe_feat, ptr(dX), ldx, M, ptr(dfeat), ldf, stream())
             call("clift_wgrad_narrow", ptr(dfeat), ldf, nf, ptr(ctx.F), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
             dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
-            gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
+            with exact_fp32():              # (the basis Linear is not one of the bf16 layers in any mode)
+                gemm(M, nc, nf, dfeat, ldf, Wb, _pitch(Wb), dF, nc, b_trans=1)
             call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(va), C.byref(ga), ptr(ctx.rays), ptr(ctx.jitter),
                  ptr(ctx.act_idx), M, ptr(dF), ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
             vm_grad_finish(model, gviews, "appearance", ga)

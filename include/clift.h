@@ -185,6 +185,11 @@ int clift_app_encode_bwd(const float* feat, int ldf, int nf, int pe_feat, const 
 int clift_app_front_fwd(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
                         int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, float* X,
                         int ldx, float* F, clift_stream_t s);
+/* ... with the choice of X's storage (ABI 17): x_bf16 = 1 writes X as (M, ldx) bf16, ldx even (bf16 mode: the appearance MLP's input is bf16-stored
+ * like every other streamed activation of that mode); x_bf16 = 0 is clift_app_front_fwd. */
+int clift_app_front_fwd_x(const clift_march_t* h_m, const clift_vm_t* h_app, const float* rays, const float* jitter, const int* act_idx,
+                          int M, const float* Wb, int ldb, int nf, int pe_feat, int pe_view, float* xa, float* feat, int ldf, void* X,
+                          int ldx, float* F, int x_bf16, clift_stream_t s);
 
 /* ---- nn.Linear building block on the matrix cores (tensoRF.py:65,393-397,475-491,576-582 and their
  * backward).  C[m][n] (+)= act( sum_k A(m,k) * B(n,k) + bias[n] ) * (mask[m][n] > 0)
@@ -318,6 +323,17 @@ int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, c
 int clift_app_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
                              const float* bout, int E, int M, float* hidden, int ldh, float* pre, int ldp, float* out, int ldo,
                              int sigmoid, clift_stream_t s);
+/* bf16 mode (ABI 17; csrc/layer_nb16.hip): the same pair of layers over a bf16-STORED input activation A (M, lda), W (128, 128) fp32 rounded to
+ * bf16 in the kernel, fp32 accumulate; `hidden` (M, ldh) bf16-stored or NULL; the output layer takes the bf16-rounded hidden activation (what
+ * the unfused pair would read back) against fp32 output weights, its four column-group shares summed in a fixed order.  E <= 4. */
+int clift_app_head_last2_bf16_fwd(const void* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                  const float* bout, int E, int M, void* hidden, int ldh, float* out, int ldo, int sigmoid,
+                                  clift_stream_t s);
+/* bf16 mode (ABI 17): backward of the no <= 4 wide output layer over the bf16-stored 128-wide hidden activation H (tensoRF.py:397 backward), one
+ * pass over H:  dX (M, ldx) bf16-stored = (H > 0) . (dOut W),  gW (no, 128) += dOut^T H,  gb (no) += column sums of dOut (nullable).
+ * dOut (M, ldd) fp32 with ldd >= 4 (pad columns ignored), products fp32. */
+int clift_out_layer_bwd_n128_bf16(const float* dOut, int ldd, int no, const float* W, int ldw, const void* H, int ldh, int M,
+                                  void* dX, int ldx, float* gW, int ldgw, float* gb, clift_stream_t s);
 /* bf16 mode: the first three layers of an xyz head (K = 3 layer + two 256 x 256 hidden layers, tensoRF.py:475-479, 576-579) and,
  * for E in [1,4], its E-wide output layer, in ONE launch with the activations resident in LDS (bf16 operands, fp32 accumulate --
  * the arithmetic of clift_linear_k3_fwd + clift_gemm(precision 1) with bf16-stored activations).  h1 / h2 / h3: nullable bf16-stored

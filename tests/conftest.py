@@ -84,3 +84,14 @@ def grad_close(a, b, what="", rtol=2e-3, scale_atol=1e-3, outlier_frac=1e-3, out
     allow = max(2 if b.numel() <= 1024 else 1, int(outlier_frac * b.numel()))
     assert nbad <= allow, f"{what}: {nbad}/{b.numel()} elements outside tolerance (max|b|={mx:.3g})"
     assert float(err.max()) <= outlier_cap * mx + 1e-12, f"{what}: max error {float(err.max()):.3g} vs scale {mx:.3g}"
+
+
+@pytest.fixture(autouse=True)
+def _restore_default_mlp_mode():
+    """several tests switch the process-wide MLP arithmetic and used to leave it at "fp32", so that what the rest of the suite
+    exercised depended on test order.  Every test now starts and ends in the shipped default (or CLIFT_MLP_DTYPE)."""
+    from contrastive_lift_amd import engine
+    want = os.environ.get("CLIFT_MLP_DTYPE", engine.DEFAULT_MLP_DTYPE)
+    engine.set_mlp_precision(want)
+    yield
+    engine.set_mlp_precision(want)

@@ -31,6 +31,8 @@ def test_gpus_flag_self_launches_that_many_ranks():
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["requested_gpus"] == 2
     assert line["allreduce_of_ones"] == 2.0          # both ranks took part in the collective
+    # the comparison the N > 1 bench line's `data_parallel_self_check` is built on tells equal from unequal ranks
+    assert line["self_check_primitive"] == {"identical_tensor_delta": 0.0, "rank_dependent_tensor_delta": 1.0}
 
 
 def test_gpus_8_launch_check_reports_eight_ranks_over_gloo():
@@ -61,6 +63,10 @@ def test_bench_two_ranks_on_one_gpu_reports_two():
     assert line["value"] > 0 and line["allreduce_overlap"] is not None
     # the N > 1 record is complete: dominant-kernel roofline, the exchange timed by itself, per-rank step times
     assert line["roofline"]["frac"] > 0 and line["allreduce_ms"]["ms"] > 0 and len(line["rank_ms_per_step_min_max"]) == 2
+    # ... and self-validating: the ranks end the run with identical parameters, overlapped and synchronous exchange agree
+    chk = line["data_parallel_self_check"]
+    assert chk["params_identical_across_ranks"] and chk["param_max_abs_delta_across_ranks"] == 0.0, chk
+    assert chk["overlap_grad_equal"] and chk["overlap_grad"]["finite"], chk
     assert line["dtype"] == "f32" and "three bf16 terms" in line["config"]["mlp_arithmetic"]
 
 

@@ -1,0 +1,204 @@
+"""Round 5, GPU: the bf16 forms of the 128-wide appearance MLP (csrc/layer_nb16.hip) against float64 on the bf16-rounded operands, the bf16
+appearance chain inside the engine against the exact one, and the bit-reproducibility of the fused output layers whose LDS reads were found
+consumed above their wait (csrc/layer_f32.hip, layer_n128.hip; DESIGN.md 'in-flight register rule')."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _r(x):
+    """fp32 values rounded to bf16 (what a bf16 kernel sees of an fp32-stored weight)."""
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def _gemm(**kw):
+    from contrastive_lift_amd import engine
+    prev = engine.set_mlp_precision("bf16")
+    try:
+        engine.gemm(**kw)
+    finally:
+        engine.set_mlp_precision(prev)
+
+
+def _padded(rows, cols, pitch, gen, scale=1.0):
+    w = torch.zeros((rows, pitch), dtype=torch.float32, device=DEV)
+    w[:, :cols] = scale * torch.randn((rows, cols), generator=gen, device=DEV)
+    return w
+
+
+@pytest.mark.parametrize("M", [64, 100, 4133, 70001])
+@pytest.mark.parametrize("K", [128, 160])
+def test_nb16_forward_against_fp64(M, K):
+    """H = relu(X W^T + b), X (M, K) bf16-stored, W (128, K) fp32 rounded in the kernel, H bf16-stored: within half a bf16 ulp + fp32 summation
+    noise of the float64 product of the rounded operands."""
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    X = _bf(torch.randn((M, K), generator=g, device=DEV))
+    W = _padded(128, K - (10 if K == 160 else 0), K, g, 0.2)
+    b = 0.1 * torch.randn(128, generator=g, device=DEV)
+    H = torch.full((M, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _gemm(M=M, N=128, K=K, A=X, lda=K, B=W, ldb=K, Cm=H, ldc=128, bias=b, act=1)
+    ref = torch.relu(X.double() @ _r(W).T + b.double())
+    err = (H.double() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-5 * float(ref.abs().max())
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert bool(torch.isfinite(H.float()).all())
+
+
+@pytest.mark.parametrize("M", [64, 1000, 50021])
+def test_nb16_input_gradients_against_fp64(M):
+    g = torch.Generator(device=DEV).manual_seed(M)
+    dY = _bf(torch.randn((M, 128), generator=g, device=DEV))
+    Hm = _bf(torch.randn((M, 128), generator=g, device=DEV).clamp_min(0))          # a ReLU output: zeros and positives
+    W2 = 0.2 * torch.randn((128, 128), generator=g, device=DEV)
+    dX = torch.full((M, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _gemm(M=M, N=128, K=128, A=dY, lda=128, B=W2, ldb=128, Cm=dX, ldc=128, b_trans=1, mask=Hm, ldmask=128)
+    ref = (dY.double() @ _r(W2)) * (Hm.double() > 0)
+    err = (dX.double() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-5 * float(ref.abs().max())
+    assert bool((err <= tol).all()), float((err - tol).max())
+    # the first layer's input gradient: 128 -> 160 columns (150 + zero pad), no mask, fp32- and bf16-stored results
+    W1 = _padded(128, 150, 160, g, 0.2)
+    ref1 = dY.double() @ _r(W1)
+    d32 = torch.full((M, 160), float("nan"), dtype=torch.float32, device=DEV)
+    _gemm(M=M, N=160, K=128, A=dY, lda=128, B=W1, ldb=160, Cm=d32, ldc=160, b_trans=1)
+    assert float((d32.double() - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
+    assert float(d32[:, 150:].abs().max()) == 0.0
+    d16 = torch.full((M, 160), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _gemm(M=M, N=160, K=128, A=dY, lda=128, B=W1, ldb=160, Cm=d16, ldc=160, b_trans=1)
+    assert torch.equal(d16, d32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M", [64, 1000, 4096, 70001])
+@pytest.mark.parametrize("NX", [128, 160])
+def test_nb16_weight_gradient_against_fp64(M, NX):
+    g = torch.Generator(device=DEV).manual_seed(M + NX)
+    dY = _bf(torch.randn((M, 128), generator=g, device=DEV))
+    X = _bf(torch.randn((M, NX), generator=g, device=DEV))
+    gW = torch.ones((128, NX), dtype=torch.float32, device=DEV)          # accumulates on top of what is there
+    gb = torch.ones(128, dtype=torch.float32, device=DEV)
+    _gemm(M=128, N=NX, K=M, A=dY, lda=128, B=X, ldb=NX, Cm=gW, ldc=NX, a_trans=1, b_trans=1, accumulate=1, colsum=gb)
+    ref = dY.double().T @ X.double() + 1.0
+    refb = dY.double().sum(0) + 1.0
+    assert float((gW.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    assert float((gb.double() - refb).abs().max()) <= 3e-5 * float(refb.abs().max())
+
+
+@pytest.mark.parametrize("M", [64, 777, 33000])
+def test_nb16_last_two_layers_fused(M):
+    """clift_app_head_last2_bf16_fwd: hidden = bf16(relu(A W^T + b)), out = sigmoid(hidden Wo^T + bo); with and without the hidden store the
+    colours are the same bits, and a row's bits do not depend on how many rows share the launch."""
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator(device=DEV).manual_seed(M)
+    A = _bf(torch.randn((M, 128), generator=g, device=DEV).clamp_min(0))
+    W = 0.15 * torch.randn((128, 128), generator=g, device=DEV)
+    b = 0.1 * torch.randn(128, generator=g, device=DEV)
+    Wo = 0.3 * torch.randn((3, 128), generator=g, device=DEV)
+    bo = 0.1 * torch.randn(3, generator=g, device=DEV)
+    H = torch.full((M, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = torch.full((M, 3), float("nan"), device=DEV)
+    call("clift_app_head_last2_bf16_fwd", ptr(A), 128, ptr(W), 128, ptr(b), ptr(Wo), 128, ptr(bo), 3, M, ptr(H), 128, ptr(out), 3, 1, stream())
+    href = torch.relu(A.double() @ _r(W).T + b.double())
+    err = (H.double() - href).abs()
+    assert bool((err <= href.abs() * 2.0 ** -8 + 1e-5 * float(href.abs().max())).all())
+    oref = torch.sigmoid(H.double() @ Wo.double().T + bo.double())            # from the STORED (rounded) activation, fp32 output weights
+    assert float((out.double() - oref).abs().max()) <= 2e-6
+    out2 = torch.full((M, 3), float("nan"), device=DEV)
+    call("clift_app_head_last2_bf16_fwd", ptr(A), 128, ptr(W), 128, ptr(b), ptr(Wo), 128, ptr(bo), 3, M, None, 128, ptr(out2), 3, 1, stream())
+    assert torch.equal(out, out2)
+    half = M // 2
+    out3 = torch.full((half, 3), float("nan"), device=DEV)
+    call("clift_app_head_last2_bf16_fwd", ptr(A), 128, ptr(W), 128, ptr(b), ptr(Wo), 128, ptr(bo), 3, half, None, 128, ptr(out3), 3, 1, stream())
+    assert torch.equal(out[:half], out3)
+
+
+@pytest.mark.parametrize("M", [16, 1000, 65537])
+def test_nb16_output_layer_backward(M):
+    from contrastive_lift_amd._lib import call, ptr, stream
+    g = torch.Generator(device=DEV).manual_seed(M)
+    d = torch.zeros((M, 4), device=DEV)
+    d[:, :3] = torch.randn((M, 3), generator=g, device=DEV)
+    d[:, 3] = 7.0                                                         # a pad column that must be ignored
+    H = _bf(torch.randn((M, 128), generator=g, device=DEV).clamp_min(0))
+    Wo = 0.3 * torch.randn((3, 128), generator=g, device=DEV)
+    dX = torch.full((M, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    gW = torch.ones((3, 128), device=DEV)
+    gb = torch.ones(3, device=DEV)
+    call("clift_out_layer_bwd_n128_bf16", ptr(d), 4, 3, ptr(Wo), 128, ptr(H), 128, M, ptr(dX), 128, ptr(gW), 128, ptr(gb), stream())
+    ref = (d[:, :3].double() @ Wo.double()) * (H.double() > 0)
+    err = (dX.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6 * float(ref.abs().max())).all())
+    refw = d[:, :3].double().T @ H.double() + 1.0
+    assert float((gW.double() - refw).abs().max()) <= 3e-5 * float(refw.abs().max())
+    assert float((gb.double() - (d[:, :3].double().sum(0) + 1.0)).abs().max()) <= 3e-5 * max(1.0, float(d[:, :3].double().sum(0).abs().max()))
+
+
+def _scene(C_=22, res=64):
+    from contrastive_lift_amd import synthetic
+    model, renderer, pool = synthetic.make_scene(grid=res, num_classes=C_, max_instances=3, seed=0, device=DEV, image=128)
+    return model, renderer, pool
+
+
+def test_bf16_appearance_chain_against_the_exact_chain():
+    """bf16 mode with the bf16 appearance chain (the default of that mode since round 5) against bf16 mode with the appearance MLP on the exact
+    kernels (rounds 2 - 4): colours within 2e-2 of their scale, appearance-head and table gradients within bf16 noise of each other; the front
+    end's bf16-stored X is the rounded fp32 X bit for bit."""
+    from contrastive_lift_amd import engine
+    model, renderer, pool = _scene()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rays = pool[torch.randint(0, pool.shape[0], (2048,), generator=g).to(DEV)].contiguous()
+    jit = torch.rand(2048, generator=g).to(DEV)
+    cot = torch.randn((2048, 3), generator=g).to(DEV)
+    prev = engine.set_mlp_precision("bf16")
+    res = {}
+    try:
+        for flag in (True, False):
+            engine.APP_BF16 = flag
+            model.grad_flat.zero_()
+            o, ctx = engine.render_forward(model, renderer, rays, jit, False, grad_heads=("app",), want_sem=False, want_inst=False)
+            assert ctx.X.dtype == (torch.bfloat16 if flag else torch.float32)
+            engine.render_backward(model, ctx, model.named_grad_views(), g_rgb=cot)
+            gv = {k: v.detach().clone() for k, v in model.named_grad_views().items()}
+            res[flag] = (o["rgb"].clone(), ctx.X.clone(), gv)
+    finally:
+        engine.APP_BF16 = True
+        engine.set_mlp_precision(prev)
+    assert torch.equal(res[True][1], res[False][1].to(torch.bfloat16))
+    scale = float(res[False][0].abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-2 * scale
+    for k in ("render_appearance_mlp.mlp.0.weight", "render_appearance_mlp.mlp.2.weight", "render_appearance_mlp.mlp.4.weight", "render_appearance_mlp.mlp.4.bias",
+              "appearance_basis_mat.weight", "appearance_plane.0", "density_plane.1"):
+        a, b = res[True][2][k].double(), res[False][2][k].double()
+        assert float(b.abs().max()) > 0, k
+        rel = float((a - b).norm() / b.norm())
+        assert rel <= 5e-2, (k, rel)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp32x6", "bf16"])
+def test_fused_output_layers_reproduce_their_bits(mode):
+    """The fused last-two-layer kernels (appearance: k_layer_n128<OUTV> / k_layer_nb16<OUTV>; instance heads: k_layer_f32<OUTV> / k_layer_x6<OUTV>)
+    render the same rays 40 times: every per-sample output bit-identical to the first pass.  (Round 5 found three FMAs of k_layer_f32<OUTV>
+    scheduled above the wait that publishes their LDS operand; tools/determinism_soak.py is the long form of this test.)"""
+    from contrastive_lift_amd import engine
+    model, renderer, pool = _scene(C_=2)
+    rays = pool[:8192].contiguous()
+    prev = engine.set_mlp_precision(mode)
+    try:
+        o, ctx = engine.render_forward(model, renderer, rays, None, False, grad_heads=())
+        ref = [t.clone() for t in (ctx.rgb_s, ctx.sem_s, ctx.inst_s, o["rgb"], o["instances"])]
+        for it in range(40):
+            o, ctx = engine.render_forward(model, renderer, rays, None, False, grad_heads=())
+            for a, b in zip((ctx.rgb_s, ctx.sem_s, ctx.inst_s, o["rgb"], o["instances"]), ref):
+                assert torch.equal(a, b), (mode, it)
+    finally:
+        engine.set_mlp_precision(prev)
