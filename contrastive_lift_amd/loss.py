@@ -56,6 +56,52 @@ def slow_fast_loss(instance_features, labels_gt, confidences, return_grad=False)
     return _Scaled.apply(instance_features, loss[0], grad)
 
 
+@torch.no_grad()
+def create_virtual_gt_with_linear_assignment(labels_gt, predicted_scores):
+    """T:332-344: match the (sorted, first E) 2-D instance ids of an image to the E output slots: cost[id][slot] = -(sum of the slot's softmax
+    probability over the id's rays / (count + 1e-4)), Hungarian method on the HOST like the reference (scipy; an L x E matrix, L <= E), every
+    ray of a matched id gets that slot as its class, every other ray class 0.  The per-id sums are one index_add on the device; what crosses
+    the bus is the L x E cost matrix."""
+    import numpy as np
+    import scipy.optimize
+    E = predicted_scores.shape[-1]
+    ids = torch.unique(labels_gt)[:E]                              # torch.unique sorts
+    prob = torch.softmax(predicted_scores.detach().to(torch.float32), dim=-1)
+    slot_of = torch.searchsorted(ids, labels_gt.contiguous())
+    slot_of = torch.where((slot_of < ids.numel()) & (ids[slot_of.clamp_max(ids.numel() - 1)] == labels_gt), slot_of, torch.full_like(slot_of, ids.numel()))
+    sums = torch.zeros((ids.numel() + 1, E), dtype=torch.float32, device=prob.device).index_add_(0, slot_of, prob)
+    cnt = torch.zeros(ids.numel() + 1, dtype=torch.float32, device=prob.device).index_add_(0, slot_of, torch.ones_like(slot_of, dtype=torch.float32))
+    cost = (-(sums[:-1] / (cnt[:-1, None] + 1e-4))).cpu().numpy().astype(np.float64)
+    rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))
+    table = torch.zeros(ids.numel() + 1, dtype=labels_gt.dtype)
+    table[torch.as_tensor(rows, dtype=torch.long)] = torch.as_tensor(cols, dtype=labels_gt.dtype)
+    return table.to(labels_gt.device)[slot_of]
+
+
+def linear_assignment_loss(instance_features, labels_gt, confidences, return_grad=False):
+    """The "linear_assignment" branch of calculate_instance_clustering_loss (T:237-241; the template's default instance_loss_mode, the
+    Panoptic-Lifting baseline): mean over rays of CrossEntropyLoss(reduction='none')(scores, matched slot) * confidence -- unless every ray's
+    argmax already is its slot: then the term is the constant 0 and NO gradient flows ("should never reinforce correct labels").
+    Returns (loss, grad or None) with ``return_grad``; grad None means the inactive case."""
+    f = _lib.f32(instance_features, "instance_features").contiguous()
+    n, E = f.shape
+    y = labels_gt.to(f.device)
+    conf = _lib.f32(confidences.to(f.device), "confidences").contiguous()
+    target = create_virtual_gt_with_linear_assignment(y, f)
+    if not bool(torch.any(target != f.argmax(dim=-1))):
+        zero = torch.zeros((), dtype=torch.float32, device=f.device)
+        return (zero, None) if return_grad else zero.requires_grad_(True)
+    onehot = torch.zeros_like(f).scatter_(1, target.reshape(-1, 1).to(torch.int64), 1.0)
+    rows = torch.empty((n,), dtype=torch.float32, device=f.device)
+    grows = torch.empty_like(f)
+    _lib.call("clift_semantic_loss_rows", _lib.ptr(f), _lib.ptr(onehot), None, n, E, 0, 1.0, 0.0, _lib.ptr(rows), _lib.ptr(grows), _lib.stream())
+    loss = (rows * conf).mean()
+    grad = grows * (conf / n)[:, None]
+    if return_grad:
+        return loss, grad
+    return _Scaled.apply(instance_features, loss, grad)
+
+
 def get_semantic_weights(reweight_classes, fg_classes, num_semantic_classes):
     """loss.py:29-33: per-class weights of the semantic losses -- ones, foreground ("thing") classes doubled when
     ``reweight_classes`` (config reweight_fg).  The trainer then overwrites entry 0 with config.weight_class_0 (T:69-70)."""

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, engine
-from .loss import contrastive_loss, slow_fast_loss
+from .loss import contrastive_loss, linear_assignment_loss, slow_fast_loss
 
 
 def default_config(**over):
@@ -434,11 +434,12 @@ class HotPathTrainer:
     def instance_pass(self, inst_batch, jitter=None):
         """inst_batch: list of dicts (one per image) with rays (n,8), instances (n,) int, confidences (n,)."""
         c, m, r = self.config, self.model, self.renderer
-        if c.instance_loss_mode not in ("slow_fast", "contrastive"):
-            raise NotImplementedError(f"HotPathTrainer: instance_loss_mode={c.instance_loss_mode!r} is not wired (slow_fast and "
-                                      "contrastive are; linear_assignment / ae_loss are the Panoptic-Lifting baselines)")
+        if c.instance_loss_mode not in ("slow_fast", "contrastive", "linear_assignment"):
+            raise NotImplementedError(f"HotPathTrainer: instance_loss_mode={c.instance_loss_mode!r} is not wired (slow_fast, contrastive and "
+                                      "linear_assignment are; ae_loss is an unused experiment of the reference)")
         self._pass_begin(self.inst_range)
         gv = m.named_grad_views()
+        contributed = False
         for img in inst_batch:
             rays = img["rays"]
             n = rays.shape[0]
@@ -460,6 +461,12 @@ class HotPathTrainer:
                 s0, s1 = m.arena.range_of("inst_slow")
                 _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
                 loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
+            elif c.instance_loss_mode == "linear_assignment":
+                # T:237-241: Hungarian-matched slots (host, like the reference), confidence-weighted cross entropy on the device.  An image
+                # whose rays all sit on their slot already contributes the constant 0: no backward for it
+                loss, g_inst = linear_assignment_loss(inst, img["instances"], img["confidences"], return_grad=True)
+                if g_inst is None:
+                    continue
             else:                                   # T:243-250: plain contrastive loss, optionally on points + features ("delta")
                 use_delta = bool(getattr(c, "use_delta", False))
                 if use_delta:
@@ -472,9 +479,13 @@ class HotPathTrainer:
                     g_inst = g_inst + 0.1 * inst / (nrm.clamp_min(1e-30) * inst.shape[0])
             self.losses[3:4].add_(loss.reshape(1))
             engine.feature_backward(m, ctx, gv, g_inst, slow_grad=False)
+            contributed = True
         if self.nosync:
             engine.reset_rows_limit(self.device)
         self._pass_fold("inst_fast")
+        if c.instance_loss_mode == "linear_assignment" and self.world == 1 and not contributed:
+            return           # (reference: the loss is a constant, every .grad stays None and torch's Adam skips every parameter, step counts included;
+                             #  in a data-parallel run another rank may have contributed: the exchange and the step then happen on all ranks)
         self._allreduce(self.inst_range)
         self.opt_inst.step()
 

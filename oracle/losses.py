@@ -108,3 +108,32 @@ def segment_consistency(seg_features, group, conf, class_weight, n_groups):
     cnt = torch.zeros(n_groups).index_add_(0, group, torch.ones(group.shape[0])).clamp_(min=1)
     target = (mean / cnt[:, None])[group].argmax(-1)
     return (F.cross_entropy(seg_features, target, weight=class_weight, reduction="none") * conf).mean()
+
+
+def virtual_labels_linear_assignment(labels_gt, scores):
+    """trainer/train_panopli_tensorf.py:332-344 (create_virtual_gt_with_linear_assignment): the (sorted, first E) 2-D instance ids of an image
+    are matched to the E output slots by the Hungarian method on cost[id][slot] = -(mean softmax probability of slot over the id's rays, count
+    + 1e-4 in the denominator); every ray of a matched id takes that slot as its class, everything else class 0."""
+    import numpy as np
+    import scipy.optimize
+    ids = sorted(torch.unique(labels_gt).cpu().tolist())[:scores.shape[-1]]
+    prob = torch.softmax(scores.detach(), dim=-1)
+    cost = np.zeros([len(ids), prob.shape[-1]])
+    for i, l in enumerate(ids):
+        sel = labels_gt == l
+        cost[i, :] = -(prob[sel, :].sum(dim=0) / (sel.sum() + 1e-4)).cpu().numpy()
+    rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))
+    new = torch.zeros_like(labels_gt)
+    for a, i in enumerate(rows):
+        new[labels_gt == ids[i]] = int(cols[a])
+    return new
+
+
+def linear_assignment(scores, labels_gt, conf):
+    """trainer/train_panopli_tensorf.py:237-241: confidence-weighted cross entropy of the instance scores against the matched slots -- unless
+    every ray's argmax already is its slot, in which case the term is a constant 0 without a gradient ("should never reinforce correct
+    labels").  Returns (loss, active)."""
+    target = virtual_labels_linear_assignment(labels_gt, scores)
+    if bool(torch.any(target != scores.argmax(dim=-1))):
+        return (F.cross_entropy(scores, target, reduction="none") * conf).mean(), True
+    return torch.zeros(()), False

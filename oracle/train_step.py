@@ -88,6 +88,10 @@ class CpuTrainer:
         if self.inst_mode == "slow_fast":
             olosses.ema_(self.slow, self.fast, 0.9)
             loss = olosses.slow_fast(inst, labels, conf)
+        elif self.inst_mode == "linear_assignment":                # T:237-241: Hungarian-matched slots, confidence-weighted CE
+            loss, active = olosses.linear_assignment(inst, labels, conf)
+            if not active:                                         # a constant: no parameter receives a gradient, Adam skips them all
+                return dict(loss=loss.detach(), inst=inst.detach())
         else:                                                      # T:243-250 contrastive (optionally on points + features)
             feats = xyz + inst if self.use_delta else inst
             loss = olosses.contrastive(feats, labels, self.temperature)

@@ -447,7 +447,7 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
-def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None):
+def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None, E=3, n_ids=4):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -457,7 +457,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     import trainer.train_panopli_tensorf as T
     import model.renderer.panopli_tensoRF_renderer as RR
     from model.loss.loss import TVLoss, SCELoss
-    res, C, E = (9, 13, 17), 4, 3
+    res, C = (9, 13, 17), 4
     aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
     P, pool, rng = _scene(121, res, C, E, aabb, 200)
     if mode != "slow_fast":                      # single instance MLP with E outputs (tensoRF.py:462-511, slow_fast_mode=False)
@@ -484,6 +484,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
         training_step = T.TensoRFTrainer.training_step
         calculate_instance_clustering_loss = T.TensoRFTrainer.calculate_instance_clustering_loss
         ema_update_slownet = T.TensoRFTrainer.ema_update_slownet
+        create_virtual_gt_with_linear_assignment = T.TensoRFTrainer.create_virtual_gt_with_linear_assignment
 
         def __call__(self, *a):
             return self.forward(*a)
@@ -516,6 +517,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     else:
         sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
     sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = mode, True, 100.0, use_delta
+    sh.loss_instances_cluster = torch.nn.CrossEntropyLoss(reduction="none")                 # T:78
     sh.device = torch.device("cpu")
     sh.current_epoch = epoch
     sh.current_lambda_dist_reg = 0.005 * (1 - np.exp(-0.25 * epoch))                      # T:447
@@ -555,7 +557,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
             sem = probs.argmax(-1)
             pick2 = torch.from_numpy(rng.choice(pool.shape[0], size=Bi, replace=False))
             irays = pool[pick2].clone()
-            labels = torch.from_numpy(rng.integers(1, 5, size=(Bi,)))
+            labels = torch.from_numpy(rng.integers(1, n_ids + 1, size=(Bi,)))
             iconf = torch.from_numpy(rng.uniform(0, 1, (Bi,)).astype(np.float32))
             out.update({f"s{st}.rays": rays.clone(), f"s{st}.rgbs": rgbs.clone(), f"s{st}.probs": probs.clone(), f"s{st}.confs": confs.clone(),
                         f"s{st}.mask": mask.clone(), f"s{st}.irays": irays.clone(), f"s{st}.labels": labels.clone(), f"s{st}.iconf": iconf.clone()})
@@ -867,6 +869,23 @@ def g18_sce():
     npz("g18_sce", **out)
 
 
+def g20_config_overlays():
+    """Every experiment overlay of the reference's config tree, resolved over its template (the reference's own YAML files read with this
+    repo's Hydra-less loader: OmegaConf is not in the image): what `+experiment=<name>` hands to the trainer.  Written as JSON (names, numbers,
+    strings, lists: data)."""
+    import glob
+    import json
+    from contrastive_lift_amd.config import load_config
+    out = {}
+    for f in sorted(glob.glob(os.path.join(REF, "config", "experiment", "*.yaml"))):
+        name = os.path.basename(f)[:-5]
+        out[name] = dict(load_config(os.path.join(REF, "config"), name))
+    out["<template only>"] = dict(load_config(os.path.join(REF, "config")))
+    with open(os.path.join(HERE, "g20_config_overlays.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("g20_config_overlays", len(out), "configs")
+
+
 def main():
     only = sys.argv[1:]
     if not os.path.isdir(REF):
@@ -893,6 +912,9 @@ def main():
     g17_meanshift_clustering()
     g18_sce()
     g12_training_steps(fname="g12e_training_steps_sce", steps=2, sce=(0.85, 0.15))
+    g20_config_overlays()
+    # instance_loss_mode "linear_assignment" (the template's default; T:237-241,332-344): six output slots, eight 2-D ids (two stay unmatched)
+    g12_training_steps(mode="linear_assignment", fname="g12l_training_steps_linear_assignment", steps=2, E=6, n_ids=8)
 
 
 if __name__ == "__main__":

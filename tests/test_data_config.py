@@ -256,3 +256,28 @@ def test_trainer_rejects_unbuilt_config_variants():
     for k, v in (("probabilistic_ce_mode", "NoTTAConf"), ("optimize_instance_only", True)):
         with pytest.raises(NotImplementedError):
             HotPathTrainer(m, r, default_config(**{k: v}))
+
+
+def test_every_experiment_overlay_of_the_reference_is_kept():
+    """config/experiment/ holds all twelve overlays of the reference's tree and `+experiment=<name>` resolves to the same values as the
+    reference's own files (golden G20: the reference's YAML files resolved over its template); `mlp_dtype` is this build's extension key."""
+    from contrastive_lift_amd.config import load_config
+    want = json.load(open(os.path.join(REPO, "tests", "golden", "g20_config_overlays.json")))
+    assert len(want) == 13
+    for name, ref in want.items():
+        ours = dict(load_config(os.path.join(REPO, "config"), None if name == "<template only>" else name))
+        assert ours.pop("mlp_dtype") == "fp32x6"
+        assert ours == ref, (name, {k: (ours.get(k), ref.get(k)) for k in set(ours) | set(ref) if ours.get(k) != ref.get(k)})
+
+
+def test_linear_assignment_matching_on_the_host():
+    """loss.create_virtual_gt_with_linear_assignment (device index_add + host Hungarian step) against the oracle's restatement of T:332-344 --
+    which golden G12l pins against the reference trainer -- incl. more 2-D ids than output slots and ids without any matched slot."""
+    from contrastive_lift_amd.loss import create_virtual_gt_with_linear_assignment as prod
+    from oracle.losses import virtual_labels_linear_assignment as orc
+    g = torch.Generator().manual_seed(0)
+    for E, L, n in ((6, 8, 64), (3, 2, 50), (25, 40, 300), (4, 4, 10), (500, 30, 256)):
+        for _ in range(4):
+            y = torch.randint(1, L + 1, (n,), generator=g)
+            f = 3.0 * torch.randn(n, E, generator=g)
+            assert torch.equal(prod(y, f), orc(y, f)), (E, L, n)

@@ -953,7 +953,7 @@ def test_psnr_parity_over_a_training_trajectory():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast

@@ -202,3 +202,36 @@ def test_fused_output_layers_reproduce_their_bits(mode):
                 assert torch.equal(a, b), (mode, it)
     finally:
         engine.set_mlp_precision(prev)
+
+
+def test_linear_assignment_mode_with_a_wide_instance_layer_against_the_oracle():
+    """instance_loss_mode "linear_assignment" (the template's default; config/experiment/panopli_MOS.yaml: max_instances 500) with a 40-wide
+    instance output layer -- wider than every fused output-layer kernel takes (E <= 4) and than the narrow stream (<= 32): the layer runs on the
+    generic launches, forward and backward -- three steps of the HIP trainer against the CPU oracle's (golden G12l pins the oracle and the
+    6-wide case against the reference itself): loss to 1e-3, every instance-head parameter within 10 % of a learning-rate step."""
+    from test_gpu_parity import _import, build_model, scene
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from oracle.train_step import CpuTrainer
+    cl, op, orender, ofld, olosses, orays = _import()
+    res, C_, E, Bi = (20, 24, 28), 3, 40, 512
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    _, rays, rng = scene(op, orays, 91, res, C_, 3, Bi)
+    P = op.add_blob(op.make_params(91, res, C_, E, slow_fast=False), res, 2.5, 0.45)
+    m = build_model(cl, P, res, C_, E, -3.0, slow_fast=False)
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="softmax").to(DEV)
+    cfg = default_config(chunk=0, instance_optimization_epoch=0, late_semantic_optimization=0, instance_loss_mode="linear_assignment", max_instances=E)
+    tr = HotPathTrainer(m, r, cfg, current_epoch=4)
+    ct = CpuTrainer(P, orender.RenderCfg(aabb, res, density_shift=-3.0), chunk=4096, epoch=4, instance_loss_mode="linear_assignment")
+    labels = torch.from_numpy(rng.integers(1, 61, size=(Bi,)))               # more ids than slots: the ids past the 40th stay unmatched (class 0)
+    conf = torch.from_numpy(rng.uniform(0.2, 1, Bi).astype(np.float32))
+    for step in range(3):
+        jit = torch.from_numpy(rng.uniform(0, 1, Bi).astype(np.float32))
+        oi = ct.instance_pass(rays, labels, conf, jit)
+        tr.losses.zero_()
+        tr.instance_pass([dict(rays=rays.to(DEV), instances=labels.to(DEV), confidences=conf.to(DEV))], jitter=jit.to(DEV))
+        rel_close(tr.losses[3], oi["loss"], 1e-3, what=f"step {step} linear-assignment loss")
+        sd = m.state_dict()
+        for k, v in ct.P.items():
+            if k.startswith("render_instance_mlp."):
+                diff = float((sd[k].cpu() - v.detach()).abs().max())
+                assert diff <= 0.1 * 5e-4 * (step + 1) + 1e-7, (step, k, diff)

@@ -194,7 +194,7 @@ def test_g11_metrics_vs_reference():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
