@@ -134,3 +134,31 @@ def instance_mlp(P, xn):
     if "render_instance_mlp.slow_mlp.0.weight" in P:
         return torch.cat([fast, _mlp(P, "render_instance_mlp.slow_mlp", xn, n)], -1)
     return fast
+
+
+def grid_feature(P, prefix, xn, explicit=False):
+    """tensoRF.py:127-134 (compute_feature) for the semantic / instance grids: basis Linear (no bias) of the plane-major product vector."""
+    prod = (vm_products_explicit if explicit else vm_products_fast)(P, prefix, xn)
+    return prod.T @ P[f"{prefix}_basis_mat.weight"].T
+
+
+def semantic_head(P, xn, softmax=True, explicit=False):
+    """compute_semantic_feature + render_semantic_mlp (tensoRF.py:142-145, 584-594): the MLP's input is the normalised position when
+    use_semantic_mlp, else the 27 features of the semantic VM grid (tensoRF.py:78-83)."""
+    if "semantic_plane.0" not in P:
+        return semantic_mlp(P, xn, softmax)
+    out = _mlp(P, "render_semantic_mlp.mlp", grid_feature(P, "semantic", xn, explicit), _count_layers(P, "render_semantic_mlp.mlp"))
+    return torch.softmax(out, -1) if softmax else out
+
+
+def instance_head(P, xn, explicit=False):
+    """compute_instance_feature + render_instance_mlp (tensoRF.py:152-156, 497-511), likewise; fast and slow nets read the same features."""
+    if "instance_plane.0" not in P:
+        return instance_mlp(P, xn)
+    return instance_mlp(P, grid_feature(P, "instance", xn, explicit))
+
+
+def instance_width(P):
+    n = _count_layers(P, "render_instance_mlp.mlp")
+    e = P[f"render_instance_mlp.mlp.{2 * (n - 1)}.weight"].shape[0]
+    return 2 * e if "render_instance_mlp.slow_mlp.0.weight" in P else e

@@ -13,12 +13,17 @@ def tv_plane(x):
     return 2 * (h_tv / cnt_h + w_tv / cnt_w) / b
 
 
-def total_tv(P, lambda_density=0.1, lambda_appearance=0.01):
-    """tensoRF.py:248-258,281-290 for the MLP-heads configuration (no semantic/instance grids):
-    planes only, each x1e-2."""
+def total_tv(P, lambda_density=0.1, lambda_appearance=0.01, lambda_semantics=0.02, lambda_instances=0.02, sem_on=True, inst_on=True):
+    """tensoRF.py:248-290 (total_tv_loss): density and appearance PLANES x 1e-2; semantic / instance grids, where the head has one, planes x 1e-2
+    + LINES x 1e-3, switched on with their loss terms (``sem_on``: epoch >= late_semantic_optimization, ``inst_on``: epoch >=
+    instance_optimization_epoch)."""
     d = sum(tv_plane(P[f"density_plane.{i}"]) * 1e-2 for i in range(3))
     a = sum(tv_plane(P[f"appearance_plane.{i}"]) * 1e-2 for i in range(3))
-    return d * lambda_density + a * lambda_appearance
+    out = d * lambda_density + a * lambda_appearance
+    for pre, lam, on in (("semantic", lambda_semantics, sem_on), ("instance", lambda_instances, inst_on)):
+        if on and f"{pre}_plane.0" in P:
+            out = out + lam * sum(tv_plane(P[f"{pre}_plane.{i}"]) * 1e-2 + tv_plane(P[f"{pre}_line.{i}"]) * 1e-3 for i in range(3))
+    return out
 
 
 def contrastive(features, labels, temperature):

@@ -24,8 +24,11 @@ def _linear(rng, out_f, in_f, zero_bias=False):
 
 def make_params(seed, res, num_classes, num_inst, n_dens=(16, 16, 16), n_app=(48, 48, 48), dim_app=27,
                 pe_view=2, pe_feat=2, dim_mlp_color=128, dim_mlp_sem=256, n_sem_layers=5,
-                dim_mlp_inst=256, n_inst_layers=4, grid_scale=0.1, slow_fast=True):
-    """res = (Rx, Ry, Rz).  Returns an ordered dict name -> float32 tensor (reference shapes)."""
+                dim_mlp_inst=256, n_inst_layers=4, grid_scale=0.1, slow_fast=True, sem_grid=False, inst_grid=False,
+                n_sem=(32, 32, 32), n_inst=(32, 32, 32), dim_sem=27, dim_inst=27, dim_mlp_sem_grid=128):
+    """res = (Rx, Ry, Rz).  Returns an ordered dict name -> float32 tensor (reference shapes).
+    ``sem_grid`` / ``inst_grid``: the head on its own VM grid (use_semantic_mlp / use_instance_mlp False, tensoRF.py:70-83): 3 x n components ->
+    basis Linear (no bias) -> 27 features -> 3-layer MLP (128 wide for semantics, dim_mlp_inst for instances)."""
     rng = np.random.default_rng(seed)
     P = {}
 
@@ -48,12 +51,21 @@ def make_params(seed, res, num_classes, num_inst, n_dens=(16, 16, 16), n_app=(48
         w, b = _linear(rng, dims[li + 1], dims[li], zero_bias=(li == 2))
         P[f"render_appearance_mlp.mlp.{2 * li}.weight"] = w
         P[f"render_appearance_mlp.mlp.{2 * li}.bias"] = b
-    dims = [3] + [dim_mlp_sem] * (n_sem_layers - 1) + [num_classes]
+    if inst_grid:               # (drawn in the order of the reference's __init__: instance head before the semantic one)
+        grids("instance", n_inst)
+        P["instance_basis_mat.weight"] = _linear(rng, dim_inst, sum(n_inst))[0]
+    if sem_grid:
+        grids("semantic", n_sem)
+        P["semantic_basis_mat.weight"] = _linear(rng, dim_sem, sum(n_sem))[0]
+        dim_mlp_sem, n_sem_layers = dim_mlp_sem_grid, 3
+    dims = [dim_sem if sem_grid else 3] + [dim_mlp_sem] * (n_sem_layers - 1) + [num_classes]
     for li in range(n_sem_layers):
         w, b = _linear(rng, dims[li + 1], dims[li])
         P[f"render_semantic_mlp.mlp.{2 * li}.weight"] = w
         P[f"render_semantic_mlp.mlp.{2 * li}.bias"] = b
-    dims = [3] + [dim_mlp_inst] * (n_inst_layers - 1) + [num_inst]
+    if inst_grid:
+        n_inst_layers = 3
+    dims = [dim_inst if inst_grid else 3] + [dim_mlp_inst] * (n_inst_layers - 1) + [num_inst]
     for net in (("mlp", "slow_mlp") if slow_fast else ("mlp",)):
         for li in range(n_inst_layers):
             w, b = _linear(rng, dims[li + 1], dims[li])

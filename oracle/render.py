@@ -120,7 +120,7 @@ def render_forward(P, rays, cfg, jitter=None, white_bg=False, explicit=False, re
     dist_reg = dist_loss(w, mid, dists)
     S = z.shape[1]
     C = P[[k for k in P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".weight")][-1]].shape[0]
-    D = fld.instance_mlp(P, torch.zeros(1, 3, dtype=z.dtype)).shape[-1]
+    D = fld.instance_width(P)
     rgb = torch.zeros(N, S, 3, dtype=z.dtype)
     sem = torch.zeros(N, S, C, dtype=z.dtype)
     inst = torch.zeros(N, S, D, dtype=z.dtype)
@@ -131,8 +131,8 @@ def render_forward(P, rays, cfg, jitter=None, white_bg=False, explicit=False, re
         feat = fld.appearance_feature(P, xa, explicit)
         rgb = rgb.clone(); sem = sem.clone(); inst = inst.clone()
         rgb[act] = fld.appearance_mlp(P, viewdirs[act], feat)
-        sem[act] = fld.semantic_mlp(P, xa, softmax=(cfg.semantic_weight_mode == "softmax"))
-        inst[act] = fld.instance_mlp(P, xa)
+        sem[act] = fld.semantic_head(P, xa, softmax=(cfg.semantic_weight_mode == "softmax"), explicit=explicit)
+        inst[act] = fld.instance_head(P, xa, explicit)
     opacity = w.sum(-1)
     rgb_map = (w[..., None] * rgb).sum(-2)
     ws = w[..., None].detach() if cfg.stop_semantic_grad else w[..., None]
@@ -154,12 +154,12 @@ def render_instance_feature(P, rays, cfg, jitter=None, explicit=False):
     with torch.no_grad():
         xn, z, inbox, dists, mid, sigma, alpha, w, bg = _density_weights(P, rays, cfg, jitter, explicit)
     N, S = z.shape
-    D = fld.instance_mlp(P, torch.zeros(1, 3, dtype=z.dtype)).shape[-1]
+    D = fld.instance_width(P)
     inst = torch.zeros(N, S, D, dtype=z.dtype)
     act = w > cfg.weight_thres
     if bool(act.any()):
         inst = inst.clone()
-        inst[act] = fld.instance_mlp(P, xn[act])
+        inst[act] = fld.instance_head(P, xn[act], explicit)
     inst_map = (w[..., None] * inst).sum(-2)
     with torch.no_grad():
         dist_map = (w * z).sum(-1)
@@ -177,5 +177,5 @@ def render_segment_feature(P, rays, cfg, jitter=None, explicit=False):
     act = w > cfg.weight_thres
     if bool(act.any()):
         seg = seg.clone()
-        seg[act] = fld.semantic_mlp(P, xn[act], softmax=(cfg.semantic_weight_mode == "softmax"))
+        seg[act] = fld.semantic_head(P, xn[act], softmax=(cfg.semantic_weight_mode == "softmax"), explicit=explicit)
     return _softmax_log((w[..., None].detach() * seg).sum(-2), cfg)

@@ -13,14 +13,15 @@ import torch
 from . import losses as olosses
 from . import render as orender
 
-GRID_KEYS = ("density_plane", "density_line", "appearance_plane", "appearance_line")
+GRID_KEYS = ("density_plane", "density_line", "appearance_plane", "appearance_line", "semantic_plane", "semantic_line")
+INST_GRID_KEYS = ("instance_plane", "instance_line")
 
 
 class CpuTrainer:
     def __init__(self, P, cfg, lr=5e-4, weight_decay=1e-8, lambda_rgb=1.0, lambda_semantics=0.1, lambda_dist_reg=0.005,
                  lambda_tv_density=0.1, lambda_tv_appearance=0.01, chunk=2048, epoch=4, class_weights=None, dino=True,
                  instance_loss_mode="slow_fast", temperature=100.0, use_delta=False, lambda_segment=1.2,
-                 late_semantic_optimization=0, sce=None):
+                 late_semantic_optimization=0, sce=None, lambda_tv_semantics=0.02, lambda_tv_instances=0.02, instance_optimization_epoch=0):
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
         self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
         self.inst_mode, self.temperature, self.use_delta = instance_loss_mode, temperature, use_delta
@@ -29,15 +30,20 @@ class CpuTrainer:
         self.sem_on = epoch >= late_semantic_optimization          # T:175,198: no semantic term before that epoch
         self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
         self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
+        self.l_tvs, self.l_tvi, self.inst_on = lambda_tv_semantics, lambda_tv_instances, epoch >= instance_optimization_epoch
         grids = [v for k, v in self.P.items() if k.startswith(GRID_KEYS)]
-        nets = [v for k, v in self.P.items() if not k.startswith(GRID_KEYS) and not k.startswith("render_instance_mlp")]
+        nets = [v for k, v in self.P.items() if not k.startswith(GRID_KEYS + INST_GRID_KEYS) and not k.startswith(("render_instance_mlp", "instance_basis_mat"))]
         self.main_params = grids + nets
         self.opt_main = torch.optim.Adam([{"params": grids, "lr": lr * 20}, {"params": nets, "lr": lr}], lr=lr,
                                          weight_decay=weight_decay, betas=(0.9, 0.99))     # T:99-100
         self.fast = [v for k, v in self.P.items() if k.startswith("render_instance_mlp.mlp.")]
         self.slow = [v for k, v in self.P.items() if k.startswith("render_instance_mlp.slow_mlp.")]
-        self.opt_inst = torch.optim.Adam([{"params": self.fast + ([] if dino else self.slow), "lr": lr}], lr=lr,
-                                         weight_decay=weight_decay, betas=(0.9, 0.999))    # T:101-102
+        # grid instance head (tensoRF.py:232-236): its planes / lines at the grid rate, basis matrix + fast MLP at the net rate
+        self.inst_grid = [v for k, v in self.P.items() if k.startswith(INST_GRID_KEYS)]
+        self.fast_mlp = list(self.fast)                                   # (the EMA pairs the two MLPs' parameters, T:325-329)
+        self.fast = [v for k, v in self.P.items() if k.startswith("instance_basis_mat")] + self.fast
+        groups = ([{"params": self.inst_grid, "lr": lr * 20}] if self.inst_grid else []) + [{"params": self.fast + ([] if dino else self.slow), "lr": lr}]
+        self.opt_inst = torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.999))    # T:101-102
         C = self.P[[k for k in self.P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".bias")][-1]].shape[0]
         self.cw = torch.ones(C) if class_weights is None else class_weights
         if class_weights is None:
@@ -47,7 +53,7 @@ class CpuTrainer:
         """``segments`` = dict(rays, group, conf, jitter, n_groups): the segment-consistency term of T:185-197 (active from
         segment_optimization_epoch on in the shipped configs)."""
         self.opt_main.zero_grad(set_to_none=True)
-        for p in self.fast + self.slow:
+        for p in self.fast + self.slow + self.inst_grid:
             p.grad = None
         outs = []
         for ci, i in enumerate(range(0, rays.shape[0], self.chunk)):
@@ -60,7 +66,7 @@ class CpuTrainer:
             rgb, rgbs, conf = rgb * keep[:, None], rgbs * keep[:, None], conf * keep
         dreg = torch.stack([o[5] for o in outs]).mean()
         l_rgb = torch.nn.functional.mse_loss(rgb, rgbs)
-        l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva)
+        l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva, self.l_tvs, self.l_tvi, self.sem_on, self.inst_on)
         if not self.sem_on:
             l_sem = torch.zeros(())
         elif self.sce is not None:
@@ -86,7 +92,7 @@ class CpuTrainer:
         # net happens at the top of the loss (T:258-259) -- so the slow features of step t come from the pre-update weights
         inst, xyz = orender.render_instance_feature(self.P, rays, self.cfg, jitter)
         if self.inst_mode == "slow_fast":
-            olosses.ema_(self.slow, self.fast, 0.9)
+            olosses.ema_(self.slow, self.fast_mlp, 0.9)
             loss = olosses.slow_fast(inst, labels, conf)
         elif self.inst_mode == "linear_assignment":                # T:237-241: Hungarian-matched slots, confidence-weighted CE
             loss, active = olosses.linear_assignment(inst, labels, conf)

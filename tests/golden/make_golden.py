@@ -128,13 +128,13 @@ def grad_digest(prefix, named_grads):
     return out
 
 
-def build_reference_model(P, res, C, E, shift, softmax=True, slow_fast=True):
+def build_reference_model(P, res, C, E, shift, softmax=True, slow_fast=True, sem_mlp=True, inst_mlp=True):
     from model.radiance_field.tensoRF import TensorVMSplit
     with quiet():
         m = TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32),
                           num_semantic_classes=C, dim_feature_instance=(2 * E if slow_fast else E), splus_density_shift=shift,
                           output_mlp_semantics=(torch.nn.Softmax(dim=-1) if softmax else torch.nn.Identity()),
-                          use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=slow_fast)
+                          use_semantic_mlp=sem_mlp, use_instance_mlp=inst_mlp, slow_fast_mode=slow_fast)
     missing, unexpected = m.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
     assert not missing and not unexpected
     return m
@@ -447,7 +447,7 @@ def g11_metrics():
     npz("g11_metrics", **out)
 
 
-def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None, E=3, n_ids=4):
+def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None, E=3, n_ids=4, grids=False):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -460,8 +460,8 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     res, C = (9, 13, 17), 4
     aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
     P, pool, rng = _scene(121, res, C, E, aabb, 200)
-    if mode != "slow_fast":                      # single instance MLP with E outputs (tensoRF.py:462-511, slow_fast_mode=False)
-        P = op.add_blob(op.make_params(121, res, C, E, slow_fast=False), res, amplitude=2.5, sigma_g=0.45)
+    if mode != "slow_fast" or grids:             # single instance MLP with E outputs (tensoRF.py:462-511, slow_fast_mode=False); grids: both heads on VM grids
+        P = op.add_blob(op.make_params(121, res, C, E, slow_fast=(mode == "slow_fast"), sem_grid=grids, inst_grid=grids), res, amplitude=2.5, sigma_g=0.45)
     B, Bi, epoch = 96, 64, 4
     cfg = _t.SimpleNamespace(
         lr=5e-4, weight_decay=1e-8, decay_step=[9, 10], decay_gamma=0.5, warmup_epochs=0, chunk=40, perturb=1.0,
@@ -471,7 +471,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
         late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=(2 if segments else 100),
         segment_grouping_mode=("argmax_conf" if segments else "none"), batch_size_segments=6, chunk_segment=50,
         probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E)
-    m = build_reference_model(P, res, C, E, shift=-3.0, slow_fast=(mode == "slow_fast"))
+    m = build_reference_model(P, res, C, E, shift=-3.0, slow_fast=(mode == "slow_fast"), sem_mlp=not grids, inst_mlp=not grids)
     rr = build_reference_renderer(aabb, res, "softmax")
     cw = torch.ones(C)
     cw[0] = 0.0
@@ -869,6 +869,56 @@ def g18_sce():
     npz("g18_sce", **out)
 
 
+def g19_grid_heads():
+    """The semantic / instance heads on their own VM grids (use_semantic_mlp / use_instance_mlp False: tensoRF.py:70-83,142-156; the allgrid,
+    instGRIDsemMLP and onlyRGBsegGRID overlays): full forward with gradients of every parameter, the instance-feature and segment-feature passes,
+    for (a) both heads on grids, single instance net and (b) semantic MLP + instance grid with the slow-fast twin."""
+    import model.renderer.panopli_tensoRF_renderer as RR
+    res, C, E = (9, 13, 17), 4, 3
+    aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
+    out = dict(res=np.array(res), C=C, E=E, seed=191, shift=-3.0, aabb=aabb)
+    for tag, sem_grid, inst_grid, sf in (("a", True, True, False), ("b", False, True, True)):
+        _, rays, rng = _scene(191, res, C, E, aabb, 80)
+        P = op.add_blob(op.make_params(191, res, C, E, slow_fast=sf, sem_grid=sem_grid, inst_grid=inst_grid), res, amplitude=2.5, sigma_g=0.45)
+        N, D = rays.shape[0], (2 * E if sf else E)
+        jitter = torch.from_numpy(rng.uniform(0, 1, size=(N,)).astype(np.float32))
+        cot = {k: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)) for k, sh in (("rgb", (N, 3)), ("sem", (N, C)), ("inst", (N, D)))}
+        m = build_reference_model(P, res, C, E, shift=-3.0, slow_fast=sf, sem_mlp=not sem_grid, inst_mlp=not inst_grid)
+        rr = build_reference_renderer(aabb, res, "softmax")
+        real_rl, real_r = RR.torch.rand_like, RR.torch.rand
+        RR.torch.rand_like = lambda t, *a, **k: jitter.view(-1, 1).to(t)
+        RR.torch.rand = lambda *a, **k: torch.ones(1)
+        try:
+            rgb, sem, inst, depth, feats, dreg = rr.forward(m, rays, 1.0, False, True)
+        finally:
+            RR.torch.rand_like, RR.torch.rand = real_rl, real_r
+        ((rgb * cot["rgb"]).sum() + (sem * cot["sem"]).sum() + (inst * cot["inst"]).sum()).backward()
+        out.update({f"{tag}.rays": rays, f"{tag}.jitter": jitter, f"{tag}.cot_rgb": cot["rgb"], f"{tag}.cot_sem": cot["sem"], f"{tag}.cot_inst": cot["inst"],
+                    f"{tag}.rgb": rgb, f"{tag}.sem": sem, f"{tag}.inst": inst, f"{tag}.depth": depth, f"{tag}.sem_grid": int(sem_grid),
+                    f"{tag}.inst_grid": int(inst_grid), f"{tag}.slow_fast": int(sf)})
+        out.update(grad_digest(f"{tag}.g", {k: p.grad for k, p in m.named_parameters()}))
+        m.zero_grad(set_to_none=True)
+        fi, xyz = rr.forward_instance_feature(m, rays, 0, False)
+        (fi * cot["inst"]).sum().backward()
+        out.update({f"{tag}.f_inst": fi, f"{tag}.f_xyz": xyz})
+        out.update(grad_digest(f"{tag}.fi.g", {k: p.grad for k, p in m.named_parameters()}))
+        m.zero_grad(set_to_none=True)
+        fs = rr.forward_segment_feature(m, rays, 0, False)
+        (fs * cot["sem"]).sum().backward()
+        out.update({f"{tag}.f_seg": fs})
+        out.update(grad_digest(f"{tag}.fs.g", {k: p.grad for k, p in m.named_parameters()}))
+        # the TV term of the trainer's loss with every grid term on (tensoRF.py:248-290)
+        from model.loss.loss import TVLoss
+        cfgtv = __import__("types").SimpleNamespace(late_semantic_optimization=0, instance_optimization_epoch=0, lambda_tv_density=0.1,
+                                                    lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02)
+        m.zero_grad(set_to_none=True)
+        tv = m.total_tv_loss(TVLoss(), cfgtv, 1)
+        tv.backward()
+        out[f"{tag}.tv"] = tv.detach()
+        out.update(grad_digest(f"{tag}.tv.g", {k: p.grad for k, p in m.named_parameters() if k.split(".")[0].endswith(("_plane", "_line"))}))
+    npz("g19_grid_heads", **out)
+
+
 def g20_config_overlays():
     """Every experiment overlay of the reference's config tree, resolved over its template (the reference's own YAML files read with this
     repo's Hydra-less loader: OmegaConf is not in the image): what `+experiment=<name>` hands to the trainer.  Written as JSON (names, numbers,
@@ -915,6 +965,9 @@ def main():
     g20_config_overlays()
     # instance_loss_mode "linear_assignment" (the template's default; T:237-241,332-344): six output slots, eight 2-D ids (two stay unmatched)
     g12_training_steps(mode="linear_assignment", fname="g12l_training_steps_linear_assignment", steps=2, E=6, n_ids=8)
+    g19_grid_heads()
+    # the allgrid overlay's arrangement: both heads on VM grids, plain contrastive instance loss (optimizer groups of the grid heads, TV on their tables)
+    g12_training_steps(mode="contrastive", fname="g12g_training_steps_grid_heads", steps=2, grids=True)
 
 
 if __name__ == "__main__":

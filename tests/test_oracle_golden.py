@@ -132,6 +132,45 @@ def test_g7_instance_and_segment_feature():
     _digest_check(g, "seg.g", {k: v.grad for k, v in P.items()})
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g19_grid_heads(tag):
+    """Semantic / instance heads on their own VM grids (tensoRF.py:70-83,142-156; golden G19 = the reference's forward, instance-feature and
+    segment-feature passes with the gradients of every parameter, and its TV term with the grid terms on): (a) both heads on grids, (b) semantic
+    MLP + instance grid with the slow-fast twin."""
+    g = load_golden("g19_grid_heads")
+    res = tuple(int(x) for x in g["res"])
+    C, E = int(g["C"]), int(g["E"])
+    sem_grid, inst_grid, sf = bool(int(g[f"{tag}.sem_grid"])), bool(int(g[f"{tag}.inst_grid"])), bool(int(g[f"{tag}.slow_fast"]))
+    P = op.clone_params(op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=sf, sem_grid=sem_grid, inst_grid=inst_grid), res, 2.5, 0.45),
+                        requires_grad=True)
+    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
+    rays = T(g[f"{tag}.rays"])
+    rgb, sem, inst, depth, feats, dreg = orender.render_forward(P, rays, cfg, T(g[f"{tag}.jitter"]), False)
+    for nm, a in (("rgb", rgb), ("sem", sem), ("inst", inst), ("depth", depth)):
+        rel_close(a, g[f"{tag}.{nm}"], TIGHT, what=nm)
+    ((rgb * T(g[f"{tag}.cot_rgb"])).sum() + (sem * T(g[f"{tag}.cot_sem"])).sum() + (inst * T(g[f"{tag}.cot_inst"])).sum()).backward()
+    _digest_check(g, f"{tag}.g", {k: v.grad for k, v in P.items()})
+    for v in P.values():
+        v.grad = None
+    fi, xyz = orender.render_instance_feature(P, rays, cfg)
+    rel_close(fi, g[f"{tag}.f_inst"], TIGHT, what="instance features")
+    rel_close(xyz, g[f"{tag}.f_xyz"], TIGHT, what="surface points")
+    (fi * T(g[f"{tag}.cot_inst"])).sum().backward()
+    _digest_check(g, f"{tag}.fi.g", {k: v.grad for k, v in P.items()})
+    for v in P.values():
+        v.grad = None
+    fs = orender.render_segment_feature(P, rays, cfg)
+    rel_close(fs, g[f"{tag}.f_seg"], TIGHT, what="segment features")
+    (fs * T(g[f"{tag}.cot_sem"])).sum().backward()
+    _digest_check(g, f"{tag}.fs.g", {k: v.grad for k, v in P.items()})
+    for v in P.values():
+        v.grad = None
+    tv = olosses.total_tv(P)
+    rel_close(tv, g[f"{tag}.tv"], TIGHT, what="TV with the grid terms")
+    tv.backward()
+    _digest_check(g, f"{tag}.tv.g", {k: v.grad for k, v in P.items() if k.split(".")[0].endswith(("_plane", "_line"))})
+
+
 def test_g8_contrastive():
     g = load_golden("g8_losses")
     for tag in "abcd":
@@ -194,7 +233,7 @@ def test_g11_metrics_vs_reference():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -206,18 +245,28 @@ def test_g12_three_reference_training_steps(fixture):
     res = tuple(int(x) for x in g["res"])
     C, E = int(g["C"]), int(g["E"])
     mode = str(g["mode"]) if "mode" in g else "slow_fast"
-    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=(mode == "slow_fast")), res, 2.5, 0.45)
+    grids = "grid_heads" in fixture               # sixth fixture: both heads on VM grids (the allgrid overlay)
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=(mode == "slow_fast"), sem_grid=grids, inst_grid=grids), res, 2.5, 0.45)
     cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
-    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]),
+    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]), late_semantic_optimization=1,
+                    instance_optimization_epoch=3,
                     instance_loss_mode=mode, use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False,
                     sce=(tuple(float(x) for x in g["sce"]) if "sce" in g and float(g["sce"][1]) != 0.0 else None))   # 4th fixture: SCELoss
     rel_close(tr.l_dist, g["lambda_dist"], 1e-6, what="dist-reg ramp")
     # optimizer layout of the reference (T:98-103): 7 main groups (4 grid groups at 20 lr, 3 net groups at lr) + 1 instance group
     og = g["opt_groups"]
-    assert list(g["opt_group_counts"]) == [7, 1]
+    nmain = int(g["opt_group_counts"][0])
+    assert list(g["opt_group_counts"]) == ([10, 4] if grids else [7, 1])          # grid heads: + semantic planes / lines / basis (+ MLP in place); instance planes, lines, basis, MLP
     main_lr = {float(x["lr"]): sum(p.numel() for p in x["params"]) for x in tr.opt_main.param_groups}
-    assert main_lr[1e-2] == int(og[:4, 4].sum()) and main_lr[5e-4] == int(og[4:7, 4].sum())
-    assert sum(p.numel() for p in tr.opt_inst.param_groups[0]["params"]) == int(og[7, 4])
+    want = {}
+    for row in og[:nmain]:
+        want[float(row[0])] = want.get(float(row[0]), 0) + int(row[4])
+    assert main_lr == want
+    inst_lr = {float(x["lr"]): sum(p.numel() for p in x["params"]) for x in tr.opt_inst.param_groups}
+    want = {}
+    for row in og[nmain:]:
+        want[float(row[0])] = want.get(float(row[0]), 0) + int(row[4])
+    assert inst_lr == want
     assert tr.opt_main.param_groups[0]["betas"] == (0.9, 0.99) and tr.opt_inst.param_groups[0]["betas"] == (0.9, 0.999)
     assert all(abs(x["weight_decay"] - og[0, 1]) < 1e-20 for x in tr.opt_main.param_groups + tr.opt_inst.param_groups)
     for st in range(int(g["steps"])):
@@ -236,7 +285,7 @@ def test_g12_three_reference_training_steps(fixture):
         for k, v in tr.P.items():
             flat = v.detach().reshape(-1)
             sub = flat if flat.numel() <= 4096 else flat[::17]
-            lr = 1e-2 if k.startswith(("density_", "appearance_plane", "appearance_line")) else 5e-4
+            lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
             rel_close(flat.norm(), g[f"s{st}.pnorm.{k}"], 1e-4, atol=1e-7, what=f"step {st} |{k}|")
             assert float((sub - T(g[f"s{st}.psub.{k}"]).reshape(-1)).abs().max()) <= 0.05 * lr * (st + 1), (st, k)
 
