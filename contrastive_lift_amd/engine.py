@@ -45,7 +45,7 @@ def vm_struct(views, prefix, res):
     return v
 
 
-_GROUP_OF = {"density": "grid_density", "appearance": "grid_app"}
+_GROUP_OF = {"density": "grid_density", "appearance": "grid_app", "semantic": "grid_sem", "instance": "grid_inst"}
 
 
 def vm_grad_struct(model, gviews, prefix):
@@ -526,6 +526,99 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
          int(d.dtype == torch.bfloat16), stream())
 
 
+# ----------------------------------------------------------------------------- heads on their own VM grids (tensoRF.py:70-83,142-156)
+def _grid_precision():
+    # the grid heads' MLPs are short (27 -> 128 -> 128 -> C, 27 -> 256 -> 256 -> E): in bf16 mode they stay exact (no bf16-stored forms are built
+    # for them); in fp32x6 mode engine.gemm sends their one 256 x 256 layer to the split kernels like any other
+    return _Precision(0 if MLP_PRECISION == 1 else MLP_PRECISION)
+
+
+def feat_mlp_fwd(layers, X, M, out, ldo, col_off=0, keep=True, out_act=0):
+    """MLP over a feature matrix X (M, ldx) -- ldx = the first layer's row pitch, pad columns zero -- instead of over positions: hidden layers
+    through engine.gemm (bias + ReLU), the last layer into out[:, col_off:col_off + n_out] (+ row softmax when ``out_act`` is 2).
+    Returns the hidden activations (for feat_mlp_bwd) or None."""
+    h, acts = X, []
+    for W, b in layers[:-1]:
+        hn = torch.empty((M, W.shape[0]), dtype=torch.float32, device=X.device)
+        gemm(M, W.shape[0], _pitch(W), h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1)
+        acts.append(hn)
+        h = hn
+    Wo, bo = layers[-1]
+    if (Wo.shape[0] <= 32 and h.shape[1] == 256 and _pitch(Wo) % 4 == 0 and _pitch(Wo) >= 256 and MLP_PRECISION in (0, 2)
+            and os.environ.get("CLIFT_NO_PERSISTENT") is None):
+        out_layer_fwd(M, h, Wo, bo, out, ldo, col_off, out_act)
+    else:
+        gemm(M, Wo.shape[0], _pitch(Wo), h, h.shape[1], Wo, _pitch(Wo), out, ldo, bias=bo, c_off=col_off)
+        if out_act == 2:
+            _row_softmax_inplace(out, M, Wo.shape[0], ldo, col_off)
+    return acts if keep else None
+
+
+def feat_mlp_bwd(layers, glayers, X, acts, dpre, M, keep=None):
+    """Backward of feat_mlp_fwd: dpre (M, ld) = gradient w.r.t. the last layer's pre-activation output (ld % 4 == 0, pad zero); accumulates the
+    weight / bias gradients and returns the gradient w.r.t. X (M, ldx)."""
+    keep = keep if keep is not None else []
+    d = dpre
+    keep.append(d)
+    for li in range(len(layers) - 1, -1, -1):
+        W, b = layers[li]
+        gW, gb = glayers[li]
+        h = acts[li - 1] if li > 0 else X
+        no, kin = W.shape[0], h.shape[1]
+        wgrad(no, kin, M, d, d.shape[1], h, kin, gW, gb)
+        dn = torch.empty((M, kin), dtype=torch.float32, device=X.device)
+        if li > 0:
+            gemm(M, kin, no, d, d.shape[1], W, _pitch(W), dn, kin, b_trans=1, mask=h, ldmask=kin)
+        else:
+            gemm(M, kin, no, d, d.shape[1], W, _pitch(W), dn, kin, b_trans=1)
+        d = dn
+        keep.append(d)
+    return d
+
+
+def grid_head_fwd(model, views, ctx, prefix, nets, keep, out_act=0):
+    """A head whose MLP reads the 27 features of its own VM grid (compute_feature, tensoRF.py:127-134, on the semantic / instance tables) for
+    the chunk's active samples: product gather (the appearance head's kernel: generic in the component count), basis Linear, then every net of
+    ``nets`` = [(layers, out, ldo, col_off)] on the same features (the instance head's fast and slow MLPs).  Returns what the backward needs."""
+    M, dev = ctx.M, ctx.rays.device
+    with _grid_precision():
+        vm = vm_struct(views, prefix, ctx.res)
+        nc = 3 * vm.comps
+        F = torch.empty((M, nc), dtype=torch.float32, device=dev)
+        call("clift_app_gather_fwd", C.byref(ctx.ms), C.byref(vm), ptr(ctx.rays), ptr(ctx.jitter), ptr(ctx.act_idx), M, ptr(F), ptr(ctx.xa), stream())
+        Wb = views[f"{prefix}_basis_mat.weight"]
+        nf, ldf = Wb.shape[0], (Wb.shape[0] + 3) // 4 * 4
+        feat = torch.zeros((M, ldf), dtype=torch.float32, device=dev)          # (pad columns stay zero: the first layer's K is its row pitch)
+        with exact_fp32():
+            gemm(M, nf, nc, F, nc, Wb, _pitch(Wb), feat, ldf)
+        acts = [feat_mlp_fwd(layers, feat, M, out, ldo, col_off, keep, out_act) for layers, out, ldo, col_off in nets]
+    return dict(prefix=prefix, F=F if keep else None, feat=feat if keep else None, acts=acts)
+
+
+def grid_head_bwd(model, views, gviews, ctx, st, nets, keep):
+    """Backward of grid_head_fwd.  ``nets`` = [(layers, glayers, acts, dpre)] for the nets that receive a gradient (their input gradients add up
+    on the shared features); then the basis matrix's gradient, dF = dfeat Wb and the scatter into the head's tables."""
+    M, dev, prefix = ctx.M, ctx.rays.device, st["prefix"]
+    with _grid_precision():
+        dfeat = None
+        for layers, glayers, acts, dpre in nets:
+            d = feat_mlp_bwd(layers, glayers, st["feat"], acts, dpre, M, keep)
+            dfeat = d if dfeat is None else dfeat.add_(d)
+        Wb, gWb = views[f"{prefix}_basis_mat.weight"], gviews[f"{prefix}_basis_mat.weight"]
+        nf, nc = Wb.shape
+        call("clift_wgrad_narrow", ptr(dfeat), dfeat.shape[1], nf, ptr(st["F"]), nc, nc, M, ptr(gWb), _pitch(gWb), None, 0, stream())
+        dF = torch.empty((M, nc), dtype=torch.float32, device=dev)
+        with exact_fp32():
+            gemm(M, nc, nf, dfeat, dfeat.shape[1], Wb, _pitch(Wb), dF, nc, b_trans=1)
+        model.xcd_workspace_for(prefix)
+        vm = vm_struct(views, prefix, ctx.res)
+        g = vm_grad_struct(model, gviews, prefix)
+        call("clift_app_gather_bwd", C.byref(ctx.ms), C.byref(vm), C.byref(g), ptr(ctx.rays), ptr(ctx.jitter), ptr(ctx.act_idx), M, ptr(dF),
+             ptr(ctx.xa) if APP_SCATTER_XA else None, stream())
+        vm_grad_finish(model, gviews, prefix, g)
+        keep.extend([dfeat, dF])
+
+
 # ----------------------------------------------------------------------------- forward
 class RenderCtx:
     pass
@@ -735,7 +828,11 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
         def sem_chain(keep):
             sem_layers = _lin_params(None, "render_semantic_mlp.mlp", views)
             sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, sem_s, Ccls, keep_first="sem" in grad_heads, out_act=2 if model.render_semantic_mlp.softmax else 0)
+            sm = 2 if model.render_semantic_mlp.softmax else 0
+            if model.semantic_plane is not None:           # the head on its own VM grid
+                ctx.sem_grid = grid_head_fwd(model, views, ctx, "semantic", [(sem_layers, sem_s, Ccls, 0)], "sem" in grad_heads, sm)
+            else:
+                ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, sem_s, Ccls, keep_first="sem" in grad_heads, out_act=sm)
             ctx.sem_s = sem_s
 
         br = Branches()
@@ -754,9 +851,15 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
             def slow_chain(keep):
                 ctx.inst_slow_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.slow_mlp", views), xa, M, ctx.inst_s, D, E,
                                                  keep_first="slow" in grad_heads)
-            br.run(2, fast_chain)
-            if model.slow_fast_mode:
-                br.run(3, slow_chain)
+            if model.instance_plane is not None:           # the head on its own VM grid: fast and slow nets read the same features
+                nets = [(_lin_params(None, "render_instance_mlp.mlp", views), ctx.inst_s, D, 0)]
+                if model.slow_fast_mode:
+                    nets.append((_lin_params(None, "render_instance_mlp.slow_mlp", views), ctx.inst_s, D, E))
+                br.run(2, lambda keep: setattr(ctx, "inst_grid", grid_head_fwd(model, views, ctx, "instance", nets, "fast" in grad_heads or "slow" in grad_heads)))
+            else:
+                br.run(2, fast_chain)
+                if model.slow_fast_mode:
+                    br.run(3, slow_chain)
         br.join()
     # (the sum kernel writes every (ray, channel) when there are heads to sum; only a chunk without active samples needs the zeros)
     fresh = torch.empty if M > 0 else torch.zeros
@@ -905,6 +1008,13 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
                 dpre = torch.empty((M, ldp), dtype=torch.float32, device=dev)
                 kind = 2 if model.render_semantic_mlp.softmax else 0
                 call("clift_rows_act_bwd", ptr(ctx.sem_s), Ccls, ptr(d_sem), Ccls, M, Ccls, kind, ptr(dpre), ldp, stream())
+            if getattr(ctx, "sem_grid", None) is not None:
+                st_ = ctx.sem_grid
+                if st_["F"] is None:
+                    raise _lib.CliftError("backward through a grid head whose forward ran without keeping its activations (head not named in grad_heads)")
+                grid_head_bwd(model, views, gviews, ctx, st_, [(_lin_params(None, "render_semantic_mlp.mlp", views),
+                                                                _lin_params(None, "render_semantic_mlp.mlp", gviews), st_["acts"][0], dpre)], keep)
+                return
             xyz_mlp_bwd(_lin_params(None, "render_semantic_mlp.mlp", views), _lin_params(None, "render_semantic_mlp.mlp", gviews),
                         ctx.xa, ctx.sem_acts, dpre, M, keep)
 
@@ -925,7 +1035,27 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             br.run(0, app_chain)
         if d_sem is not None:
             br.run(1, sem_chain)
-        if d_inst is not None:
+        if d_inst is not None and getattr(ctx, "inst_grid", None) is not None:
+            def inst_grid_chain(keep):
+                st_ = ctx.inst_grid
+                if st_["F"] is None:
+                    raise _lib.CliftError("backward through a grid head whose forward ran without keeping its activations (head not named in grad_heads)")
+                E_ = model.render_instance_mlp.output_channels
+                ldp = (E_ + 3) // 4 * 4
+
+                def pre(off, fused):
+                    if act_fused:
+                        return fused
+                    dp = torch.empty((M, ldp), dtype=torch.float32, device=dev)
+                    call("clift_rows_act_bwd", None, 0, C.c_void_p(d_inst.data_ptr() + 4 * off), D, M, E_, 0, ptr(dp), ldp, stream())
+                    return dp
+                nets = [(_lin_params(None, "render_instance_mlp.mlp", views), _lin_params(None, "render_instance_mlp.mlp", gviews), st_["acts"][0], pre(0, d_inst))]
+                if model.slow_fast_mode and slow_grad:
+                    nets.append((_lin_params(None, "render_instance_mlp.slow_mlp", views), _lin_params(None, "render_instance_mlp.slow_mlp", gviews),
+                                 st_["acts"][1], pre(E_, d_inst_slow)))
+                grid_head_bwd(model, views, gviews, ctx, st_, nets, keep)
+            br.run(2, inst_grid_chain)
+        elif d_inst is not None:
             br.run(2, inst_chain("render_instance_mlp.mlp", ctx.inst_fast_acts, 0))
             if model.slow_fast_mode and slow_grad:
                 br.run(3, inst_chain("render_instance_mlp.slow_mlp", ctx.inst_slow_acts, model.render_instance_mlp.output_channels))
@@ -988,7 +1118,18 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
         if head == "semantic":
             layers = _lin_params(None, "render_semantic_mlp.mlp", views)
             ctx.sem_s = torch.empty((M, Ccls), dtype=torch.float32, device=dev)
-            ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, ctx.sem_s, Ccls, keep_first="sem" in grad_heads, out_act=2 if model.render_semantic_mlp.softmax else 0)
+            sm = 2 if model.render_semantic_mlp.softmax else 0
+            if model.semantic_plane is not None:
+                ctx.sem_grid = grid_head_fwd(model, views, ctx, "semantic", [(layers, ctx.sem_s, Ccls, 0)], "sem" in grad_heads, sm)
+            else:
+                ctx.sem_acts = xyz_mlp_fwd(layers, xa, M, ctx.sem_s, Ccls, keep_first="sem" in grad_heads, out_act=sm)
+        elif model.instance_plane is not None:
+            E = model.render_instance_mlp.output_channels
+            ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
+            nets = [(_lin_params(None, "render_instance_mlp.mlp", views), ctx.inst_s, D, 0)]
+            if model.slow_fast_mode:
+                nets.append((_lin_params(None, "render_instance_mlp.slow_mlp", views), ctx.inst_s, D, E))
+            ctx.inst_grid = grid_head_fwd(model, views, ctx, "instance", nets, "fast" in grad_heads or "slow" in grad_heads)
         else:
             E = model.render_instance_mlp.output_channels
             ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
@@ -1062,6 +1203,40 @@ def appearance_feature_points(model, xyz):
     Wb = views["appearance_basis_mat.weight"]
     out = torch.empty((n, Wb.shape[0]), dtype=torch.float32, device=x.device)
     gemm(n, Wb.shape[0], nc, F, nc, Wb, _pitch(Wb), out, out.shape[1])
+    return out
+
+
+@torch.no_grad()
+def grid_feature_points(model, prefix, xyz):
+    """TensorVMSplit.compute_semantic_feature / compute_instance_feature for a head on its own VM grid: VM products + basis Linear (no gradient)."""
+    x = _points(xyz)
+    reset_rows_limit(x.device)
+    n = x.shape[0]
+    views = model.named_views()
+    vm = vm_struct(views, prefix, grid_res(views))
+    nc = 3 * vm.comps
+    F = torch.empty((n, nc), dtype=torch.float32, device=x.device)
+    call("clift_vm_products_points", C.byref(vm), ptr(x), x.shape[1], n, ptr(F), stream())
+    Wb = views[f"{prefix}_basis_mat.weight"]
+    out = torch.empty((n, Wb.shape[0]), dtype=torch.float32, device=x.device)
+    with exact_fp32():
+        gemm(n, Wb.shape[0], nc, F, nc, Wb, _pitch(Wb), out, out.shape[1])
+    return out
+
+
+@torch.no_grad()
+def feat_mlp_points(seq, feats):
+    """Evaluate a feature-input MLP head (grid heads: MLPRenderSemanticFeature / MLPRenderInstanceFeature on 27 features) on arbitrary rows."""
+    f = _lib.f32(feats, "features").reshape(-1, feats.shape[-1]).contiguous()
+    reset_rows_limit(f.device)
+    M = f.shape[0]
+    layers = [(m.weight, m.bias) for m in seq if isinstance(m, torch.nn.Linear)]
+    ldx = _pitch(layers[0][0])
+    X = torch.zeros((M, ldx), dtype=torch.float32, device=f.device)
+    X[:, :f.shape[1]] = f
+    out = torch.empty((M, layers[-1][0].shape[0]), dtype=torch.float32, device=f.device)
+    with _grid_precision():
+        feat_mlp_fwd(layers, X, M, out, out.shape[1], keep=False)
     return out
 
 

@@ -5,9 +5,10 @@ reference; the arithmetic runs in libclift.so (HIP, gfx950).  Storage differs fr
 every trainable tensor is a view into one flat arena (arena.py) -- VM tables channels-last, weight matrices
 with a 16-byte row pitch -- while keeping the reference's logical shapes.
 
-Supported configuration: ``use_semantic_mlp=True`` and ``use_instance_mlp=True`` (the template default and
-every shipped contrastive-lift config, config/template/panopli_paper.yaml:36-37).  Grid semantic/instance heads
-and distilled-feature grids (reference tensoRF.py:70-83,91-94) raise NotImplementedError (next).
+Both head arrangements of the reference are built: xyz MLPs (``use_semantic_mlp`` / ``use_instance_mlp`` True: the template default and the
+contrastive-lift configs) and heads on their own VM grids (False: 3 x 32 components -> basis Linear -> 27 features -> 3-layer MLP,
+tensoRF.py:70-83; the allgrid / instGRIDsemMLP / onlyRGBsegGRID overlays, round 5).  Distilled-feature grids (tensoRF.py:91-94) raise
+NotImplementedError.
 """
 import ctypes as C
 
@@ -58,8 +59,8 @@ class MLPRenderSemanticFeature(nn.Module):
         self.mlp = _seq_mlp([in_channels] + [dim_mlp] * (num_mlp_layers - 1) + [out_channels])
 
     def forward(self, distilled_feats, feat_xyz):
-        from .engine import xyz_mlp_points
-        out = xyz_mlp_points(self.mlp, feat_xyz)
+        from .engine import feat_mlp_points, xyz_mlp_points
+        out = (xyz_mlp_points if self.in_feat_mlp == 3 else feat_mlp_points)(self.mlp, feat_xyz)
         return torch.softmax(out, -1) if self.softmax else out
 
 
@@ -77,10 +78,11 @@ class MLPRenderInstanceFeature(nn.Module):
             self.slow_mlp = _seq_mlp(dims)     # same architecture, independently initialised (tensoRF.py:483-491)
 
     def forward(self, distilled_feats, feat_xyz):
-        from .engine import xyz_mlp_points
-        out = xyz_mlp_points(self.mlp, feat_xyz)
+        from .engine import feat_mlp_points, xyz_mlp_points
+        fn = xyz_mlp_points if self.in_feat_mlp == 3 else feat_mlp_points
+        out = fn(self.mlp, feat_xyz)
         if self.slow_fast_mode:
-            out = torch.cat([out, xyz_mlp_points(self.slow_mlp, feat_xyz)], -1)
+            out = torch.cat([out, fn(self.slow_mlp, feat_xyz)], -1)
         return out
 
 
@@ -94,9 +96,9 @@ class TensorVMSplit(nn.Module):
                  use_distilled_features_semantic=False, use_distilled_features_instance=False,
                  num_feature_comps=(48, 48, 48), pe_sem=0, pe_ins=0, slow_fast_mode=False, use_proj=False, device=None):
         super().__init__()
-        if not (use_semantic_mlp and use_instance_mlp):
-            raise NotImplementedError("clift: grid semantic/instance heads are not built yet (SURVEY 8f 'next'); "
-                                      "use use_semantic_mlp=True, use_instance_mlp=True (the template default)")
+        for flag, comps, what in ((use_semantic_mlp, num_semantics_comps, "semantic"), (use_instance_mlp, num_instance_comps, "instance")):
+            if not flag and comps is not None and (len(set(comps)) != 1 or comps[0] not in (16, 32, 48)):
+                raise NotImplementedError(f"clift: the {what} grid takes 16, 32 or 48 components per plane, equal on the three planes (got {comps})")
         if use_distilled_features_semantic or use_distilled_features_instance or use_proj or use_feature_reg:
             raise NotImplementedError("clift: distilled-feature grids / projection head / feature regulariser are off "
                                       "in every shipped contrastive-lift config and are not built")
@@ -130,9 +132,24 @@ class TensorVMSplit(nn.Module):
         self.render_appearance_mlp = MLPRenderFeature(dim_appearance, 3, pe_view, pe_feat, dim_mlp_color)
         self.render_instance_mlp = None
         if dim_feature_instance is not None:
-            self.render_instance_mlp = MLPRenderInstanceFeature(3, ins_out, num_mlp_layers=4, dim_mlp=dim_mlp_instance,
-                                                                slow_fast_mode=slow_fast_mode)
-        self.render_semantic_mlp = MLPRenderSemanticFeature(3, num_semantic_classes, softmax=softmax)
+            if num_instance_comps is not None and not use_instance_mlp:       # tensoRF.py:70-74: the head on its own VM grid
+                self.instance_plane, self.instance_line = self.init_one_svd(tuple(num_instance_comps), grid_dim, 0.1)
+                self.instance_basis_mat = nn.Linear(sum(num_instance_comps), dim_instances, bias=False)
+                self.render_instance_mlp = MLPRenderInstanceFeature(dim_instances, ins_out, num_mlp_layers=3, dim_mlp=dim_mlp_instance,
+                                                                    slow_fast_mode=slow_fast_mode)
+            elif use_instance_mlp:
+                self.render_instance_mlp = MLPRenderInstanceFeature(3, ins_out, num_mlp_layers=4, dim_mlp=dim_mlp_instance,
+                                                                    slow_fast_mode=slow_fast_mode)
+        self.render_semantic_mlp = None
+        if num_semantics_comps is not None and not use_semantic_mlp:          # tensoRF.py:78-82
+            self.semantic_plane, self.semantic_line = self.init_one_svd(tuple(num_semantics_comps), grid_dim, 0.1)
+            self.semantic_basis_mat = nn.Linear(sum(num_semantics_comps), dim_semantics, bias=False)
+            self.render_semantic_mlp = MLPRenderSemanticFeature(dim_semantics, num_semantic_classes, num_mlp_layers=3, dim_mlp=dim_mlp_semantics,
+                                                                softmax=softmax)
+        elif use_semantic_mlp:
+            self.render_semantic_mlp = MLPRenderSemanticFeature(3, num_semantic_classes, softmax=softmax)
+        if self.render_semantic_mlp is None:
+            raise NotImplementedError("clift: a field without a semantic head (use_semantic_mlp False and no num_semantics_comps) is not built")
         self.arena = None
         self.param_flat = self.grad_flat = None
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -164,9 +181,21 @@ class TensorVMSplit(nn.Module):
                     out.append((f"{prefix}.{j}.weight", m, "weight", "matrix", grp))
                     out.append((f"{prefix}.{j}.bias", m, "bias", "vector", grp))
         seq("render_appearance_mlp.mlp", self.render_appearance_mlp.mlp, "net_app")
-        # the semantic MLP is its own optimizer range: while it has no gradient source (epoch < late_semantic_optimization)
+
+        def grids(pre, grp):
+            for i in range(3):
+                out.append((f"{pre}_plane.{i}", getattr(self, f"{pre}_plane"), i, "grid", grp))
+            for i in range(3):
+                out.append((f"{pre}_line.{i}", getattr(self, f"{pre}_line"), i, "grid", grp))
+        # the semantic head is its own optimizer range(s): while it has no gradient source (epoch < late_semantic_optimization)
         # the reference's Adam skips it (grad is None), so its step -- and its step COUNT -- must be skippable too
+        if self.semantic_plane is not None:          # head on a VM grid: tables at the grid rate, basis matrix + MLP at the net rate
+            grids("semantic", "grid_sem")
+            out.append(("semantic_basis_mat.weight", self.semantic_basis_mat, "weight", "matrix", "net_sem"))
         seq("render_semantic_mlp.mlp", self.render_semantic_mlp.mlp, "net_sem")
+        if self.instance_plane is not None:
+            grids("instance", "grid_inst")
+            out.append(("instance_basis_mat.weight", self.instance_basis_mat, "weight", "matrix", "inst_fast"))
         if self.render_instance_mlp is not None:
             seq("render_instance_mlp.mlp", self.render_instance_mlp.mlp, "inst_fast")
             if self.slow_fast_mode:
@@ -216,7 +245,7 @@ class TensorVMSplit(nn.Module):
     def xcd_workspace_for(self, prefix):
         """Make sure the accumulation copies of a table group exist (allocation + zero fill happen on the current
         stream, before any side-stream branch uses them)."""
-        a, b = self.arena.range_of({"density": "grid_density", "appearance": "grid_app"}[prefix])
+        a, b = self.arena.range_of({"density": "grid_density", "appearance": "grid_app", "semantic": "grid_sem", "instance": "grid_inst"}[prefix])
         return self.xcd_workspace(prefix, 8 * (b - a))
 
     def xcd_workspace(self, key, numel):
@@ -253,14 +282,25 @@ class TensorVMSplit(nn.Module):
         return appearance_feature_points(self, xyz_sampled)
 
     def compute_semantic_feature(self, xyz_sampled):
-        return xyz_sampled          # use_semantic_mlp (tensoRF.py:142-144)
+        if self.use_semantic_mlp:
+            return xyz_sampled      # tensoRF.py:142-144
+        from .engine import grid_feature_points
+        return grid_feature_points(self, "semantic", xyz_sampled)
 
     def compute_instance_feature(self, xyz_sampled):
-        return xyz_sampled          # use_instance_mlp (tensoRF.py:152-154)
+        if self.use_instance_mlp:
+            return xyz_sampled      # tensoRF.py:152-154
+        from .engine import grid_feature_points
+        return grid_feature_points(self, "instance", xyz_sampled)
 
     # ------------------------------------------------------------------ reference API: grid surgery (tensoRF.py:158-197)
     def _grid_lists(self):
-        return ((self.density_plane, self.density_line), (self.appearance_plane, self.appearance_line))
+        out = [(self.density_plane, self.density_line), (self.appearance_plane, self.appearance_line)]
+        if self.semantic_plane is not None:
+            out.append((self.semantic_plane, self.semantic_line))
+        if self.instance_plane is not None:
+            out.append((self.instance_plane, self.instance_line))
+        return tuple(out)
 
     @torch.no_grad()
     def shrink(self, t_l, b_r):
@@ -294,43 +334,59 @@ class TensorVMSplit(nn.Module):
 
     # ------------------------------------------------------------------ reference API: optimizer groups
     def get_optimizable_parameters(self, lr_grid, lr_net, weight_decay=0):
-        """tensoRF.py:199-213 (MLP-heads configuration)."""
-        return [{'params': self.density_line, 'lr': lr_grid, 'weight_decay': weight_decay},
-                {'params': self.appearance_line, 'lr': lr_grid},
-                {'params': self.density_plane, 'lr': lr_grid, 'weight_decay': weight_decay},
-                {'params': self.appearance_plane, 'lr': lr_grid},
-                {'params': self.appearance_basis_mat.parameters(), 'lr': lr_net},
-                {'params': self.render_appearance_mlp.parameters(), 'lr': lr_net},
-                {'params': self.render_semantic_mlp.parameters(), 'lr': lr_net}]
+        """tensoRF.py:199-213."""
+        g = [{'params': self.density_line, 'lr': lr_grid, 'weight_decay': weight_decay},
+             {'params': self.appearance_line, 'lr': lr_grid},
+             {'params': self.density_plane, 'lr': lr_grid, 'weight_decay': weight_decay},
+             {'params': self.appearance_plane, 'lr': lr_grid},
+             {'params': self.appearance_basis_mat.parameters(), 'lr': lr_net},
+             {'params': self.render_appearance_mlp.parameters(), 'lr': lr_net}]
+        if self.semantic_plane is not None:
+            g += [{'params': self.semantic_plane, 'lr': lr_grid}, {'params': self.semantic_line, 'lr': lr_grid},
+                  {'params': self.semantic_basis_mat.parameters(), 'lr': lr_net}]
+        return g + [{'params': self.render_semantic_mlp.parameters(), 'lr': lr_net}]
 
     def get_optimizable_instance_parameters(self, lr_grid, lr_net, using_DINO=False):
-        """tensoRF.py:229-246: fast MLP always; slow MLP only when not DINO-style."""
-        g = [{'params': self.render_instance_mlp.mlp.parameters(), 'lr': lr_net}]
+        """tensoRF.py:229-246: (grid head: its planes / lines at the grid rate, the basis matrix,) the fast MLP; the slow MLP only when not DINO-style."""
+        g = []
+        if self.instance_plane is not None:
+            g += [{'params': self.instance_plane, 'lr': lr_grid}, {'params': self.instance_line, 'lr': lr_grid},
+                  {'params': self.instance_basis_mat.parameters(), 'lr': lr_net}]
+        g.append({'params': self.render_instance_mlp.mlp.parameters(), 'lr': lr_net})
         if self.slow_fast_mode and not using_DINO:
             g.append({'params': self.render_instance_mlp.slow_mlp.parameters(), 'lr': lr_net})
         return g
 
     # ------------------------------------------------------------------ reference API: TV regulariser
     def total_tv_loss(self, regularizer=None, config=None, current_epoch=0, accumulate_grad=True, scale=1.0):
-        """tensoRF.py:248-258,281-290 for the MLP-heads configuration: density and appearance PLANES, x1e-2 each,
-        weighted by config.lambda_tv_density / lambda_tv_appearance.  One streaming HIP pass per plane computes the
-        value and (accumulate_grad) adds ``scale * d loss`` straight into the gradient arena.
-        Returns a 0-dim device tensor (detached)."""
-        lam_d = float(getattr(config, "lambda_tv_density", 0.1)) if config is not None else 0.1
-        lam_a = float(getattr(config, "lambda_tv_appearance", 0.01)) if config is not None else 0.01
+        """tensoRF.py:248-290: density and appearance PLANES x 1e-2, weighted by config.lambda_tv_density / lambda_tv_appearance; with a head on
+        its own VM grid, that grid's planes x 1e-2 + LINES x 1e-3 weighted by lambda_tv_semantics / lambda_tv_instances, from
+        late_semantic_optimization / instance_optimization_epoch on.  One streaming HIP launch per eight tables computes the value and
+        (accumulate_grad) adds ``scale * d loss`` straight into the gradient arena -- except for the INSTANCE grid, whose term only enters the
+        value: in the reference that gradient lands on parameters of the instance optimizer, which clears them (T:211) before its own
+        backward, so it is never applied.  Returns a 0-dim device tensor (detached)."""
+        g = lambda k, d: float(getattr(config, k, d)) if config is not None else d
+        sem_on = config is None or current_epoch >= getattr(config, "late_semantic_optimization", 0)
+        inst_on = config is None or current_epoch >= getattr(config, "instance_optimization_epoch", 0)
+        terms = [(f"{pre}_plane.{i}", lam * 1e-2, True) for pre, lam in (("density", g("lambda_tv_density", 0.1)), ("appearance", g("lambda_tv_appearance", 0.01)))
+                 for i in range(3)]
+        if self.semantic_plane is not None and sem_on:
+            lam = g("lambda_tv_semantics", 0.02)
+            terms += [(f"semantic_plane.{i}", lam * 1e-2, True) for i in range(3)] + [(f"semantic_line.{i}", lam * 1e-3, True) for i in range(3)]
+        if self.instance_plane is not None and inst_on:
+            lam = g("lambda_tv_instances", 0.02)
+            terms += [(f"instance_plane.{i}", lam * 1e-2, False) for i in range(3)] + [(f"instance_line.{i}", lam * 1e-3, False) for i in range(3)]
         out = torch.zeros(1, dtype=torch.float32, device=self.param_flat.device)
-        ts = _lib.TVSet()
-        n = 0
-        for pre, lam in (("density", lam_d), ("appearance", lam_a)):
-            for i in range(3):
-                p = self._views[f"{pre}_plane.{i}"]
-                g = self._gviews[f"{pre}_plane.{i}"] if accumulate_grad else None
+        for c0 in range(0, len(terms), 8):
+            ts = _lib.TVSet()
+            for n, (name, wgt, with_grad) in enumerate(terms[c0:c0 + 8]):
+                p = self._views[name]
+                gr = self._gviews[name] if (accumulate_grad and with_grad) else None
                 _, c, h, w = p.shape
-                ts.plane[n], ts.grad[n] = p.data_ptr(), (g.data_ptr() if g is not None else None)
-                ts.H[n], ts.W[n], ts.C[n], ts.weight[n] = h, w, c, float(lam * 1e-2 * scale)
-                n += 1
-        ts.n = n
-        _lib.call("clift_tv_fwd_bwd_multi", C.byref(ts), _lib.ptr(out), _lib.stream())     # all six planes in one launch
+                ts.plane[n], ts.grad[n] = p.data_ptr(), (gr.data_ptr() if gr is not None else None)
+                ts.H[n], ts.W[n], ts.C[n], ts.weight[n] = h, w, c, float(wgt * scale)
+            ts.n = len(terms[c0:c0 + 8])
+            _lib.call("clift_tv_fwd_bwd_multi", C.byref(ts), _lib.ptr(out), _lib.stream())     # (all six planes of the MLP-heads field in one launch)
         return out[0] / scale if scale != 1.0 else out[0]
 
     # ------------------------------------------------------------------ checkpoint helpers

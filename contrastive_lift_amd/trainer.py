@@ -122,14 +122,17 @@ class HotPathTrainer:
     # ------------------------------------------------------------------ optimizers (T:98-103)
     def setup_optimizers(self):
         m, c = self.model, self.config
+        have = lambda *gs: [g for g in gs if g in m.arena.groups]                # (grid_sem / grid_inst exist only when that head sits on its own VM grid)
         a0, a1 = m.arena.range_of("grid_density", "grid_app")
         b0, b1 = m.arena.range_of("net_app")
         s0, s1 = m.arena.range_of("net_sem")
-        self.opt_main = ArenaAdam(m, [("grids", a0, a1, c.lr * 20), ("net_app", b0, b1, c.lr), ("net_sem", s0, s1, c.lr)],
-                                  (0.9, 0.99), c.weight_decay)
-        self.main_range = m.arena.range_of("grid_density", "grid_app", "net_app", "net_sem")
+        main = [("grids", a0, a1, c.lr * 20), ("net_app", b0, b1, c.lr)]
+        if have("grid_sem"):                                                     # tensoRF.py:205-208: the semantic tables at the grid rate
+            main.append(("grid_sem",) + m.arena.range_of("grid_sem") + (c.lr * 20,))
+        self.opt_main = ArenaAdam(m, main + [("net_sem", s0, s1, c.lr)], (0.9, 0.99), c.weight_decay)
+        self.main_range = m.arena.range_of(*have("grid_density", "grid_app", "net_app", "grid_sem", "net_sem"))
         self.late_range = m.arena.range_of("grid_density")                       # final only after the density backward
-        self.early_range = m.arena.range_of("grid_app", "net_app", "net_sem")     # final once the head chains are issued
+        self.early_range = m.arena.range_of(*have("grid_app", "net_app", "grid_sem", "net_sem"))     # final once the head chains are issued
         # data-parallel exchange of the main pass: True = early range all-reduced asynchronously under the density backward, False = one
         # synchronous all-reduce after the backward, "auto" (default) = measure both over the first steps and keep the faster one.  The
         # persistent kernels hold one block per CU for a whole launch, so while the asynchronous collective is in flight they leave
@@ -142,8 +145,11 @@ class HotPathTrainer:
         # The slow MLP is listed in the reference's instance optimizer when not DINO-style (F:241-244), but its output is detached
         # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
         i0, i1 = m.arena.range_of("inst_fast")
-        self.opt_inst = ArenaAdam(m, [("inst_fast", i0, i1, c.lr)], (0.9, 0.999), c.weight_decay)
-        self.inst_range = (i0, i1)
+        inst = [("inst_fast", i0, i1, c.lr)]
+        if have("grid_inst"):                                                    # tensoRF.py:232-236: the instance tables at the grid rate
+            inst.insert(0, ("grid_inst",) + m.arena.range_of("grid_inst") + (c.lr * 20,))
+        self.opt_inst = ArenaAdam(m, inst, (0.9, 0.999), c.weight_decay)
+        self.inst_range = m.arena.range_of(*have("grid_inst", "inst_fast"))
         # sync-free capacities were learnt for the previous grid / step size / bounding box: forget them (two synchronising steps again)
         if hasattr(self, "_caps"):
             self._caps = {}
@@ -159,6 +165,8 @@ class HotPathTrainer:
         self._shards = None
         if self.device.type != "cuda" or not bool(getattr(self.config, "grad_shards", True)):
             return
+        if "grid_sem" in m.arena.groups or "grid_inst" in m.arena.groups:
+            return           # (a head on its own VM grid puts tables between the MLP ranges: the shard range would span them; those configs add directly)
         s0, s1 = m.arena.range_of("net_app", "net_sem", "inst_fast")
         n = s1 - s0
         stride = (n + 63) // 64 * 64                                   # floats; shards start on 256-byte boundaries
@@ -401,7 +409,7 @@ class HotPathTrainer:
         if calibrating:
             torch.cuda.synchronize(self.device)
             self._calibration_record(early, time.perf_counter() - t_cal)
-        self.opt_main.step(skip=() if sem_on else ("net_sem",))      # no semantic term yet: the head's grad is None in the reference
+        self.opt_main.step(skip=() if sem_on else ("net_sem", "grid_sem"))      # no semantic term yet: the head's grad is None in the reference
         self.last_outputs = (rgb, sem)
         return ctxs
 

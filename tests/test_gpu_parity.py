@@ -953,7 +953,7 @@ def test_psnr_parity_over_a_training_trajectory():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
@@ -967,8 +967,15 @@ def test_g12_reference_training_steps_on_gpu(fixture):
     C_, E = int(g["C"]), int(g["E"])
     mode = str(g["mode"]) if "mode" in g else "slow_fast"
     sf = mode == "slow_fast"
-    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf), res, 2.5, 0.45)
-    m = build_model(cl, P, res, C_, E, float(g["shift"]), slow_fast=sf)
+    grids = "grid_heads" in fixture                # sixth fixture: both heads on their own VM grids (the allgrid overlay), plain contrastive loss
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf, sem_grid=grids, inst_grid=grids), res, 2.5, 0.45)
+    if grids:
+        m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_, dim_feature_instance=E,
+                             splus_density_shift=float(g["shift"]), use_semantic_mlp=False, use_instance_mlp=False, slow_fast_mode=False, device=DEV)
+        missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
+        assert not missing and not unexpected
+    else:
+        m = build_model(cl, P, res, C_, E, float(g["shift"]), slow_fast=sf)
     r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
     cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
                          use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False, max_instances=E)

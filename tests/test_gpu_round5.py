@@ -235,3 +235,85 @@ def test_linear_assignment_mode_with_a_wide_instance_layer_against_the_oracle():
             if k.startswith("render_instance_mlp."):
                 diff = float((sd[k].cpu() - v.detach()).abs().max())
                 assert diff <= 0.1 * 5e-4 * (step + 1) + 1e-7, (step, k, diff)
+
+
+# ============================================================================ heads on their own VM grids (tensoRF.py:70-83,142-156)
+def _grid_model(cl, P, res, C_, E, sem_grid, inst_grid, sf):
+    m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_,
+                         dim_feature_instance=(2 * E if sf else E), splus_density_shift=-3.0, use_semantic_mlp=not sem_grid, use_instance_mlp=not inst_grid,
+                         slow_fast_mode=sf, device=DEV)
+    missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+def _digest(g, prefix, named_grads, min_checked):
+    from conftest import T
+    n = 0
+    for k, gr in named_grads.items():
+        key = f"{prefix}sub.{k}"
+        if key not in g:
+            continue
+        if gr is None:
+            flat = torch.zeros(1)
+        elif gr.dim() == 4:                      # channels-last view -> logical NCHW order of the fixture
+            flat = gr.detach().contiguous(memory_format=torch.contiguous_format).reshape(-1).cpu()
+        else:
+            flat = gr.detach().contiguous().reshape(-1).cpu()
+        sub = flat if flat.numel() <= 4096 else flat[::17]
+        ref = T(g[key]).double()
+        scale = float(T(g[f"{prefix}norm.{k}"])) / max(1.0, np.sqrt(flat.numel()))
+        rel_close(sub, ref, 2e-3, atol=2e-3 * max(scale, 1e-12) + 1e-9, what=key)
+        rel_close(flat.norm(), g[f"{prefix}norm.{k}"], 1e-3, atol=1e-9, what=f"norm {k}")
+        n += 1
+    assert n >= min_checked, n
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_grid_heads_golden_g19(tag):
+    """The semantic / instance heads on their own VM grids against the REFERENCE's outputs and gradients (golden G19): full forward + backward,
+    instance-feature and segment-feature passes, the TV term with the grid terms; (a) both heads on grids, (b) semantic MLP + instance grid with
+    the slow-fast twin.  Also the reference API of such a field: compute_semantic_feature / compute_instance_feature + the heads' forward."""
+    from conftest import T, load_golden
+    from test_gpu_parity import _import, _run_forward_backward
+    cl, op, orender, ofld, olosses, orays = _import()
+    g = load_golden("g19_grid_heads")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    sem_grid, inst_grid, sf = bool(int(g[f"{tag}.sem_grid"])), bool(int(g[f"{tag}.inst_grid"])), bool(int(g[f"{tag}.slow_fast"]))
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf, sem_grid=sem_grid, inst_grid=inst_grid), res, 2.5, 0.45)
+    m = _grid_model(cl, P, res, C_, E, sem_grid, inst_grid, sf)
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+    rays = T(g[f"{tag}.rays"])
+    outs, grads = _run_forward_backward(cl, m, r, rays, T(g[f"{tag}.jitter"]), False, (T(g[f"{tag}.cot_rgb"]), T(g[f"{tag}.cot_sem"]), T(g[f"{tag}.cot_inst"])))
+    for a, nm in zip(outs[:4], ("rgb", "sem", "inst", "depth")):
+        rel_close(a, g[f"{tag}.{nm}"], 1e-3, what=nm)
+    _digest(g, f"{tag}.g", grads, 30)
+    names = [k for k, _ in m.named_parameters()]
+    fi, xyz = r.forward_instance_feature(m, rays.to(DEV), 0, False)
+    rel_close(fi, g[f"{tag}.f_inst"], 1e-3, what="instance features")
+    rel_close(xyz, g[f"{tag}.f_xyz"], 1e-3, what="surface points")
+    gr = torch.autograd.grad((fi * T(g[f"{tag}.cot_inst"]).to(DEV)).sum(), list(m.parameters()), allow_unused=True)
+    _digest(g, f"{tag}.fi.g", dict(zip(names, gr)), 6)
+    fs = r.forward_segment_feature(m, rays.to(DEV), 0, False)
+    rel_close(fs, g[f"{tag}.f_seg"], 1e-3, what="segment features")
+    gr = torch.autograd.grad((fs * T(g[f"{tag}.cot_sem"]).to(DEV)).sum(), list(m.parameters()), allow_unused=True)
+    _digest(g, f"{tag}.fs.g", dict(zip(names, gr)), 6)
+    # TV with every grid term on: value, and the gradient it adds to the arena (the instance grid's term enters the value only)
+    m.grad_flat.zero_()
+    cfg = type("Cfg", (), dict(late_semantic_optimization=0, instance_optimization_epoch=0, lambda_tv_density=0.1, lambda_tv_appearance=0.01,
+                               lambda_tv_semantics=0.02, lambda_tv_instances=0.02))
+    tv = m.total_tv_loss(None, cfg, 1, accumulate_grad=True)
+    rel_close(tv, g[f"{tag}.tv"], 1e-4, what="TV with the grid terms")
+    gv = m.named_grad_views()
+    _digest(g, f"{tag}.tv.g", {k: gv[k] for k in gv if k.split(".")[0].endswith(("_plane", "_line")) and not k.startswith("instance_")}, 12 if not sem_grid else 18)
+    if inst_grid:
+        assert float(gv["instance_plane.0"].abs().max()) == 0.0
+    # point-wise reference API
+    x = torch.rand((257, 3), device=DEV) * 1.6 - 0.8
+    Pd = {k: v for k, v in P.items()}
+    if sem_grid:
+        rel_close(m.compute_semantic_feature(x), ofld.grid_feature(Pd, "semantic", x.cpu()), 1e-3, what="compute_semantic_feature")
+        rel_close(m.render_semantic_mlp(None, m.compute_semantic_feature(x)), ofld.semantic_head(Pd, x.cpu()), 1e-3, what="semantic head on points")
+    if inst_grid:
+        rel_close(m.render_instance_mlp(None, m.compute_instance_feature(x)), ofld.instance_head(Pd, x.cpu()), 1e-3, what="instance head on points")
