@@ -375,7 +375,10 @@ def main():
         if roof is not None:
             # (the driver's record keeps `roofline`, `config` and `cpu_baseline` whole and only the NAMES of other keys: what a reader of that
             # record should see of the extras rides inside `roofline`)
-            for k in ("exact_fp32", "fp32x6", "bf16", "configs3_strong_scaling_projection", "inference_roofline"):
+            if "rays1024_ms_per_step" in extra:
+                extra["rays1024"] = {"ms_per_step": extra["rays1024_ms_per_step"], "nosync_ms_per_step": extra.get("rays1024_nosync_ms_per_step"),
+                                     "shape": "1024 main-pass rays + 1024 instance rays (configs[3] per-GPU shape)"}
+            for k in ("exact_fp32", "fp32x6", "bf16", "rays1024", "configs3_strong_scaling_projection", "inference_roofline"):
                 if k in extra:
                     roof.setdefault("other_measurements", {})[k] = extra[k]
     rccl_ranks = dist.get_world_size() if (world > 1 and backend == "nccl") else 0
@@ -711,6 +714,19 @@ def small_batch_probe(a, dev, pool, S, main_range, rays=1024, steps=10, warmup=3
             tr.training_step(bs[i % 4], lean=a.lean)
         torch.cuda.synchronize()
         out[n] = extras_step_time(tr, bs, steps, a.lean)
+    # the same 1024 + 1024 step in the sync-free mode (no read-back of the active-sample count; VERDICT r4 item 5 / weak point 8: at this shape --
+    # ~45 % of the step in sub-50-us launches -- the gaps around the two read-backs are a larger share than at 4096 rays)
+    nosync_ms = None
+    if a.dtype in ("fp32", "fp32x6"):
+        model, renderer, _ = synthetic.make_scene(grid=a.grid, num_classes=a.classes, max_instances=3, seed=0, device=dev)
+        tr = HotPathTrainer(model, renderer, default_config(chunk=a.chunk, instance_optimization_epoch=0, late_semantic_optimization=0, mlp_dtype=a.dtype, nosync=True),
+                            current_epoch=4)
+        bs = [synthetic.make_batches(pool, rays, a.inst_rays, a.classes, 25, seed=300 + i, device=dev) for i in range(4)]
+        for i in range(warmup + 3):          # (+ the two capacity-learning steps of the mode)
+            tr.training_step(bs[i % 4], lean=a.lean)
+        torch.cuda.synchronize()
+        nosync_ms = extras_step_time(tr, bs, steps, a.lean) * 1e3
+        overflow = tr.overflow_steps
     nbytes = 4 * (main_range[1] - main_range[0])
     # ring all-reduce over the 8 GPUs of a node: 2 (N-1)/N of the buffer per link direction; RCCL reaches ~150 GB/s bus bandwidth at this
     # message size on xGMI (7 links x ~50 GB/s per direction shared by the ring's two neighbours), + ~40 us of launch / sync latency per collective
@@ -718,6 +734,9 @@ def small_batch_probe(a, dev, pool, S, main_range, rays=1024, steps=10, warmup=3
     t1, t8 = out[8 * rays] * 1e3, out[rays] * 1e3
     return {"rays1024_ms_per_step": round(t8, 3), "rays1024_ray_samples_per_s": (rays + a.inst_rays) * S / out[rays],
             "rays8192_ms_per_step": round(t1, 3),
+            "rays1024_nosync_ms_per_step": (round(nosync_ms, 3) if nosync_ms is not None else None),
+            "rays1024_nosync_note": (f"the same step with config.nosync (no host read-back; capacities instead of counts): {nosync_ms:.3f} ms against {t8:.3f} ms with "
+                                     f"the two read-backs; {overflow} capacity overflows" if nosync_ms is not None else None),
             "rays1024_note": f"configs[3] per-GPU shape (8192 global rays / 8 ranks): 1024 main-pass rays + 1024 instance rays per step, {a.dtype}",
             "configs3_strong_scaling_projection": {
                 "projected_strong_scaling_8gpu": t1 / (t8 + ar_ms), "one_gpu_8192_rays_ms": round(t1, 3), "per_gpu_1024_rays_ms": round(t8, 3),

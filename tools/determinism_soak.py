@@ -160,18 +160,26 @@ if n_steps > 0:
         return o, ctx
     engine.render_forward, engine.feature_forward = rf, ff
 
-    def step():
+    def restore():
         with torch.no_grad():
             model.param_flat.copy_(snap["p"])
         tr.opt_main.m.copy_(snap["m0"]); tr.opt_main.v.copy_(snap["v0"]); tr.opt_main.t = dict(snap["t0"])
         tr.opt_inst.m.copy_(snap["m1"]); tr.opt_inst.v.copy_(snap["v1"]); tr.opt_inst.t = dict(snap["t1"])
+
+    def step():
+        # Both passes start from the SAME snapshot: the main pass ends with an Adam step on gradients that were summed through floating-point
+        # atomics (order-dependent in the last bits), so an instance pass run behind it sees slightly different tables in every replay -- the
+        # first version of this tool did that and every instance-pass tensor "differed" (profiles/r05_determinism_before_fix.txt)
+        restore()
         del captured[:], fwd_ctx[:]
         t, soft = {}, {}
         tr.main_pass(batches[0], jitter=jit_main, white_bg=False)
         soft["grad.main"] = model.grad_flat[tr.main_range[0]:tr.main_range[1]].clone()
+        soft["param.after_main"] = model.param_flat.detach().clone()
+        restore()
         tr.instance_pass(batches[1], jitter=jit_inst)
         soft["grad.inst"] = model.grad_flat[tr.inst_range[0]:tr.inst_range[1]].clone()
-        soft["param.after"] = model.param_flat.detach().clone()
+        soft["param.after_inst"] = model.param_flat.detach().clone()
         for pi, (o, ctx) in enumerate(fwd_ctx):
             for k, v in ctx_tensors({k_: o.get(k_) for k_ in ("rgb", "semantics", "instances", "depth", "opacity")}, ctx, f"p{pi}.").items():
                 if v is not None:
