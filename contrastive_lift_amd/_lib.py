@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclift.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -98,6 +98,7 @@ _SIGNATURES = {
     "clift_app_front_fwd": ([_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_app_front_fwd_x": ([_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P], C.c_int),
     "clift_app_head_last2_bf16_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
+    "clift_app_head_last2_x6_fwd": ([_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P], C.c_int),
     "clift_out_layer_bwd_n128_bf16": ([_P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P], C.c_int),
     "clift_gemm": ([_P, _P], C.c_int),
     "clift_linear_k3_fwd": ([_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P], C.c_int),

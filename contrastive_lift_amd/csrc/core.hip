@@ -20,7 +20,7 @@ int clift_check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int clift_version(void) { return 17; }
+extern "C" int clift_version(void) { return 18; }
 
 // Data-parallel runs: while an asynchronous RCCL all-reduce is in flight the persistent launches (one block per CU, held for the whole
 // launch) leave `k` CUs to the collective's kernels.  Host state of the calling process; takes effect at the next launch.
@@ -43,6 +43,7 @@ void clift_bind_rows_limit_layer_x6(const int* p);
 void clift_bind_rows_limit_layer_bf16(const int* p);
 void clift_bind_rows_limit_layer_x6w(const int* p);
 void clift_bind_rows_limit_layer_nb16(const int* p);
+void clift_bind_rows_limit_layer_n6(const int* p);
 
 extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_march(dev_limit);
@@ -55,6 +56,7 @@ extern "C" int clift_bind_rows_limit(const int* dev_limit) {
     clift_bind_rows_limit_layer_bf16(dev_limit);
     clift_bind_rows_limit_layer_x6w(dev_limit);
     clift_bind_rows_limit_layer_nb16(dev_limit);
+    clift_bind_rows_limit_layer_n6(dev_limit);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { clift_set_error("clift_bind_rows_limit: %s", hipGetErrorString(e)); return 2; }
     return 0;
@@ -70,6 +72,7 @@ void clift_bind_grad_shards_layer_x6(const void* p);
 void clift_bind_grad_shards_layer_bf16(const void* p);
 void clift_bind_grad_shards_layer_x6w(const void* p);
 void clift_bind_grad_shards_layer_nb16(const void* p);
+void clift_bind_grad_shards_layer_n6(const void* p);
 
 extern "C" int clift_bind_grad_shards(const void* dev_desc) {
     clift_bind_grad_shards_march(dev_desc);
@@ -82,6 +85,7 @@ extern "C" int clift_bind_grad_shards(const void* dev_desc) {
     clift_bind_grad_shards_layer_bf16(dev_desc);
     clift_bind_grad_shards_layer_x6w(dev_desc);
     clift_bind_grad_shards_layer_nb16(dev_desc);
+    clift_bind_grad_shards_layer_n6(dev_desc);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { clift_set_error("clift_bind_grad_shards: %s", hipGetErrorString(e)); return 2; }
     return 0;

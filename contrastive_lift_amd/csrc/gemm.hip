@@ -254,6 +254,20 @@ extern "C" int clift_gemm(const clift_gemm_t* h, clift_stream_t s) {
     if (h->precision == 2 && h->a_trans && h->b_trans && h->M == 256 && h->N == 256 && h->K >= 4096 && h->accumulate && !h->c_trans && !h->bias && !h->mask &&
         h->act == 0 && h->lda % 4 == 0 && h->ldb % 4 == 0 && (((uintptr_t)h->A) & 15) == 0 && (((uintptr_t)h->B) & 15) == 0)
         return clift_wgrad_x6_launch(p, st);
+    // fp32x6, the 128-wide appearance layers (layer_n6.hip): forward K = 128 / 160 -> 128 (bias, ReLU), masked input gradient 128 -> 128, unmasked
+    // input gradient 128 -> 160, every M (a row's bits must not depend on its launch); and their weight gradients 128 x {128, 160}
+    if (h->precision == 2 && !h->a_trans && splits == 1 && !h->accumulate && !h->c_trans && h->lda % 4 == 0 && h->lda >= h->K && h->ldc % 4 == 0 &&
+        (((uintptr_t)h->C) & 15) == 0 && getenv("CLIFT_NO_PERSISTENT") == nullptr && getenv("CLIFT_X6_TILED") == nullptr) {
+        const bool fwd = !h->b_trans && h->N == 128 && (h->K == 128 || h->K == 160) && !h->mask && h->ldb >= h->K && h->ldc >= 128 && (h->act == 0 || h->act == 1);
+        const bool dg_m = h->b_trans && h->N == 128 && h->K == 128 && h->mask && !h->bias && h->act == 0 && h->ldmask % 4 == 0 && h->ldmask >= 128 &&
+                          (((uintptr_t)h->mask) & 15) == 0 && h->ldb >= 128 && h->ldc >= 128;
+        const bool dg_u = h->b_trans && h->N == 160 && h->K == 128 && !h->mask && !h->bias && h->act == 0 && h->ldb >= 160 && h->ldc >= 160;
+        if (fwd || dg_m || dg_u) return clift_layer_n6_launch(p, h->b_trans, st);
+    }
+    if (h->precision == 2 && h->a_trans && h->b_trans && h->M == 128 && (h->N == 128 || h->N == 160) && h->K >= 1 && h->accumulate && !h->c_trans && !h->bias &&
+        !h->mask && h->act == 0 && h->lda % 4 == 0 && h->lda >= 128 && h->ldb % 4 == 0 && h->ldb >= h->N && h->ldc >= h->N &&
+        getenv("CLIFT_NO_PERSISTENT") == nullptr && getenv("CLIFT_X6_TILED") == nullptr)
+        return clift_wgrad_n6_launch(p, st);
     // fp32x6: forward / dgrad forms (row-major A, one weight-sized B); any other shape takes the tiled split kernel
     if (h->precision == 2 && !h->a_trans && !h->accumulate && splits == 1 && !h->c_trans && (long)h->N * h->K <= (1L << 22)) {
         const long need = clift_gemm_split_workspace_bytes(h->N, h->K);

@@ -55,6 +55,8 @@ long clift_gemm_split_workspace_bytes(int N, int K);                            
 int clift_gemm_split_launch(const GemmP& p, int a_trans, int b_trans, void* workspace, hipStream_t st);
 int clift_layer_x6_launch(const GemmP& p, int b_trans, hipStream_t st);                              // layer_x6.hip
 int clift_wgrad_x6_launch(const GemmP& p, hipStream_t st);                                           // layer_x6w.hip
+int clift_layer_n6_launch(const GemmP& p, int b_trans, hipStream_t st);                              // layer_n6.hip
+int clift_wgrad_n6_launch(const GemmP& p, hipStream_t st);
 
 // acc[x][y] = 32x32 accumulator tile (x, y) of this wave; (wm, wn) = wave coordinates in the block; li = lane & 31,
 // lh = lane >> 5.  csum = this thread's partial bias-gradient (column sum of A) when do_colsum.

@@ -119,6 +119,10 @@ def exact_fp32():
 # bf16-STORED input / hidden activations / hidden gradients (csrc/layer_nb16.hip), like the xyz heads of that mode.  Tests clear APP_BF16 to get the
 # old arrangement back.
 APP_BF16 = True
+# fp32x6 mode and the same layers.  Rounds 3 - 4 kept them exact as well (the only split kernel for their shapes was the tiled one: slower than the
+# exact persistent kernels).  Round 5: persistent split kernels for the 128-wide forms (csrc/layer_n6.hip) -- 6 / 16 of the matrix time, the same
+# fp32 streams.  Tests clear APP_X6 to get the exact arrangement back.
+APP_X6 = True
 
 
 def _app_precision():
@@ -127,6 +131,8 @@ def _app_precision():
     # mode whose results were disturbed by the other process's fp32x6 launches (profiles/r03_x6_notes.txt).  Exact fp32 there.
     if MLP_PRECISION == 1 and APP_BF16 and os.environ.get("CLIFT_NO_PERSISTENT") is None:
         return _Precision(1)
+    if MLP_PRECISION == 2 and APP_X6 and os.environ.get("CLIFT_NO_PERSISTENT") is None and os.environ.get("CLIFT_X6_TILED") is None:
+        return _Precision(2)
     if MLP_PRECISION in (1, 2):
         return _Precision(0)
     return _Precision(MLP_PRECISION)
@@ -175,10 +181,21 @@ def gemm(M, N, K, A, lda, B, ldb, Cm, ldc, a_trans=0, b_trans=0, bias=None, act=
     # ... and their weight gradients (csrc/layer_x6w.hip)
     x6w = (a_trans and b_trans and M == 256 and N == 256 and K >= 4096 and accumulate and not c_trans and bias is None and mask is None
            and not act and int(lda) % 4 == 0 and int(ldb) % 4 == 0 and A.dtype == torch.float32 and B.dtype == torch.float32)
-    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6 or x6w) else 0
+    # ... and the 128-wide layers of the appearance MLP (csrc/layer_n6.hip): forward K in {128, 160} -> 128, masked dgrad 128 -> 128, unmasked dgrad
+    # 128 -> 160, weight gradients 128 x {128, 160}
+    f32s = A.dtype == torch.float32 and B.dtype == torch.float32 and Cm.dtype == torch.float32
+    n6 = (f32s and not a_trans and not accumulate and not c_trans and int(lda) % 4 == 0 and int(lda) >= K and int(ldc) % 4 == 0 and g.C % 16 == 0 and
+          ((not b_trans and N == 128 and K in (128, 160) and mask is None and int(ldb) >= K and act in (0, 1)) or
+           (b_trans and K == 128 and bias is None and not act and
+            ((N == 128 and mask is not None and int(ldmask) % 4 == 0 and int(ldmask) >= 128 and g.mask % 16 == 0) or (N == 160 and mask is None and int(ldb) >= 160)))))
+    n6w = (f32s and a_trans and b_trans and M == 128 and N in (128, 160) and accumulate and not c_trans and bias is None and mask is None and not act
+           and int(lda) % 4 == 0 and int(lda) >= 128 and int(ldb) % 4 == 0 and int(ldb) >= N and int(ldc) >= N)
+    if os.environ.get("CLIFT_NO_PERSISTENT") is not None or os.environ.get("CLIFT_X6_TILED") is not None:
+        n6 = n6w = False
+    g.precision = MLP_PRECISION if (MLP_PRECISION != 2 or x6 or x6w or n6 or n6w) else 0
     g.a_bf16, g.b_bf16 = int(A.dtype == torch.bfloat16), int(B.dtype == torch.bfloat16)
     g.c_bf16, g.mask_bf16 = int(Cm.dtype == torch.bfloat16), int(mask is not None and mask.dtype == torch.bfloat16)
-    if g.precision == 2 and not x6w:
+    if g.precision == 2 and not (x6w or n6 or n6w):
         # the persistent split kernel takes 16-byte aligned rows; anything else (odd output pitch ...) goes to the library's tiled split
         # kernel, which needs a workspace for the split weight planes
         persistent = (int(lda) % 4 == 0 and int(ldc) % 4 == 0 and g.C % 16 == 0 and (mask is None or (int(ldmask) % 4 == 0 and g.mask % 16 == 0))
@@ -803,7 +820,11 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                     and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # second hidden layer + output layer + sigmoid in one launch; H2 is written only for a backward
                 H2 = torch.empty((M, 128), dtype=torch.float32, device=dev) if "app" in grad_heads else None
-                app_last2(M, H1, W2, b2, W3, b3, H2, rgb_s)
+                if MLP_PRECISION == 2 and os.environ.get("CLIFT_X6_TILED") is None:        # (only inside _app_precision() with APP_X6)
+                    call("clift_app_head_last2_x6_fwd", ptr(H1), 128, ptr(W2), _pitch(W2), ptr(b2), ptr(W3), _pitch(W3), ptr(b3), W3.shape[0], M,
+                         ptr(H2), 128, ptr(rgb_s), 3, 1, stream())
+                else:
+                    app_last2(M, H1, W2, b2, W3, b3, H2, rgb_s)
             elif (MLP_PRECISION == 1 and hdt == torch.bfloat16 and H1.dtype == torch.bfloat16 and tuple(W2.shape) == (128, 128) and W3.shape[0] <= 4
                     and W3.shape[1] == 128 and M >= 64 and os.environ.get("CLIFT_NO_PERSISTENT") is None):
                 # bf16 mode: the same pair of layers over the bf16-stored activation (csrc/layer_nb16.hip)

@@ -199,7 +199,10 @@ int clift_app_front_fwd_x(const clift_march_t* h_m, const clift_vm_t* h_app, con
  *   v_mfma_f32_32x32x16_bf16 with fp32 accumulation; all tensors stay fp32 in memory (BASELINE config 3).
  * precision 2: "fp32x6" -- fp32-faithful products on the bf16 matrix cores: every operand value is split exactly into three
  *   bf16 terms and the six leading cross products are accumulated in fp32 (error below fp32 product rounding).  Applies to
- *   the forward / dgrad forms (a_trans = 0, no accumulate); other forms run as precision 0.  Needs `workspace`.
+ *   the forward / dgrad forms (a_trans = 0, no accumulate); other forms run as precision 0.  Needs `workspace` -- except for the forms that
+ *   have persistent split kernels, which need none: N = K = 256 forward / masked dgrad and the 256 x 256 weight gradient (csrc/layer_x6*.hip)
+ *   and, ABI 18, the 128-wide appearance layers (csrc/layer_n6.hip: forward K in {128, 160} -> N = 128, masked dgrad 128 -> 128, unmasked dgrad
+ *   128 -> 160, weight gradients 128 x {128, 160} with a_trans = b_trans = accumulate = 1).
  * K % 4 == 0, lda/ldb % 4 == 0, 16-byte aligned bases.
  * split_k > 1 partitions K over blockIdx.z and requires accumulate = 1 (atomic add into C).
  * Dispatch (no change of contract): the N = K = 256 hidden-layer forms with M >= 4096 -- forward (plain A, [n][k] weights, no
@@ -323,6 +326,12 @@ int clift_xyz_head_last2_fwd(const float* A, int lda, const float* W, int ldw, c
 int clift_app_head_last2_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
                              const float* bout, int E, int M, float* hidden, int ldh, float* pre, int ldp, float* out, int ldo,
                              int sigmoid, clift_stream_t s);
+/* fp32x6 (ABI 18; csrc/layer_n6.hip): the same pair of layers with the 128 x 128 product as six bf16 products of exactly three-way-split
+ * operands (fp32-faithful, see clift_gemm precision 2), the output layer in exact fp32 FMAs on the finished tile, its four column-group shares
+ * summed in a fixed order; `hidden` (M, ldh) fp32 or NULL (not written).  E <= 4. */
+int clift_app_head_last2_x6_fwd(const float* A, int lda, const float* W, int ldw, const float* b, const float* Wout, int ldwo,
+                                const float* bout, int E, int M, float* hidden, int ldh, float* out, int ldo, int sigmoid,
+                                clift_stream_t s);
 /* bf16 mode (ABI 17; csrc/layer_nb16.hip): the same pair of layers over a bf16-STORED input activation A (M, lda), W (128, 128) fp32 rounded to
  * bf16 in the kernel, fp32 accumulate; `hidden` (M, ldh) bf16-stored or NULL; the output layer takes the bf16-rounded hidden activation (what
  * the unfused pair would read back) against fp32 output weights, its four column-group shares summed in a fixed order.  E <= 4. */
