@@ -384,6 +384,26 @@ def out_layer_fwd(M, h, W, b, out, ldo, col_off, act):
     call("clift_out_layer_fwd", ptr(h), h.shape[1], ptr(W), _pitch(W), ptr(b), W.shape[0], M, C.c_void_p(out.data_ptr() + 4 * col_off), ldo, act, stream())
 
 
+class HeadActs(list):
+    """The hidden activations an xyz head keeps for its backward (acts[i] = output of layer i, or None where the backward re-derives it), plus
+    -- fp32x6 mode -- the sign bytes a persistent forward left for activation i (``signs[i]``, from sign_bits_for): held HERE, next to the tensor
+    they describe and for exactly as long, instead of as an ad-hoc attribute on the tensor object (which a view or a clone would drop silently)."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.signs = {}
+
+    def sign_bits_of(self, i, M):
+        """The sign bytes of activation i, or None; checked against the activation they were written with."""
+        sb = self.signs.get(i)
+        if sb is None:
+            return None
+        h = self[i]
+        if h is None or h.shape[0] != M or sb.numel() != (M + 31) // 32 * 1024:
+            raise _lib.CliftError("sign bytes and activation of an xyz head do not come from the same forward")
+        return sb
+
+
 def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True, out_act=0):
     """layers = [(W,b)]; xa (M,4); hidden activations returned for the backward; final layer written into
     out[:, col_off:col_off+n_out] with row pitch ldo -- as logits (``out_act`` 0) or after a softmax over the row (2: the semantic head,
@@ -391,7 +411,7 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True, out_act=0):
     ``keep_first`` = False: the caller will not run a backward through this head, so the first (K = 3) layer's activation is
     never materialised (acts[0] is None) -- fp32 path, 256-wide heads."""
     dev = xa.device
-    acts = []
+    acts = HeadActs()
     W0, b0 = layers[0]
     hdt = act_dtype()                     # bf16 mode stores the hidden activations as bf16 (half the HBM stream of these layers)
     rest = layers[1:-1]
@@ -431,9 +451,11 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True, out_act=0):
         h = torch.empty((M, 256), dtype=torch.float32, device=dev)
         # a backward will run: the kernel also leaves the SIGNS of its output (32 B per row) for the next layer's masked dgrad, which then
         # does not stream the 1 KB-per-row activation a second time just to test it against zero
-        h.sign_bits = sign_bits_for(M, dev) if (keep_first and len(layers) >= 4) else None
-        first2_x6(M, xa, W0, b0, W1, b1, h, h.sign_bits)
+        sb1 = sign_bits_for(M, dev) if (keep_first and len(layers) >= 4) else None
+        first2_x6(M, xa, W0, b0, W1, b1, h, sb1)
         acts += [None, h]
+        if sb1 is not None:
+            acts.signs[1] = sb1
         rest = layers[2:-1]
     else:
         h = torch.empty((M, W0.shape[0]), dtype=hdt, device=dev)
@@ -457,9 +479,9 @@ def xyz_mlp_fwd(layers, xa, M, out, ldo, col_off=0, keep_first=True, out_act=0):
         sb = (sign_bits_for(M, dev) if (keep_first and MLP_PRECISION == 2 and li_ < len(rest) - 1 and tuple(W.shape) == (256, 256) and h.dtype == torch.float32
                                         and os.environ.get("CLIFT_X6_TILED") is None and os.environ.get("CLIFT_NO_PERSISTENT") is None) else None)
         gemm(M, W.shape[0], W.shape[1], h, h.shape[1], W, _pitch(W), hn, hn.shape[1], bias=b, act=1, sign_bits=sb)
-        if sb is not None:
-            hn.sign_bits = sb
         acts.append(hn)
+        if sb is not None:
+            acts.signs[len(acts) - 1] = sb
         h = hn
     W, b = Wo, bo
     if (MLP_PRECISION in (0, 2) and W.shape[0] <= 32 and W.shape[1] == 256 and h.dtype == torch.float32 and h.shape[1] == 256 and out.dtype == torch.float32
@@ -530,7 +552,7 @@ def xyz_mlp_bwd(layers, glayers, xa, acts, dpre, M, keep=None):
             keep.append(d)
             continue
         wgrad(no, ni, M, d, d.shape[1], h, h.shape[1], gW, gb)
-        sb = getattr(h, "sign_bits", None)
+        sb = acts.sign_bits_of(li - 1, M) if isinstance(acts, HeadActs) else None
         if (sb is not None and MLP_PRECISION == 2 and no == 256 and ni == 256 and d.dtype == torch.float32 and d.shape[1] % 4 == 0
                 and os.environ.get("CLIFT_X6_TILED") is None):
             gemm(M, ni, no, d, d.shape[1], W, _pitch(W), dn, ni, b_trans=1, sign_bits=sb)      # mask = the signs the forward left behind
