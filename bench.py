@@ -415,6 +415,11 @@ def main():
                 "allreduce_cu_reserve": tr.allreduce_cu_reserve if world > 1 else None,
                 "allreduce_ms": ar_ms, "rank_ms_per_step_min_max": rank_ms, "data_parallel_self_check": dp_check}
         line.update(extra)
+        #  the arithmetic of the headline number at the top level, with the exact-fp32 step of the same run beside it when it was measured
+        line["arithmetic"] = {"fp32x6": "fp32x6 (fp32-faithful: six bf16 MFMA products of exactly three-way-split fp32 operands, fp32 accumulate)",
+                              "fp32": "exact fp32 (fp32 MFMA)", "bf16": "bf16 operands, fp32 accumulate"}[a.dtype]
+        if a.dtype == "fp32x6" and isinstance(extra.get("exact_fp32"), dict):
+            line["exact_fp32_ms_per_step"] = extra["exact_fp32"].get("ms_per_step")
         line["step_ms_median"] = step_ms[len(step_ms) // 2]
         line["step_ms_min_max"] = [step_ms[0], step_ms[-1]]
         print(json.dumps(line))
@@ -476,8 +481,9 @@ MLP_ARITHMETIC = {
     "fp32x6": "fp32 in, fp32 out, fp32-FAITHFUL products on the bf16 matrix cores for the 256-wide layers (forward, input gradient, weight gradient): every "
               "fp32 operand is split exactly into three bf16 terms (8 + 8 + 8 significant bits), the six leading cross products run on "
               "v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped terms are below one fp32 rounding of the product (row-max relative "
-              "error vs float64 2e-7 .. 8e-7 = the exact-fp32 kernels' own; tests/test_gpu_round3.py, test_gpu_round4.py); K = 3 / E <= 32 / 128-wide "
-              "layers, activations, losses, tables and the optimizer are plain fp32",
+              "error vs float64 2e-7 .. 8e-7 = the exact-fp32 kernels' own; tests/test_gpu_round3.py, test_gpu_round4.py); since round 5 the 128-wide "
+              "appearance layers likewise (csrc/layer_n6.hip, tests/test_gpu_round5b.py); K = 3 / E <= 32 layers, activations, losses, tables and the "
+              "optimizer are plain fp32",
     "fp32": "exact fp32 products on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain), fp32 accumulate",
     "bf16": "MLP operands rounded to bf16 (RNE) in the kernels, hidden activations / hidden gradients bf16-stored, fp32 accumulate; everything else fp32",
 }
