@@ -181,11 +181,11 @@ __global__ __launch_bounds__(64 * NCG, 2) void k_layer_n6(GemmP g, int rows_per_
             const u32x4 fh = __builtin_bit_cast(u32x4, T[ci]);
             const u32x4 fm = __builtin_bit_cast(u32x4, T[PLANE + ci]);
             const u32x4 fl = __builtin_bit_cast(u32x4, T[2 * PLANE + ci]);
-            // the next tile's rows: split one piece per step beside the MFMAs, refill its registers with the tile after
+            // the next tile's rows: split one piece per two steps beside the MFMAs, refill its registers with the tile after
             // (unconditional: past the last tile the pieces are clamped copies of the range's last row, split into a stage nobody reads)
-            if (s < PER) {
-                split_store(nxt, s);
-                fetch(t + 2, s);
+            if (s % 2 == 0 && s / 2 < PER) {             // (every other step: ~2.5 VALU per MFMA instead of ~7 in the first half of the tile)
+                split_store(nxt, s / 2);
+                fetch(t + 2, s / 2);
             }
             acc0 = n6_mfma(wh[s], fh, acc0);
             acc1 = n6_mfma(wh[s], fm, acc1);
