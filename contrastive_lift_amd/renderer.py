@@ -53,7 +53,9 @@ class _FeatureFn(torch.autograd.Function):
         grads = _alloc_grads(model)
         slow_grad = any(n.startswith("render_instance_mlp.slow_mlp") and need for n, need in zip(ctx.names, ctx.needs))
         engine.feature_backward(model, ctx.rctx, grads, g_out, slow_grad=slow_grad)
-        pref = "render_semantic_mlp" if ctx.head == "semantic" else "render_instance_mlp"
+        # what a feature pass reaches: the head's MLP and, when the head sits on its own VM grid (tensoRF.py:70-83), that grid's tables and basis
+        pref = (("render_semantic_mlp", "semantic_plane", "semantic_line", "semantic_basis_mat") if ctx.head == "semantic" else
+                ("render_instance_mlp", "instance_plane", "instance_line", "instance_basis_mat"))
         return (None,) * 6 + tuple(grads[n] if (need and n.startswith(pref)) else None for n, need in zip(ctx.names, ctx.needs))
 
 
