@@ -11,6 +11,8 @@ timeout 1500 python -m pytest "tests/test_gpu_parity.py" tests/test_gpu_round3.p
    tests/test_gpu_round3.py::test_full_size_gradients_hip_and_fp32_oracle_against_fp64_oracle tests/test_gpu_round4b.py tests/test_gpu_round4.py tests/test_gpu_round5.py \
    -q -m gpu --timeout 900 -x > $out/pytest_around.log 2>&1
 echo "pytest around rc=$?"; tail -8 $out/pytest_around.log | cut -c1-300
+timeout 800 python tools/last2_soak.py 90 exact_infer,exact_infer,exact_keep,x6_infer,x6_keep > $out/last2_soak.log 2>&1
+echo "last2 soak rc=$?"; grep -E "RESULT|launch" $out/last2_soak.log | cut -c1-400
 bash tools/gpu_ab_flags.sh $(basename $out)/ab 2 "" "APP_X6=False" > /dev/null 2>&1
 cat $out/ab/summary.txt
 prof() {  # name, command...
@@ -30,3 +32,5 @@ for n in fp32x6 bf16 rays1024; do python -c "
 import json; d=json.loads(open('$out/$n.out').read().strip().splitlines()[-1]); print('$n ms_per_step', d['ms_per_step'], 'median', d.get('step_ms_median'), 'frac', d['roofline']['frac'])"; done
 tail -2 $out/inference.out
 head -40 $out/kernel_stats_fp32x6.txt | cut -c1-150
+timeout 1200 python tools/determinism_soak.py single fp32x6 ${2:-4000} 500 > $out/soak_fp32x6_n6.log 2>&1
+echo "soak fp32x6 (n6 appearance kernels) rc=$?"; grep -E "RESULT|iter" $out/soak_fp32x6_n6.log | tail -6 | cut -c1-400
