@@ -188,7 +188,7 @@ if n_steps > 0:
             for ki, v in enumerate(keep):
                 if torch.is_tensor(v):
                     t[f"bwd{bi}.{ki}{tuple(v.shape)}"] = v
-        t["losses"] = tr.losses.clone()
+        soft["loss values"] = tr.losses.clone()      # (block partial sums folded with floating-point atomics: order-dependent in the last bits, like the gradients)
         return t, soft
 
     ref, soft_ref = step()
