@@ -243,6 +243,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
     }
     if (OUTV) {                                         // drain the two-tile pipeline of the output layer
+        // A barrier FIRST (round 5): the park below writes share buffer (ntiles - 1) & 1 -- the buffer the LAST loop iteration's outv_fetch(ntiles - 3)
+        // reads.  Inside the loop that pair (park of iteration t + 1, fetch of iteration t) is separated by the barrier at the top of every tile; here
+        // nothing separated them, and a wave that left the loop early overwrote shares a slower wave had not fetched yet: a few rows of tile
+        // ntiles - 3 summed one wave's share of the wrong tile (tools/last2_soak.py: 5 of 65 600 launches of the no-hidden-store form, rows 8 k + 6 / 7
+        // of the tile's second half, |delta| <= 8e-5; profiles/r05_determinism.txt).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
             outv_issue(s_);

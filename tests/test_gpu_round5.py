@@ -264,6 +264,10 @@ def _digest(g, prefix, named_grads, min_checked):
             flat = gr.detach().contiguous().reshape(-1).cpu()
         sub = flat if flat.numel() <= 4096 else flat[::17]
         ref = T(g[key]).double()
+        if ref.numel() == 1 and flat.numel() > 1:      # the reference had NO gradient for this tensor (the fixture holds one zero): ours must be all zero
+            assert float(ref) == 0.0 and float(flat.abs().max()) == 0.0, key
+            n += 1
+            continue
         scale = float(T(g[f"{prefix}norm.{k}"])) / max(1.0, np.sqrt(flat.numel()))
         rel_close(sub, ref, 2e-3, atol=2e-3 * max(scale, 1e-12) + 1e-9, what=key)
         rel_close(flat.norm(), g[f"{prefix}norm.{k}"], 1e-3, atol=1e-9, what=f"norm {k}")
