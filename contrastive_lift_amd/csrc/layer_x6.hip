@@ -44,7 +44,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // Timing probes (tools/x6_ablation.sh builds variants of the library with -DX6_ABL=<bits>; results are garbage by construction, never shipped):
 // 1 no fragment reads after a tile's first, 2 no activation split (staging reads, VALU, plane writes), 4 no k-half exchange / finish,
-// 8 no LDS-DMA and no waits for it, 16 no output stores, 32 no barrier.
+// 8 no LDS-DMA and no waits for it, 16 no output stores, 32 no barrier; fixed-cost probes (tools/x6_fixed_probe.py): 64 weights not loaded (synthesised),
+// 128 weights not split, 256 no staging of tile 0 in the prologue, 512 no tiles at all, 1024 the kernel returns at once (launch + dispatch only).
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     // register ballast: the wave allocates its whole 256-register budget, so that two of them fill the SIMD's file and no wave of another kernel
     // (another PROCESS sharing the device) is scheduled beside this MFMA stream -- see layer_x6w.hip for what happens otherwise
     asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    if (X6_ABL & 1024) return;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cg = wave & 3, kh = wave >> 2;       // column group, k-half (scalars)
     const int b = blockIdx.x, half = (b >> 3) & 1, range = (b & 7) + 8 * (b >> 4);
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     if (range >= nranges) return;
     const int rbeg = range * rows_per_range, rend = min(g.M, rbeg + rows_per_range);
     if (rbeg >= rend) return;
-    const int ntiles = (rend - rbeg + X6_ROWS - 1) / X6_ROWS;
+    const int ntiles = (X6_ABL & 512) ? 0 : (rend - rbeg + X6_ROWS - 1) / X6_ROWS;
     const int ncol = 128 * half + 32 * cg;                   // first output column of this wave's MFMA tile
     const int fcol = ncol + 16 * kh + 4 * lh;                // this lane's first FINISHED column: groups q = 2 kh, 2 kh + 1 -> fcol, fcol + 8
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     };
 
     // ---- prologue: tile 0's rows -> staging -> split into stage 0; tile 1's rows on their way while the weights are prepared
+    if (!(X6_ABL & 256)) {
     if (GEN) { pos_dma(0); pos_dma(1); }
     else {
 #pragma unroll
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sp_x) : : "memory");
         gen_values();
         split_a(); split_b0(); split_b1(); split_c(0u, i); split_d0(); split_d1(); split_e(0u, i);
+    }
     }
     {   // what tile 0 "receives" (exchange parity 1, this wave's slot): zeros
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -299,7 +303,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v[8];
-        if (!DGRAD) {
+        if (X6_ABL & 64) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)(lane + 3 * e + 7 * j) * 0.001f;
+        } else if (!DGRAD) {
             const float* q = g.B + (size_t)(ncol + li) * g.ldb + 128 * kh + 16 * j + 8 * lh;
             const float4 a = *reinterpret_cast<const float4*>(q), c = *reinterpret_cast<const float4*>(q + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
@@ -311,7 +318,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
             unsigned h, m, l;
-            x6_split_pair(v[2 * pr], v[2 * pr + 1], h, m, l);
+            if (X6_ABL & 128) { h = __float_as_uint(v[2 * pr]); m = __float_as_uint(v[2 * pr + 1]); l = h ^ m; }
+            else x6_split_pair(v[2 * pr], v[2 * pr + 1], h, m, l);
             wh[j][pr] = h; wm[j][pr] = m; wl[j][pr] = l;
         }
     }

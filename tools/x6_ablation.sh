@@ -18,6 +18,8 @@ if [ "$1" = build ]; then
   wait
   rm -f tools/_scratch/abl/*.o
   ls -la tools/_scratch/abl
+elif [ "$1" = fixed ]; then
+  for v in 0 $VARIANTS; do timeout 200 python tools/x6_fixed_probe.py $v; done
 else
   for rep in 1 2; do for v in $VARIANTS; do for sg in $STAGGER; do
     timeout 120 python tools/x6_ablation.py $v $sg
