@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     float4* const kd = lds + 2 * LF_TILE;                                    // K3W: two dH1 tile images ...
     float4* const kx = kd + 2 * LF_TILE;                                     // ... and four position slots of 64 float4
     float4* const wl4 = lds + 2 * LF_TILE + (GEN ? LF_XROWS : 0);            // OUTV: wl4[c * 64 + k / 4]
-    float4* const part = wl4 + 256;                                          // OUTV: part[(tile & 1) * 256 + wave * 32 + row]
+    float4* const part = wl4 + 256;                                          // OUTV: part[wave * 32 + row]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     if (rows_limited()) {          // sync-free step: the launch was sized by a capacity; re-balance the row ranges over the true row count
         g.M = limit_rows(g.M);
@@ -164,64 +164,41 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     float4 prev[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     int prev_m = rend;                                                       // row of `prev`; rend = nothing to store yet
     if (GEN) { fill_positions(0); __syncthreads(); }
-    // ---- OUTV state
-    const unsigned wl0 = (unsigned)(uintptr_t)(lds_ptr_t)wl4, part0 = (unsigned)(uintptr_t)(lds_ptr_t)part;
-    const unsigned wlane = wl0 + (unsigned)((8 * wave + lh) * 16);           // this lane's slice of a Wout row: floats 32 wave + 4 lh + 8 q ...
-    f32x4 pv = {0.f, 0.f, 0.f, 0.f};                                         // this lane's share of the E dot products of the previous tile
-    f32x4 wv[2];              // (also the eight shares of the cross-wave sum: the two uses never overlap)
+    // ---- OUTV: the narrow output layer of a finished tile, SYNCHRONOUSLY (round 5; see the same change in layer_n128.hip).  The pipelined form of
+    // rounds 2 - 4 (weight fragments read one k-step ahead by hand, the waves' shares parked in a double buffer and fetched one tile later) is the
+    // scheme whose frame-render form was caught returning rows with one wave's share of the wrong tile (tools/last2_soak.py on its 128-wide twin;
+    // profiles/r05_determinism.txt).  Here: shares from the tile's registers right after its MFMA loop (the same FMA chain: the same bits), ONE share
+    // buffer between two barriers, the next tile's barrier protects its reuse; no hand-issued LDS traffic, no cross-tile state.
+    float bo_out = 0.f;
     if (OUTV) {
         float* wl = reinterpret_cast<float*>(wl4);
         for (int e = tid; e < 1024; e += 512) { const int c = e >> 8, k = e & 255; wl[e] = c < op.E ? op.Wout[(size_t)c * op.ldwo + k] : 0.f; }
+        bo_out = (op.bout && (tid & 3) < op.E) ? op.bout[tid & 3] : 0.f;
         __syncthreads();
     }
-    // narrow layer, one (column group q, output c) pair per k-step, pairs p = 4 q + c = 0 .. 15: the weight fragment of pair p is read
-    // at k-step 7 + p ...
-    auto outv_issue = [&](int p_) {
-        const int q = p_ >> 2, c = p_ & 3;
-        unsigned b = wlane;                       // (opaque copy: keeps the compiler from hoisting sixteen precomputed addresses into registers)
-        asm volatile("" : "+v"(b));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(wv[p_ & 1]) : "v"(b + (unsigned)((c * 64 + 2 * q) * 16)) : "memory");
-    };
-    // ... and used at k-step 8 + p (after that step's lgkmcnt(0)): 4 FMAs
-    auto outv_fma = [&](int p_) {
-        const int q = p_ >> 2, c = p_ & 3;
-        // (a volatile statement BEHIND the k-step's lgkmcnt(0) that the fragment passes through: without it nothing orders these FMAs after the
-        // wait -- the wait names only the MFMA fragment -- and the compiler did hoist three of the four above it, where only the latency of the
-        // previous step's MFMAs stood between the ds_read and its use; tools/isa_asm_load_check.py, round 5)
-        asm volatile("" : "+v"(wv[p_ & 1]) : : "memory");
-        const f32x4 wq = wv[p_ & 1];
-        pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
-        asm volatile("" : "+v"(pv));               // (pins the arithmetic to its k-step; otherwise it is sunk to the end of the tile and the reads pile up in registers: spills)
-    };
-    // step 3 (k-step 24): fold the half-waves, park the wave's share of tile `tile` in LDS
-    auto outv_park = [&](int tile) {
+    auto outv_tile = [&](int tile) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        float po[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const unsigned u = __float_as_uint(pv[c]);
-            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            pv[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        }
-        if (lh == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(part0 + (unsigned)(((tile & 1) * 256 + wave * 32 + li) * 16)), "v"(pv) : "memory");
-        pv = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    // step 4 (k-step 26 of the tile after that, i.e. behind a barrier): lanes 0..15 of wave w fetch the eight shares of (row 4 w + lane / 4, column lane % 4) ...
-    auto outv_fetch = [&](int tile) {
-        // (every lane reads -- lanes 16..63 repeat the addresses of lanes 0..15: a run-time branch around asm reads whose results are
-        // published by a later asm wait would let the compiler copy the registers before the data has arrived)
-        unsigned b = part0 + (unsigned)(((tile & 1) * 256 + 4 * wave + ((lane >> 2) & 3)) * 16 + (lane & 3) * 4);
-        asm volatile("" : "+v"(b));
+            float a = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(wv[w8 >> 2][w8 & 3]) : "v"(b + (unsigned)(w8 * 32 * 16)) : "memory");
-    };
-    // ... step 5 (k-step 28): add them up in a fixed order, add the bias, store
-    auto outv_store = [&](int tile) {
-        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");          // (as in outv_fma: the shares are consumed behind the wait that publishes them)
-        if (lane < 16) {
-            const int c = lane & 3, mrow = rbeg + tile * LF_ROWS + 4 * wave + (lane >> 2);
-            const float v = ((wv[0][0] + wv[0][1]) + (wv[0][2] + wv[0][3])) + ((wv[1][0] + wv[1][1]) + (wv[1][2] + wv[1][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
-            if (tile >= 0 && c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
+            for (int q = 0; q < 4; ++q) {            // this lane's columns 32 wave + 8 q + 4 lh + (0..3), ascending: the FMA chain of the pipelined form
+                const float4 w4 = wl4[c * 64 + 8 * wave + 2 * q + lh];
+                a = fmaf(prev[q].w, w4.w, fmaf(prev[q].z, w4.z, fmaf(prev[q].y, w4.y, fmaf(prev[q].x, w4.x, a))));
+            }
+            const unsigned u = __float_as_uint(a);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // lower + upper half-wave
+            po[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        if (lh == 0) part[wave * 32 + li] = make_float4(po[0], po[1], po[2], po[3]);
+        __syncthreads();
+        if (tid < 4 * LF_ROWS) {                     // 128 threads = 32 rows x 4 outputs: the eight column-waves' shares in the pipelined form's association
+            const int row = tid >> 2, c = tid & 3;
+            const float* pf = reinterpret_cast<const float*>(part) + row * 4 + c;
+            const float v = ((pf[0] + pf[128]) + (pf[2 * 128] + pf[3 * 128])) + ((pf[4 * 128] + pf[5 * 128]) + (pf[6 * 128] + pf[7 * 128])) + bo_out;
+            const int mrow = rbeg + tile * LF_ROWS + row;
+            if (c < op.E && mrow < rend) op.out[(size_t)mrow * op.ldo + c] = v;
         }
     };
     // ---- K3W state: thread (kn, khalf) sums column kn of a finished dH1 tile over rows 16 khalf .. +15
@@ -270,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
         if (!GEN) {
             // DMA of tile t: issued during tile t-1; younger than it: the 4 stores of tile t-2 (forward; the dgrad drained everything at the
             // end of tile t-1 for its mask)
-            if (t >= 2 && !K3W) wait_vmf<4>(); else wait_vmf<0>();           // (K3W: no stores, no mask loads -- the tile's DMAs are all there is)
+            // (K3W: no stores, no mask loads -- the tile's DMAs are all there is; OUTV without a hidden store: the only younger instructions are the owner
+            // threads' output stores, which most waves never issue)
+            if (t >= 2 && !K3W && (!OUTV || op.store_hidden)) wait_vmf<4>(); else wait_vmf<0>();
             __builtin_amdgcn_s_barrier();                                    // everyone's rows have landed; everyone is done with the other stage
             asm volatile("" ::: "memory");
         } else {
@@ -319,16 +298,6 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
                 const int q = (j - 8) >> 1;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
             }
-            if (OUTV) {
-                // output layer of tile t-1 (its activation is still in `prev`) and the cross-wave sum of tile t-2 (parked during tile t-1, behind
-                // this tile's barrier).  The asm reads and the arithmetic run for EVERY t -- for t = 0 / 1 on zeros, into shares nobody stores --
-                // so that no run-time branch separates an asm read from the asm wait that publishes its registers; only the store is guarded.
-                if (j >= 8 && j < 24) outv_fma(j - 8);
-                if (j >= 7 && j < 23) outv_issue(j - 7);
-                if (j == 25) outv_park(t - 1);
-                if (j == 26) outv_fetch(t - 2);
-                if (j == 28) outv_store(t - 2);
-            }
             if (DGRAD && !K3W && j >= 16 && j < 24 && (j & 1) == 0) {
                 const int q = (j - 16) >> 1;
                 const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wave + 4 * lh + 8 * q;
@@ -362,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
             }
         }
         prev_m = m;
+        if (OUTV) outv_tile(t);
     }
     if (K3W) {
         // the last tile's column sums, the two row halves of a column folded through LDS, one atomic per gradient entry and block
@@ -389,31 +359,6 @@ __global__ __launch_bounds__(512, 2) void k_layer_f32(GemmP g, int rows_per_bloc
     if (prev_m < rend && (!OUTV || op.store_hidden)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wave + 8 * q + 4 * lh) = prev[q];
-    }
-    if (OUTV) {                                         // drain the two-tile pipeline of the output layer
-        // A barrier FIRST (round 5): the park below writes share buffer (ntiles - 1) & 1 -- the buffer the LAST loop iteration's outv_fetch(ntiles - 3)
-        // reads.  Inside the loop that pair (park of iteration t + 1, fetch of iteration t) is separated by the barrier at the top of every tile; here
-        // nothing separated them, and a wave that left the loop early overwrote shares a slower wave had not fetched yet: a few rows of tile
-        // ntiles - 3 summed one wave's share of the wrong tile (tools/last2_soak.py: 5 of 65 600 launches of the no-hidden-store form, rows 8 k + 6 / 7
-        // of the tile's second half, |delta| <= 8e-5; profiles/r05_determinism.txt).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int p_ = 0; p_ < 16; ++p_) {
-            outv_issue(p_);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");
-            outv_fma(p_);
-        }
-        outv_park(ntiles - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int tile = max(ntiles - 2, 0); tile < ntiles; ++tile) {
-            outv_fetch(tile);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]) : : "memory");
-            outv_store(tile);
-        }
     }
 }
 

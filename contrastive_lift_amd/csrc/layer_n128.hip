@@ -40,7 +40,7 @@ struct OutN {
     int sigmoid;
     int store_hidden;
 };
-constexpr int LN_OUTV_F4 = 128 + 2 * 8 * 32;  // float4: Wout rows padded to 4 x 128 floats + two buffers of 8 waves x 32 rows of shares
+constexpr int LN_OUTV_F4 = 128 + 8 * 32;      // float4: Wout rows padded to 4 x 128 floats + 8 waves x 32 rows of shares
 
 template <int KC, bool DGRAD, bool OUTV>
 __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_block, OutN op) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     static_assert(!OUTV || (KC == 32 && !DGRAD), "the fused output layer exists for the 128 -> 128 forward layer only");
     __shared__ __attribute__((aligned(16))) float4 lds[2 * TILE + (OUTV ? LN_OUTV_F4 : 0)];
     float4* const wl4 = lds + 2 * TILE;      // OUTV: wl4[c * 32 + k / 4]
-    float4* const part = wl4 + 128;          // OUTV: part[(tile & 1) * 256 + wave * 32 + row of the wave's half]
+    float4* const part = wl4 + 128;          // OUTV: part[wave * 32 + row of the wave's half]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wc = wave & 3, wr = wave >> 2;
     if (rows_limited()) {          // sync-free step: re-balance the row ranges over the true row count (see layer_f32.hip)
@@ -94,66 +94,43 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     };
     float4 prev[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     int prev_m = rend;
-    // ---- OUTV state and steps
-    const unsigned wl0 = (unsigned)(uintptr_t)(lds_ptr_t)wl4, part0 = (unsigned)(uintptr_t)(lds_ptr_t)part;
-    const unsigned wlane = wl0 + (unsigned)((8 * wc + lh) * 16);             // this lane's slice of a Wout row: floats 32 wc + 4 lh + 8 q ...
-    f32x4 pv = {0.f, 0.f, 0.f, 0.f};
-    f32x4 wv[2][2];
+    // ---- OUTV: the output layer of a finished tile, SYNCHRONOUSLY (round 5).  Rounds 2 - 4 pipelined it through the MFMA loops of the two following
+    // tiles with hand-issued LDS traffic (weight fragments read one k-step ahead, the waves' shares parked in a double buffer and fetched a tile
+    // later); the frame-render form of that scheme (hidden activation not stored) returned a few rows with ONE wave's share of the wrong tile in
+    // ~1 of 15 000 launches, in several blocks at once, single process (tools/last2_soak.py; profiles/r05_determinism.txt) -- a timing-dependent
+    // fault that inspection of the listing did not pin down.  The scheme below has no hand-issued LDS traffic and no cross-tile state: shares are
+    // formed from the tile's registers right after its MFMA loop (the same FMA chain, so the same bits), meet in ONE buffer between two barriers,
+    // and the next tile's barrier protects its reuse.  ~4 % of this (non-default) kernel's time.
+    float bo_out = 0.f;
     if (OUTV) {
         float* wl = reinterpret_cast<float*>(wl4);
         for (int e = tid; e < 512; e += 512) { const int c = e >> 7, k = e & 127; wl[e] = c < op.E ? op.Wout[(size_t)c * op.ldwo + k] : 0.f; }
+        bo_out = (op.bout && (tid & 3) < op.E) ? op.bout[tid & 3] : 0.f;
         __syncthreads();
     }
-    // pairs p = 4 q + c (column group q, output c), two per k-step: fragments of pairs 2 s, 2 s + 1 are read at k-step s - 1 ...
-    auto outv_issue = [&](int s_) {
-        unsigned b = wlane;
-        asm volatile("" : "+v"(b));
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int p_ = 2 * s_ + u, q = p_ >> 2, c = p_ & 3;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(wv[s_ & 1][u]) : "v"(b + (unsigned)((c * 32 + 2 * q) * 16)) : "memory");
-        }
-    };
-    // ... and used at k-step s (after its lgkmcnt(0))
-    auto outv_fma = [&](int s_) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int p_ = 2 * s_ + u, q = p_ >> 2, c = p_ & 3;
-            // (a volatile statement BEHIND the k-step's lgkmcnt(0) that the fragment passes through: the wait itself names only the MFMA fragment, so
-            // nothing else orders these FMAs after it -- layer_f32.hip's twin of this code was found with three of four FMAs hoisted above the wait)
-            asm volatile("" : "+v"(wv[s_ & 1][u]) : : "memory");
-            const f32x4 wq = wv[s_ & 1][u];
-            pv[c] = fmaf(prev[q].w, wq.w, fmaf(prev[q].z, wq.z, fmaf(prev[q].y, wq.y, fmaf(prev[q].x, wq.x, pv[c]))));
-        }
-    };
-    auto outv_park = [&](int tile) {
+    auto outv_tile = [&](int tile) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        float po[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const unsigned u = __float_as_uint(pv[c]);
-            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            pv[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        }
-        if (lh == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(part0 + (unsigned)(((tile & 1) * 256 + wave * 32 + li) * 16)), "v"(pv) : "memory");
-        pv = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    // lanes 0..31 of wave w own (row 8 w + lane / 4 of the tile, output lane % 4): the four column-waves' shares of that row
-    auto outv_fetch = [&](int tile) {
-        // (every lane reads -- lanes 32..63 repeat the addresses of lanes 0..31: no run-time branch between asm reads and the asm wait that
-        // publishes their registers)
-        const int row = 8 * wave + ((lane >> 2) & 7);
-        unsigned b = part0 + (unsigned)(((tile & 1) * 256 + (4 * (row >> 5)) * 32 + (row & 31)) * 16 + (lane & 3) * 4);
-        asm volatile("" : "+v"(b));
+            float a = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(wv[0][0][w4]) : "v"(b + (unsigned)(w4 * 32 * 16)) : "memory");
-    };
-    auto outv_store = [&](int tile) {
-        asm volatile("" : "+v"(wv[0][0]) : : "memory");                     // (as in outv_fma: the shares are consumed behind the wait that publishes them)
-        if (lane < 32) {
-            const int c = lane & 3, mrow = rbeg + tile * LN_ROWS + 8 * wave + (lane >> 2);
-            const float v = ((wv[0][0][0] + wv[0][0][1]) + (wv[0][0][2] + wv[0][0][3])) + ((op.bout && c < op.E) ? op.bout[c] : 0.f);
-            if (tile >= 0 && c < op.E && mrow < rend) {
+            for (int q = 0; q < 4; ++q) {            // this lane's columns 32 wc + 8 q + 4 lh + (0..3), ascending: the FMA chain of the pipelined form
+                const float4 w4 = wl4[c * 32 + 8 * wc + 2 * q + lh];
+                a = fmaf(prev[q].w, w4.w, fmaf(prev[q].z, w4.z, fmaf(prev[q].y, w4.y, fmaf(prev[q].x, w4.x, a))));
+            }
+            const unsigned u = __float_as_uint(a);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // lower + upper half-wave
+            po[c] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        if (lh == 0) part[wave * 32 + li] = make_float4(po[0], po[1], po[2], po[3]);
+        __syncthreads();
+        if (tid < 4 * LN_ROWS) {                     // 256 threads = 64 rows x 4 outputs: the four column-waves of the row's half, in wave order
+            const int row = tid >> 2, c = tid & 3;
+            const float* pf = reinterpret_cast<const float*>(part) + ((4 * (row >> 5)) * 32 + (row & 31)) * 4 + c;
+            const float v = ((pf[0] + pf[32 * 4]) + (pf[2 * 32 * 4] + pf[3 * 32 * 4])) + bo_out;
+            const int mrow = rbeg + tile * LN_ROWS + row;
+            if (c < op.E && mrow < rend) {
                 if (op.pre) op.pre[(size_t)mrow * op.ldp + c] = v;
                 op.out[(size_t)mrow * op.ldo + c] = op.sigmoid ? 1.f / (1.f + expf(-v)) : v;
             }
@@ -163,7 +140,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
     for (int i = 0; i < NDMA; ++i) dma_piece(0, i);
     for (int t = 0; t < ntiles; ++t) {
         // DMA of tile t was issued during tile t-1; younger than it: the 4 stores of tile t-2 (the dgrad drained everything for its mask)
-        if (t >= 2) wait_vmn<4>(); else wait_vmn<0>();
+        // (OUTV without a hidden store: the only younger instructions are the owner threads' output stores, which half of the waves never issue)
+        if (t >= 2 && (!OUTV || op.store_hidden)) wait_vmn<4>(); else wait_vmn<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int m = rbeg + t * LN_ROWS + rt;
@@ -199,16 +177,6 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
                 const int q = j - NDMA;
                 if (prev_m < rend) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
             }
-            if (OUTV) {
-                // output layer of tile t-1 (its activation is still in `prev`) and the cross-wave sum of tile t-2 (parked during tile t-1, behind
-                // this tile's barrier); executed for every t (zeros at t = 0 / 1, never stored) so that no run-time branch separates an asm read
-                // from the asm wait that publishes its registers; only the store is guarded
-                if (j >= 1 && j < 9) outv_fma(j - 1);
-                if (j < 8) outv_issue(j);
-                if (j == 10) outv_park(t - 1);
-                if (j == 12) outv_fetch(t - 2);
-                if (j == 14) outv_store(t - 2);
-            }
             if (DGRAD && j >= NDMA + 4 && j < NDMA + 8) {
                 const int q = j - NDMA - 4;
                 const float* mp = g.mask + (size_t)min(m, rend - 1) * g.ldmask + 32 * wc + 4 * lh + 8 * q;
@@ -237,35 +205,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_n128(GemmP g, int rows_per_blo
             prev[q] = o;
         }
         prev_m = m;
+        if (OUTV) outv_tile(t);
     }
     if (prev_m < rend && (!OUTV || op.store_hidden)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(g.C + (size_t)prev_m * g.ldc + 32 * wc + 8 * q + 4 * lh) = prev[q];
-    }
-    if (OUTV) {                                         // drain the two-tile pipeline of the output layer
-        // A barrier FIRST (round 5): the park below writes share buffer (ntiles - 1) & 1 -- the buffer the LAST loop iteration's outv_fetch(ntiles - 3)
-        // reads.  Inside the loop that pair (park of iteration t + 1, fetch of iteration t) is separated by the barrier at the top of every tile; here
-        // nothing separated them, and a wave that left the loop early overwrote shares a slower wave had not fetched yet: a few rows of tile
-        // ntiles - 3 summed one wave's share of the wrong tile (tools/last2_soak.py: 5 of 65 600 launches of the no-hidden-store form, rows 8 k + 6 / 7
-        // of the tile's second half, |delta| <= 8e-5; profiles/r05_determinism.txt).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) {
-            outv_issue(s_);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0][0]), "+v"(wv[0][1]), "+v"(wv[1][0]), "+v"(wv[1][1]) : : "memory");
-            outv_fma(s_);
-        }
-        outv_park(ntiles - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int tile = max(ntiles - 2, 0); tile < ntiles; ++tile) {
-            outv_fetch(tile);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0][0]) : : "memory");
-            outv_store(tile);
-        }
     }
 }
 
