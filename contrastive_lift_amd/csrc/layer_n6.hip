@@ -14,7 +14,8 @@
 // tile ahead (coalesced: lane = piece), split by whoever loaded them (cooperative: each value is split ONCE per workgroup, 22 VALU per piece)
 // and written as three bf16 plane images into LDS (two stages; the image and its bank swizzle are layer_nb16.hip's: 16-byte chunk c of row r in
 // slot c ^ (r & 15) for 256-byte rows, c ^ ((r >> 2) & 3) for 320-byte rows); every wave then reads whole-K fragments of the tile against its
-// register-resident weight planes.  One barrier per tile.  Two workgroups per CU (60 / 48 KB of LDS each) overlap one's split with the other's MFMAs.
+// register-resident weight planes (reading them a whole k-step ahead of their MFMAs instead of where the compiler puts them measured the same or
+// slower: profiles/r05_n6_prefetch_variant.txt).  One barrier per tile.  Two workgroups per CU (60 / 48 KB of LDS each) overlap one's split with the other's MFMAs.
 // A row's bits depend on nothing but the row: fixed k order, fixed column partition -- a frame rendered in row tiles is bit-identical to the
 // unsharded render.
 #include "gemm_common.h"
