@@ -9,8 +9,7 @@
 // the ROW index m, so a fragment is 8 consecutive rows of one column.  The split does the transposition: rows travel by LDS-DMA into fp32
 // staging (wave v owns rows 4 v .. 4 v + 3 of a 32-row tile, both operands, 4 KB), each lane reads COLUMN runs of its wave's 4 rows
 // (4 x ds_read_b32, lanes along the columns: conflict-free), splits the 4 values (22 VALU) and writes three 8-byte pieces into TRANSPOSED
-// bf16 plane images [operand][plane][column][32 m], column pitch 80 bytes (fragment reads conflict-free: 80 = 5 x 16; the writes too once
-// columns 16 .. 31 of every 32 keep their two k-steps in swapped order, see run_write).
+// bf16 plane images [operand][plane][column][32 m], column pitch 80 bytes (fragment reads and the writes conflict-free: 80 = 5 x 16).
 // A wave multiplies the dY fragments of its 32 n against the X fragments of its two k-tiles: 24 MFMAs per tile in two groups of 12 that
 // alternate between two accumulators.  Rows past the end of a range are zeroed in the split (a clamped copy would be counted twice).
 // Memory instructions per tile and wave: X rows x 2 (group 0), dY rows x 2 (group 1) -- every wait is vmcnt(2).
@@ -146,9 +145,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto run_write = [&](unsigned stage, int o, int u) {
-        // (columns 16 .. 31 of every 32 keep their 32 m in rotated order, byte offset ^ 32: with a pitch that is a multiple of 16 bytes lanes l and l + 16
-        // of this write otherwise hit the same banks -- SQ_LDS_BANK_CONFLICT was 24 % of the kernel's LDS cycles, profiles/r05_pmc_tables.txt)
-        const unsigned a = lds0 + stage + (unsigned)(o * 3 * XW_PLANE + (lane + 64 * u) * XW_PITCH + ((wave * 8) ^ (((lane >> 4) & 1) * 32)));
+        const unsigned a = lds0 + stage + (unsigned)(o * 3 * XW_PLANE + (lane + 64 * u) * XW_PITCH + wave * 8);
         const u32x2 dh = {sh[0], sh[1]}, dm = {sm[0], sm[1]}, dl = {sl[0], sl[1]};
         asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(dh) : "memory");
         asm volatile("ds_write_b64 %0, %1 offset:10240" : : "v"(a), "v"(dm) : "memory");
@@ -177,7 +174,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     // fragment addresses: column (32 wn | 32 (2 kp + x)) + li, rows 16 s + 8 lh
     const unsigned fa = lds0 + (unsigned)((32 * wn + li) * XW_PITCH + 16 * lh);
     const unsigned fb = lds0 + (unsigned)(3 * XW_PLANE + (64 * kp + li) * XW_PITCH + 16 * lh);
-    const unsigned frot = (unsigned)(((li >> 4) & 1) * 32);          // this lane's columns hold their k-steps in swapped order (see run_write)
 
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -187,13 +183,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
         const int valid = valid_of(t + 1);
         u32x4 A[2][3], B[2][2][3];                      // dY fragments of k-step s; X fragments of k-step s, k-tiles 2 kp, 2 kp + 1
         auto rd = [&](int s) {
-            const unsigned a = fa + cur + ((unsigned)(32 * s) ^ frot);
+            const unsigned a = fa + cur + (unsigned)(32 * s);
             asm volatile("ds_read_b128 %0, %1" : "=v"(A[s][0]) : "v"(a) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(A[s][1]) : "v"(a) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A[s][2]) : "v"(a) : "memory");
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                const unsigned c = fb + cur + (unsigned)(x * 32 * XW_PITCH) + ((unsigned)(32 * s) ^ frot);
+                const unsigned c = fb + cur + (unsigned)(x * 32 * XW_PITCH + 32 * s);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(B[s][x][0]) : "v"(c) : "memory");
                 asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(B[s][x][1]) : "v"(c) : "memory");
                 asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(B[s][x][2]) : "v"(c) : "memory");
