@@ -25,7 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PMC_RECORD = "profiles/r03_pmc_k_layer_f32.json"        # exact-fp32 dominant kernel
-PMC_RECORD_X6 = "profiles/r04_pmc_k_layer_x6.json"      # fp32x6 dominant kernel (the default arithmetic)
+PMC_RECORD_X6 = "profiles/r05_pmc_k_layer_x6.json"      # fp32x6 dominant kernel (the default arithmetic)
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
@@ -908,7 +908,7 @@ def roofline(rec_dom, rec, nb, engine, dtype="fp32x6", ms_step=None, rec_min=Non
                          "step in three instantiations; pair of workgroups per row range, the weights' three bf16 planes in registers, cooperative activation split "
                          "through LDS-DMA staging, v_mfma_f32_32x32x16_bf16, eight waves = 4 column groups x 2 k-halves meeting through LDS)",
                "achieved": bf16_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA FLOPs = 6 x the fp32-equivalent 2MNK)", "frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
-               "frac_is": "per launch the median of three event-bracketed replays of the timed steps (rocprofv3 average of the same command: profiles/r04_kernel_stats_fp32x6_final.txt)",
+               "frac_is": "per launch the median of three event-bracketed replays of the timed steps (rocprofv3 average of the same command: profiles/r05_kernel_stats_fp32x6.txt)",
                "frac_best_of_4_brackets": x6tf(dom_best) / PEAK_BF16_MFMA_TFLOPS,
                "fp32_equivalent_tflops": ach, "fp32_equivalent_vs_exact_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                "hbm": {"achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,

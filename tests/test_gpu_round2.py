@@ -499,7 +499,8 @@ def test_appearance_head_last_two_layers_fused(M):
     b3 = torch.randn(3, generator=g) * 0.3
     H1d, W2d, b2d, W3d, b3d = (t.to(DEV) for t in (H1, W2, b2, W3, b3))
     H2_ref = torch.empty((M, 128), device=DEV)
-    engine.gemm(M, 128, 128, H1d, 128, W2d, 128, H2_ref, 128, bias=b2d, act=1)
+    with engine.exact_fp32():            # (clift_app_head_last2_fwd is the exact-fp32 kernel: so is its reference; the default arithmetic has its own pair, tests/test_gpu_round5b.py)
+        engine.gemm(M, 128, 128, H1d, 128, W2d, 128, H2_ref, 128, bias=b2d, act=1)
     pre = H2_ref.double().cpu() @ W3.double().T + b3.double()
     ref = torch.sigmoid(pre)
     for keep in (True, False):
