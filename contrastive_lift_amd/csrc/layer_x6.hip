@@ -49,6 +49,10 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #ifndef X6_ABL
 #define X6_ABL 0
 #endif
+// cache-policy probes: bit 1 = the row DMA non-temporal (aux = 2), bit 2 = the output stores non-temporal
+#ifndef X6_NT
+#define X6_NT 0
+#endif
 constexpr int X6_ROWS = 32;                         // rows per tile
 constexpr int X6_PLANE = X6_ROWS * 512;             // bytes of one bf16 plane image of a tile (32 rows x 256 k x 2 B)
 constexpr int X6_STAGE = 3 * X6_PLANE;              // 48 KB
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     auto dma_piece = [&](int t, int i) {
         if (X6_ABL & 8) return;
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * i, rend - 1);
-        __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + 4 * lane, (lds_ptr_t)(lds + X6_RAW + (wave * 4 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + 4 * lane, (lds_ptr_t)(lds + X6_RAW + (wave * 4 + i) * 1024), 16, 0, (X6_NT & 1) ? 2 : 0);
     };
     // GEN: positions of this wave's rows wave + 8 i of tile t -> staging slot (t & 1): lanes 0..15 = (row i, component), the other lanes repeat them
     const unsigned posa = lds0 + (unsigned)(X6_RAW + wave * 256);
@@ -524,7 +528,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
             // ---- gap 4
             if (even) {
                 if (OUTV != 2 && !K3W && !(X6_ABL & 16) && i >= 2)
-                    *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2];      // steps 4, 6
+                    { if (X6_NT & 2) __builtin_nontemporal_store(prev[i - 2], reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)));
+                      else *reinterpret_cast<f32x4*>(g.C + (size_t)prev_m * g.ldc + fcol + 8 * (i - 2)) = prev[i - 2]; }      // steps 4, 6
                 if (K3W && j == 0) k3_col(1);
                 if (K3W && j == 2) k3_col(4);
                 if (K3W && j == 4) k3_col(7);

@@ -51,7 +51,9 @@ for M in Ms:
          "n6 dgrad 160": lambda: engine.gemm(M, 160, 128, d1, 128, W1, 160, dX, 160, b_trans=1),
          "n6 wgrad 160": lambda: engine.wgrad(128, 160, M, d1, 128, X, 160, g1, gb1),
          "n6 wgrad 128": lambda: engine.wgrad(128, 128, M, d1, 128, H, 128, g2, gb1)}
-    if v >= 2048:        # a variant of csrc/layer_n6.hip
+    if v >= 4096:        # cache-policy variants of csrc/layer_x6.hip (X6_NT = v - 4096)
+        r = {k: f for k, f in r.items() if k.startswith("x6") and "wgrad" not in k}
+    elif v >= 2048:      # a variant of csrc/layer_n6.hip
         r = {k: f for k, f in r.items() if k.startswith("n6")}
     elif v:
         r = {k: f for k, f in r.items() if k in ("x6 forward", "x6 generated input", "x6 dgrad (sign bytes)")}
