@@ -74,3 +74,20 @@ def test_in_flight_register_guard():
     for s in glob.glob(os.path.join(REPO, "contrastive_lift_amd", "csrc", ".isa", "*.s")):
         r = subprocess.run([sys.executable, tool, s], capture_output=True, text=True)
         assert r.returncode == 0, (s, r.stdout[-2000:])
+
+
+def test_head_acts_keep_sign_bytes_with_their_activation():
+    """engine.HeadActs: the sign bytes of a persistent fp32x6 forward travel with the activation list, keyed by the activation's index,
+    and are refused when they do not belong to it (wrong row count) -- host logic, no GPU."""
+    import pytest
+    import torch
+    from contrastive_lift_amd import _lib, engine
+    M = 100
+    acts = engine.HeadActs([None, torch.zeros(M, 256)])
+    assert acts.sign_bits_of(1, M) is None and acts[1].shape == (M, 256) and len(acts) == 2
+    acts.signs[1] = torch.zeros((M + 31) // 32 * 1024, dtype=torch.uint8)
+    assert acts.sign_bits_of(1, M) is acts.signs[1]
+    with pytest.raises(_lib.CliftError, match="same forward"):
+        acts.sign_bits_of(1, M + 64)
+    acts.append(torch.zeros(M, 256))
+    assert acts.sign_bits_of(2, M) is None
