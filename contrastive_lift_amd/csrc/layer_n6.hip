@@ -75,6 +75,9 @@ __global__ __launch_bounds__(64 * NCG, 2) void k_layer_n6(GemmP g, int rows_per_
     constexpr int NPIECE = N6_ROWS * C4;
     constexpr int PER = (NPIECE + NT - 1) / NT;          // pieces per thread and tile
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * STAGE + (OUTV ? NCG * N6_ROWS + 128 : 0)];
+    // register ballast (layer_x6w.hip): with two 4-wave workgroups per CU every SIMD holds two of these waves, and with 256 registers each nothing of
+    // another PROCESS fits beside this bf16 MFMA stream (the 5-wave form leaves three SIMDs with one wave: no such guarantee there)
+    if (NCG == 4) asm volatile("v_mov_b32 v255, 0" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (rows_limited()) {          // sync-free step: re-balance the row ranges over the true row count (see layer_f32.hip)
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_n6(GemmP g, int rows_per_block
     constexpr int YPER = N6_ROWS * 32 / 512;             // dY pieces per thread and tile (2)
     constexpr int XC4 = 8 * KT, XPIECE = N6_ROWS * XC4, XPER = (XPIECE + 511) / 512;      // X pieces (KT = 4: 2; KT = 5: 3, the last one half-filled)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");       // register ballast: eight waves x 256 registers fill the CU's files (see k_layer_n6)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave & 3, wk = wave >> 2;
     if (rows_limited()) {
