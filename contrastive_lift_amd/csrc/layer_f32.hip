@@ -55,8 +55,9 @@ constexpr int LF_XROWS = 2048;               // positions staged per refill (64 
 // tensoRF.py:480-481), and the output layer out[m][c] = sum_k h[m][k] Wout[c][k] + bout[c] is applied to the tile while it is still in
 // registers instead of by a separate launch that re-reads the 1 KB-per-row activation: every lane holds 16 values of its row, so
 // 4 x 16 FMAs give its share of the E dot products (weights from LDS), a permlane swap folds the two half-waves, the eight waves'
-// shares meet in LDS and 16 lanes of the wave that owns the rows add them up (fixed order) and store.  All of it is spread through the
-// MFMA loops of the two following tiles.  store_hidden = 0: the hidden activation itself is not written (no backward through the head).
+// shares meet in LDS and 128 threads add them up (fixed order) and store -- right after the tile's MFMA loop, between two barriers (round 5: rounds
+// 2 - 4 spread it through the MFMA loops of the two following tiles by hand; see the OUTV state below).  store_hidden = 0: the hidden activation
+// itself is not written (no backward through the head).
 struct OutP {
     const float* Wout;    // (E, 256), row pitch ldwo
     int ldwo;

@@ -26,8 +26,9 @@ static __device__ __forceinline__ void wait_vmn() { asm volatile("s_waitcnt vmcn
 // OUTV (forward, KC = 32): the layer is the last hidden layer of the appearance MLP and the 3-wide output layer + sigmoid
 // (tensoRF.py:395-397,410) is applied to the tile while it is in registers: every lane holds 16 values of its row, 4 x 16 FMAs give its
 // share of the E <= 4 dot products (weights from LDS), a permlane swap folds the half-waves, the four column-waves' shares meet in LDS and
-// 32 lanes of the wave that owns the rows add them in a fixed order, add the bias, apply the sigmoid and store -- spread through the MFMA
-// loops of the two following tiles.  Replaces a launch that re-read the 512 B-per-row activation plus the row-activation launch.
+// 256 threads add them in a fixed order, add the bias, apply the sigmoid and store -- right after the tile's MFMA loop, between two barriers
+// (round 5; until then spread through the MFMA loops of the two following tiles by hand, see below).  Replaces a launch that re-read the
+// 512 B-per-row activation plus the row-activation launch.
 struct OutN {
     const float* Wout;    // (E, 128), row pitch ldwo
     int ldwo;
