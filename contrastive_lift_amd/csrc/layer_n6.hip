@@ -139,11 +139,18 @@ __global__ __launch_bounds__(64 * NCG, 2) void k_layer_n6(GemmP g, int rows_per_
         pofs[i] = row * (KCH * 16) + ((((c4 >> 1) ^ n6_sw<KCH>(row)) << 4) | ((c4 & 1) << 3));
     }
     float4 P[PER];
+    // (addresses = a wave-uniform base of the block's row range + a 32-bit byte offset: two VALU per piece instead of the 64-bit multiply-add chain;
+    // a block's range is far below 4 GB -- M / blocks rows of <= 640 B)
+    const char* const Ablk = reinterpret_cast<const char*>(g.A + (size_t)rbeg * g.lda);
+    const int nrows_blk = rend - rbeg;
+    const unsigned row_bytes = (unsigned)g.lda * 4u;
+    unsigned pcol[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) pcol[i] = (unsigned)(((tid + NT * i) - prow[i] * C4) * 16);
     auto fetch = [&](int t, int i) {
         if (NPIECE % NT != 0 && tid + NT * i >= NPIECE) return;
-        const int c4 = (tid + NT * i) - prow[i] * C4;
-        const int gr = min(rbeg + t * N6_ROWS + prow[i], rend - 1);             // rows past the range re-read its last row (never stored)
-        P[i] = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + 4 * c4);
+        const unsigned r = (unsigned)min(t * N6_ROWS + prow[i], nrows_blk - 1);  // rows past the range re-read its last row (never stored)
+        P[i] = *reinterpret_cast<const float4*>(Ablk + (r * row_bytes + pcol[i]));
     };
     unsigned char* const lb = reinterpret_cast<unsigned char*>(lds);
     auto split_store = [&](int stage, int i) {
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(64 * NCG, 2) void k_layer_n6(GemmP g, int rows_per_
         const int nxt = (t + 1) & 1;
         f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc0[r] = bias[r]; acc1[r] = 0.f; }     // (the bias rides in the first chain's start: sixteen adds fewer per tile)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int ci = li * KCH + ((2 * s + lh) ^ n6_sw<KCH>(li));
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64 * NCG, 2) void k_layer_n6(GemmP g, int rows_per_
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            v[r] = (acc0[r] + acc1[r]) + bias[r];
+            v[r] = acc0[r] + acc1[r];
             if (!DGRAD && g.act == 1) v[r] = fmaxf(v[r], 0.f);
         }
         if (MASK) {
@@ -339,17 +346,22 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_n6(GemmP g, int rows_per_block
     // bias gradient: this thread's dY pieces are always the same four columns 4 (tid & 31) .. +3 (512 is a multiple of the 32 pieces of a row), rows
     // (tid >> 5) + 16 i of every tile: four running sums of the exact fp32 values, folded over the 16 row-threads once per block
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (block-relative 32-bit byte offsets from wave-uniform bases, as in k_layer_n6)
+    const char* const Yblk = reinterpret_cast<const char*>(g.A + (size_t)rbeg * g.lda);
+    const char* const Xblk = reinterpret_cast<const char*>(g.B + (size_t)rbeg * g.ldb);
+    const int nrows_blk = rend - rbeg;
+    const unsigned ybytes = (unsigned)g.lda * 4u, xbytes = (unsigned)g.ldb * 4u;
     auto fetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < YPER; ++i) {
-            const int gr = min(rbeg + t * N6_ROWS + yrow[i], rend - 1);
-            PY[i] = *reinterpret_cast<const float4*>(g.A + (size_t)gr * g.lda + 4 * ((tid + 512 * i) & 31));
+            const unsigned r = (unsigned)min(t * N6_ROWS + yrow[i], nrows_blk - 1);
+            PY[i] = *reinterpret_cast<const float4*>(Yblk + (r * ybytes + (unsigned)(((tid + 512 * i) & 31) * 16)));
         }
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
             if (XPIECE % 512 != 0 && tid + 512 * i >= XPIECE) continue;
-            const int gr = min(rbeg + t * N6_ROWS + xrow[i], rend - 1);
-            PX[i] = *reinterpret_cast<const float4*>(g.B + (size_t)gr * g.ldb + 4 * ((tid + 512 * i) - xrow[i] * XC4));
+            const unsigned r = (unsigned)min(t * N6_ROWS + xrow[i], nrows_blk - 1);
+            PX[i] = *reinterpret_cast<const float4*>(Xblk + (r * xbytes + (unsigned)(((tid + 512 * i) - xrow[i] * XC4) * 16)));
         }
     };
     auto put = [&](int stage, int ofs, int pl_bytes, float4 v, bool live) {
