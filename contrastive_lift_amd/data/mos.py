@@ -66,9 +66,28 @@ def world_to_normscene(dims, intrinsics, cam2worlds, max_depth, rescale_factor=1
     return M
 
 
+# Thing / stuff table both dataset classes of the reference read (many_object_scenes.py:51, panopli.py:29: ``get_thing_semantics()`` =
+# [False] + column 2 of resources/scannet_reduced_things.csv, whatever the scene's own label set is): void, wall, floor, cabinet, bed, chair,
+# sofa, table, door, window, counter, shelves, curtain, ceiling, refridgerator, television, person, toilet, sink, lamp, bag, otherprop.
+# Data, pinned by golden G16 (``is_thing``).
+SCANNET_REDUCED_IS_THING = (False, False, False, False, True, True, True, False, False, False, False, False, False, False, True, True, True, True,
+                            True, False, True, False)
+
+
 class SceneTables:
     """What the readers share once cameras and per-frame targets exist: device-side ray tables, HBM-resident training
     tables, pixel batches and per-image instance batches (reference: BaseDataset + Inconsistent*SingleDataset)."""
+
+    faulty_classes = (0,)                                   # many_object_scenes.py:50, panopli.py:28
+    is_thing = SCANNET_REDUCED_IS_THING
+
+    @property
+    def things_filtered(self):                              # many_object_scenes.py:212-214
+        return {i for i, t in enumerate(self.is_thing) if t} - set(self.faulty_classes)
+
+    @property
+    def stuff_filtered(self):                               # many_object_scenes.py:216-218
+        return {i for i, t in enumerate(self.is_thing) if not t} - set(self.faulty_classes)
 
     def __len__(self):
         return len(self.train_indices if self.split == "train" else self.val_indices)
@@ -225,6 +244,15 @@ class MOSScene(SceneTables):
         H, W = self.image_dim
         seg = np.load(os.path.join(self.root, "detic_instance", f"{self.all_frame_names[sample_index]}.npy"))
         return torch.from_numpy(np.array(Image.fromarray(seg.astype(np.int16)).resize((W, H), Image.NEAREST))).long().reshape(-1)
+
+    def load_rs_targets(self, sample_index):
+        """:220-231: ground-truth labels of a validation view (``semantic`` / ``instance`` folders), NEAREST-resized."""
+        H, W = self.image_dim
+        name = self.all_frame_names[sample_index]
+        sem = Image.fromarray(np.load(os.path.join(self.root, "semantic", f"{name}.npy")).astype(np.uint8))
+        inst = Image.fromarray(np.load(os.path.join(self.root, "instance", f"{name}.npy")).astype(np.int16))
+        return dict(rs_semantics=torch.from_numpy(np.array(sem.resize((W, H), Image.NEAREST))).long().reshape(-1),
+                    rs_instances=torch.from_numpy(np.array(inst.resize((W, H), Image.NEAREST))).long().reshape(-1))
 
     def load_targets(self, sample_index):
         """:146-207 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,2), confidences (HW,)."""

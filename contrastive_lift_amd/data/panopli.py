@@ -64,6 +64,15 @@ class PanopLiScene(SceneTables):
         seg = Image.open(os.path.join(self.root, "m2f_segments", f"{self.all_frame_names[sample_index]}.png"))
         return torch.from_numpy(np.array(seg.resize((W, H), Image.NEAREST))).long().reshape(-1)
 
+    def load_rs_targets(self, sample_index):
+        """:215-225: ground-truth labels of a validation view (``rs_semantics`` / ``rs_instance`` folders), NEAREST-resized."""
+        H, W = self.image_dim
+        name = self.all_frame_names[sample_index]
+        sem = Image.open(os.path.join(self.root, "rs_semantics", f"{name}.png"))
+        inst = Image.open(os.path.join(self.root, "rs_instance", f"{name}.png"))
+        return dict(rs_semantics=torch.from_numpy(np.array(sem.resize((W, H), Image.NEAREST))).long().reshape(-1),
+                    rs_instances=torch.from_numpy(np.array(inst.resize((W, H), Image.NEAREST))).long().reshape(-1))
+
     def load_targets(self, sample_index):
         """:129-198 minus the rays: rgb (HW,3), semantics (HW,), instances (HW,), probabilities (HW,C), confidences (HW,), mask."""
         H, W = self.image_dim

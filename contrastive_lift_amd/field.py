@@ -195,7 +195,8 @@ class TensorVMSplit(nn.Module):
         seq("render_semantic_mlp.mlp", self.render_semantic_mlp.mlp, "net_sem")
         if self.instance_plane is not None:
             grids("instance", "grid_inst")
-            out.append(("instance_basis_mat.weight", self.instance_basis_mat, "weight", "matrix", "inst_fast"))
+            # its own group: "inst_fast" must mirror "inst_slow" element for element (the EMA is one axpy over the two ranges)
+            out.append(("instance_basis_mat.weight", self.instance_basis_mat, "weight", "matrix", "inst_basis"))
         if self.render_instance_mlp is not None:
             seq("render_instance_mlp.mlp", self.render_instance_mlp.mlp, "inst_fast")
             if self.slow_fast_mode:

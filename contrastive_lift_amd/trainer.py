@@ -56,24 +56,90 @@ class ArenaAdam:
         self.v = torch.zeros_like(model.param_flat)
         self.t = {r[0]: 0 for r in self.ranges}
         self.lr_scale = 1.0
+        self.frozen = set()       # ranges whose parameters this optimizer no longer holds (reference: tables replaced by ``shrink`` with no
+                                  # optimizer rebuild in the same hook, golden G21 scenario B) -- never stepped until the next rebuild
+
+    def carry_from(self, old, old_arena):
+        """After the arena was re-packed WITHOUT an optimizer rebuild (a bbox shrink in an epoch that has no grid upsample, T:448-449):
+        ranges whose size did not change (the MLPs) keep their moments and step counts at their new offsets -- the reference's Adam
+        still holds those very Parameter objects; ranges whose size changed (the cropped tables) were replaced by new Parameter
+        objects the reference's optimizer never sees: frozen until the next ``setup_optimizers``."""
+        prev = {r[0]: r for r in old.ranges}
+        for name, a, b, lr in self.ranges:
+            if name in prev and prev[name][2] - prev[name][1] == b - a and name not in old.frozen:
+                pa, pb = prev[name][1], prev[name][2]
+                self.m[a:b].copy_(old.m[pa:pb]); self.v[a:b].copy_(old.v[pa:pb])
+                self.t[name] = old.t[name]
+            else:
+                self.frozen.add(name)
+        self.lr_scale = old.lr_scale
+        return self
 
     def step(self, skip=()):
         p, g = self.model.param_flat, self.model.grad_flat
         st = _lib.stream()
         for name, a, b, lr in self.ranges:
-            if name in skip or b <= a:
+            if name in skip or name in self.frozen or b <= a:
                 continue
             self.t[name] += 1
             _lib.call("clift_adam", _lib.ptr(p[a:b]), _lib.ptr(g[a:b]), _lib.ptr(self.m[a:b]), _lib.ptr(self.v[a:b]), b - a,
                       float(lr * self.lr_scale), self.betas[0], self.betas[1], self.eps, float(self.wd), self.t[name], st)
 
     def state_dict(self):
-        return {"m": self.m.detach().clone(), "v": self.v.detach().clone(), "t": dict(self.t), "lr_scale": self.lr_scale}
+        return {"m": self.m.detach().clone(), "v": self.v.detach().clone(), "t": dict(self.t), "lr_scale": self.lr_scale, "frozen": sorted(self.frozen)}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"].to(self.m.device)); self.v.copy_(sd["v"].to(self.v.device))
         self.t = {k: int(sd["t"].get(k, 0)) for k in self.t}
         self.lr_scale = float(sd.get("lr_scale", 1.0))
+        self.frozen = set(sd.get("frozen", ()))
+
+    # ---- torch.optim.Adam's own state_dict layout (what a Lightning checkpoint of the reference holds under ``optimizer_states``)
+    def _range_of_param(self, name):
+        g = self.model.arena.by_name[name].group
+        for r in self.ranges:
+            if r[0] == g or (r[0] == "grids" and g in ("grid_density", "grid_app")):
+                return r
+        return None
+
+    def torch_state_dict(self, groups):
+        """``groups`` = [(lr, [parameter names])] in the order of the reference's param groups (tensoRF.py:199-246).  Parameters are
+        numbered across groups; a parameter that was never stepped has no state entry, like torch's lazily created state."""
+        mv, vv = self.model.arena.views(self.m), self.model.arena.views(self.v)
+        state, pgs, k = {}, [], 0
+        for lr, names in groups:
+            ids = []
+            for n in names:
+                r = self._range_of_param(n)
+                if r is not None and self.t[r[0]] > 0:
+                    state[k] = {"step": torch.tensor(float(self.t[r[0]])), "exp_avg": mv[n].detach().cpu().contiguous().clone(),
+                                "exp_avg_sq": vv[n].detach().cpu().contiguous().clone()}
+                ids.append(k)
+                k += 1
+            pgs.append({"lr": float(lr * self.lr_scale), "initial_lr": float(lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": float(self.wd),
+                        "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                        "params": ids})
+        return {"state": state, "param_groups": pgs}
+
+    def load_torch_state_dict(self, sd, groups):
+        """Inverse of ``torch_state_dict``: moments of every parameter that has state; a range's step count = that of its parameters
+        (they step together in the reference as well: one optimizer.step() per pass)."""
+        mv, vv = self.model.arena.views(self.m), self.model.arena.views(self.v)
+        names = [n for _, ns in groups for n in ns]
+        if len(names) != sum(len(g["params"]) for g in sd["param_groups"]):
+            raise ValueError(f"optimizer state has {sum(len(g['params']) for g in sd['param_groups'])} parameters, this field has {len(names)}")
+        self.m.zero_(); self.v.zero_()
+        self.t = {k: 0 for k in self.t}
+        for k, n in enumerate(names):
+            st = sd["state"].get(k)
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(mv[n].shape):
+                raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != {tuple(mv[n].shape)}")
+            mv[n].copy_(st["exp_avg"].to(self.m.device)); vv[n].copy_(st["exp_avg_sq"].to(self.v.device))
+            r = self._range_of_param(n)
+            if r is not None:
+                self.t[r[0]] = max(self.t[r[0]], int(float(st["step"])))
 
 
 def _shard_guard(fn):
@@ -111,7 +177,7 @@ class HotPathTrainer:
         self.class_weights = cw.to(self.device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.setup_optimizers()
-        self.on_train_epoch_start()
+        self.on_train_epoch_start(maintenance=False)      # (the ramp only: the field handed in is at this epoch's resolution already)
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)   # rgb, sem, tv, clustering (last step)
         # sync-free mode: per pass a capacity for the compacted buffers, learnt from the first (synchronising) steps and followed
         # asynchronously afterwards; see _capacity / _follow
@@ -120,8 +186,12 @@ class HotPathTrainer:
         self.overflow_steps = 0
 
     # ------------------------------------------------------------------ optimizers (T:98-103)
-    def setup_optimizers(self):
+    def setup_optimizers(self, carry=False):
+        """T:98-103 (``configure_optimizers``): fresh Adam moments, step counts AND MultiStepLR schedulers -- Lightning's
+        ``strategy.setup_optimizers`` (T:457,469) replaces both.  ``carry``: the arena was re-packed by a bbox shrink in an epoch without a
+        grid upsample; the reference does NOT rebuild there (ArenaAdam.carry_from)."""
         m, c = self.model, self.config
+        old = (getattr(self, "opt_main", None), getattr(self, "opt_inst", None), getattr(self, "_opt_arena", None)) if carry else None
         have = lambda *gs: [g for g in gs if g in m.arena.groups]                # (grid_sem / grid_inst exist only when that head sits on its own VM grid)
         a0, a1 = m.arena.range_of("grid_density", "grid_app")
         b0, b1 = m.arena.range_of("net_app")
@@ -146,10 +216,19 @@ class HotPathTrainer:
         # in every loss mode (T:268), so its .grad stays None and torch's Adam never touches it: only the fast range is stepped.
         i0, i1 = m.arena.range_of("inst_fast")
         inst = [("inst_fast", i0, i1, c.lr)]
-        if have("grid_inst"):                                                    # tensoRF.py:232-236: the instance tables at the grid rate
-            inst.insert(0, ("grid_inst",) + m.arena.range_of("grid_inst") + (c.lr * 20,))
+        if have("grid_inst"):                                                    # tensoRF.py:232-236: the instance tables at the grid rate, the basis matrix at the net rate
+            inst = [("grid_inst",) + m.arena.range_of("grid_inst") + (c.lr * 20,), ("inst_basis",) + m.arena.range_of("inst_basis") + (c.lr,)] + inst
         self.opt_inst = ArenaAdam(m, inst, (0.9, 0.999), c.weight_decay)
-        self.inst_range = m.arena.range_of(*have("grid_inst", "inst_fast"))
+        if old is not None and old[0] is not None:
+            self.opt_main.wd = old[0].wd                   # (the optimizer objects survive: so does the weight decay they were built with)
+            self.opt_inst.wd = old[1].wd
+            self.opt_main.carry_from(old[0], old[2])
+            self.opt_inst.carry_from(old[1], old[2])
+        else:
+            self.sched_steps = 0                           # MultiStepLR.last_epoch of the schedulers created with the optimizers
+            self._apply_lr_schedule()
+        self._opt_arena = m.arena
+        self.inst_range = m.arena.range_of(*have("grid_inst", "inst_basis", "inst_fast"))
         # sync-free capacities were learnt for the previous grid / step size / bounding box: forget them (two synchronising steps again)
         if hasattr(self, "_caps"):
             self._caps = {}
@@ -216,9 +295,72 @@ class HotPathTrainer:
         a, b = self.model.arena.range_of(*groups)
         _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), a - self._shard_range[0], b - a, 1, _lib.stream())
 
-    def on_train_epoch_start(self):
-        """T:447: dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch))."""
-        self.current_lambda_dist_reg = self.config.lambda_dist_reg * (1 - math.exp(-0.25 * self.current_epoch))
+    def on_train_epoch_start(self, maintenance=True):
+        """T:446-457, in the reference's order: the dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch)); at ``bbox_aabb_reset_epochs`` the
+        box shrinks to the alpha mask and the tables are cropped; at ``grid_upscale_epochs`` the tables are resampled to the next entry of the
+        log-spaced voxel schedule, ``weight_decay`` drops to 0 for the rest of the run and optimizers + schedulers are rebuilt.  Pinned by golden
+        G21 (the reference hook itself, five epochs).  A shrink in an epoch WITHOUT an upsample leaves the reference's optimizer holding the
+        replaced table Parameters: the cropped tables then receive no updates until the next rebuild (G21 scenario B) -- reproduced, with a
+        warning; it happens in no shipped config (every bbox_aabb_reset epoch is a grid_upscale epoch).
+        ``maintenance=False``: only the ramp (the CLI resuming a checkpoint written in the middle of an epoch, whose tables already went
+        through this epoch's hook)."""
+        c = self.config
+        e = self.current_epoch
+        self.current_lambda_dist_reg = c.lambda_dist_reg * (1 - math.exp(-0.25 * e))
+        if not maintenance:
+            return
+        shrink_at = [int(x) for x in (getattr(c, "bbox_aabb_reset_epochs", None) or ())]
+        upscale_at = [int(x) for x in (getattr(c, "grid_upscale_epochs", None) or ())]
+        if e in shrink_at:
+            if self.renderer.update_bbox_aabb_and_shrink(self.model):
+                if e not in upscale_at:
+                    print(f"clift: epoch {e} shrinks the tables without a grid upsample: like the reference, the optimizers are not rebuilt and the "
+                          "cropped tables stay fixed until the next grid_upscale epoch", flush=True)
+                    self.setup_optimizers(carry=True)
+        if e in upscale_at:
+            import numpy as np
+            voxels = torch.round(torch.exp(torch.linspace(np.log(c.min_grid_dim ** 3), np.log(c.max_grid_dim ** 3), len(upscale_at) + 1))).long().tolist()[1:]   # T:451
+            target = self.renderer.get_target_resolution(voxels[upscale_at.index(e)])
+            c.weight_decay = 0                                               # T:454
+            self.model.upsample_volume_grid(target)
+            self.renderer.update_step_size(target)
+            self.setup_optimizers()                                          # T:457
+            self.last_setup_epoch = e
+
+    # ------------------------------------------------------------------ MultiStepLR (trainer/__init__.py:134-139, T:226-228)
+    def _apply_lr_schedule(self):
+        c = self.config
+        if int(getattr(c, "warmup_epochs", 0) or 0) > 0:
+            raise NotImplementedError("HotPathTrainer: warmup_epochs > 0 (GradualWarmupScheduler) is not built (0 in every shipped config)")
+        steps = int(getattr(self, "sched_steps", 0))
+        scale = float(getattr(c, "decay_gamma", 0.5)) ** sum(1 for m in (getattr(c, "decay_step", None) or ()) if steps >= int(m))
+        self.opt_main.lr_scale = self.opt_inst.lr_scale = scale
+
+    def scheduler_step(self):
+        """T:226-228: both schedulers step once, at the last batch of every epoch.  The schedulers are re-created with the optimizers
+        (``setup_optimizers``), so the milestones of ``decay_step`` count epochs since the last grid upsample (golden G21 scenario C,
+        unpinned: it rests on Lightning's ``strategy.setup_optimizers`` replacing the scheduler objects)."""
+        self.sched_steps = int(getattr(self, "sched_steps", 0)) + 1
+        self._apply_lr_schedule()
+
+    # ------------------------------------------------------------------ parameter groups in the reference's order (tensoRF.py:199-246)
+    def torch_param_groups(self):
+        m, c = self.model, self.config
+        pl = lambda pre, kind: [f"{pre}_{kind}.{i}" for i in range(3)]
+        seq = lambda prefix: [s.name for s in m.arena.slots if s.name.startswith(prefix + ".")]
+        lg, ln = c.lr * 20, c.lr
+        main = [(lg, pl("density", "line")), (lg, pl("appearance", "line")), (lg, pl("density", "plane")), (lg, pl("appearance", "plane")),
+                (ln, ["appearance_basis_mat.weight"]), (ln, seq("render_appearance_mlp.mlp"))]
+        if m.semantic_plane is not None:
+            main += [(lg, pl("semantic", "plane")), (lg, pl("semantic", "line")), (ln, ["semantic_basis_mat.weight"])]
+        main.append((ln, seq("render_semantic_mlp.mlp")))
+        inst = []
+        if m.instance_plane is not None:
+            inst += [(lg, pl("instance", "plane")), (lg, pl("instance", "line")), (ln, ["instance_basis_mat.weight"])]
+        inst.append((ln, seq("render_instance_mlp.mlp")))
+        if m.slow_fast_mode and not bool(getattr(c, "use_DINO_style", True)):
+            inst.append((ln, seq("render_instance_mlp.slow_mlp")))
+        return main, inst
 
     def _allreduce(self, rng):
         if self.world > 1 or self.force_collectives:
@@ -338,7 +480,9 @@ class HotPathTrainer:
         ctxs, outs = [], []
         for i in range(0, B, chunk):
             if white_bg is None:
-                wb = self.white_bg or bool(torch.rand((1,)) < 0.5)       # renderer.py:164
+                wb = self.white_bg or bool(torch.rand((1,)) < 0.5)       # renderer.py:164: one coin per chunk
+            elif isinstance(white_bg, (list, tuple)):                    # (tests replaying the reference's recorded coins: one per chunk)
+                wb = bool(white_bg[i // chunk])
             else:
                 wb = bool(white_bg)
             n_c = min(chunk, B - i)
@@ -467,6 +611,7 @@ class HotPathTrainer:
                 # forward's reads.
                 f0, f1 = m.arena.range_of("inst_fast")
                 s0, s1 = m.arena.range_of("inst_slow")
+                assert f1 - f0 == s1 - s0, "arena groups inst_fast / inst_slow must have the same layout"
                 _lib.call("clift_ema", _lib.ptr(m.param_flat[s0:s1]), _lib.ptr(m.param_flat[f0:f1]), f1 - f0, 0.9, _lib.stream())
                 loss, g_inst = slow_fast_loss(inst, img["instances"], img["confidences"], return_grad=True)
             elif c.instance_loss_mode == "linear_assignment":
@@ -515,15 +660,121 @@ class HotPathTrainer:
         sd["loss_semantics.weight"] = self.class_weights.detach().clone()
         return sd
 
+    def checkpoint_dict(self, global_step=0, epoch_complete=True):
+        """Lightning-layout checkpoint: ``state_dict`` (model.* / renderer.* / loss_semantics.weight), ``epoch``, ``global_step``,
+        ``optimizer_states`` = the two Adam states in torch.optim.Adam's OWN state_dict layout with the reference's parameter-group order
+        (tensoRF.py:199-246) and ``lr_schedulers`` = the two MultiStepLR states -- what ``trainer.fit(ckpt_path=...)`` of the reference
+        restores -- plus a ``clift`` record for an exact continuation here (was the epoch finished; generators; frozen ranges)."""
+        main, inst = self.torch_param_groups()
+        c = self.config
+        sched = lambda base: {"milestones": {int(m): 1 for m in (getattr(c, "decay_step", None) or ())}, "gamma": float(getattr(c, "decay_gamma", 0.5)),
+                              "base_lrs": [float(lr) for lr, _ in base], "last_epoch": int(self.sched_steps), "verbose": False,
+                              "_step_count": int(self.sched_steps) + 1, "_get_lr_called_within_step": False,
+                              "_last_lr": [float(lr * self.opt_main.lr_scale) for lr, _ in base]}
+        return {"state_dict": self.state_dict_lightning(), "epoch": self.current_epoch, "global_step": global_step,
+                "pytorch-lightning_version": "2.0.4",
+                "optimizer_states": [self.opt_main.torch_state_dict(main), self.opt_inst.torch_state_dict(inst)],
+                "lr_schedulers": [sched(main), sched(inst)],
+                "clift": {"epoch_complete": bool(epoch_complete), "last_setup_epoch": int(getattr(self, "last_setup_epoch", 0)),
+                          "frozen": [sorted(self.opt_main.frozen), sorted(self.opt_inst.frozen)], "rng": self._rng_state()}}
+
     def save_checkpoint(self, path, global_step=0, epoch_complete=True):
-        """Lightning-layout checkpoint (keys the reference's consumers read: state_dict, epoch) plus what an exact resume
-        needs: both Adam states under Lightning's ``optimizer_states`` key and a ``clift`` record (was the epoch finished; epoch of
-        the last optimizer rebuild, from which the LR milestones count)."""
-        torch.save({"state_dict": self.state_dict_lightning(), "epoch": self.current_epoch, "global_step": global_step,
-                    "pytorch-lightning_version": "2.0.4",
-                    "optimizer_states": [self.opt_main.state_dict(), self.opt_inst.state_dict()],
-                    "clift": {"epoch_complete": bool(epoch_complete), "last_setup_epoch": int(getattr(self, "last_setup_epoch", 0)),
-                              "rng": self._rng_state()}}, path)
+        torch.save(self.checkpoint_dict(global_step, epoch_complete), path)
+
+    def on_load_checkpoint(self, checkpoint):
+        """T:461-470 followed by what Lightning does with the rest of the checkpoint (``load_state_dict`` of the module, then the optimizer
+        and scheduler states): if the checkpoint's epoch is past a grid upsample the tables are brought to the checkpoint's resolution, the
+        box and step size follow, ``weight_decay`` becomes 0 and the optimizers are rebuilt; then every weight, the renderer buffers, both
+        Adam states and the scheduler position are restored.  Accepts checkpoints of the reference (torch-layout ``optimizer_states``) and of
+        earlier builds of this repo (flat ``m`` / ``v`` records).  Golden G21 pins the hook and the continuation."""
+        c, m, r = self.config, self.model, self.renderer
+        dev = self.device
+        sd = checkpoint["state_dict"]
+        for epoch in [int(x) for x in (getattr(c, "grid_upscale_epochs", None) or ())][::-1]:
+            if checkpoint["epoch"] >= epoch:
+                c.weight_decay = 0                                                 # T:468
+                break
+        grid = [int(x) for x in sd["renderer.grid_dim"].tolist()]
+        have = [int(x) for x in r.grid_dim.tolist()]
+        if grid != have:            # (T:463-466 upsamples only past an upscale epoch; in every shipped config a changed grid implies one.  The shapes must
+            m.upsample_volume_grid(grid)                                           #  match for the strict load below either way; the values are overwritten)
+        missing, unexpected = m.load_state_dict({k[len("model."):]: v.to(dev) for k, v in sd.items() if k.startswith("model.")}, strict=True)
+        r.bbox_aabb.data = sd["renderer.bbox_aabb"].to(dev)
+        r.update_step_size(grid)
+        if "loss_semantics.weight" in sd:
+            self.class_weights = sd["loss_semantics.weight"].to(dev, torch.float32).clone()
+        self.current_epoch = int(checkpoint["epoch"])
+        self.setup_optimizers()                                                    # T:469, in the (possibly resized) arena layout
+        self.on_train_epoch_start(maintenance=False)
+        ost = checkpoint.get("optimizer_states")
+        if ost and len(ost) == 2:
+            if "param_groups" in ost[0]:
+                main, inst = self.torch_param_groups()
+                self.opt_main.load_torch_state_dict(ost[0], main)
+                self.opt_inst.load_torch_state_dict(ost[1], inst)
+            elif "m" in ost[0] and ost[0]["m"].numel() == self.opt_main.m.numel():
+                self.opt_main.load_state_dict(ost[0])
+                self.opt_inst.load_state_dict(ost[1])
+        extra = checkpoint.get("clift", {})
+        if checkpoint.get("lr_schedulers"):
+            self.sched_steps = int(checkpoint["lr_schedulers"][0]["last_epoch"])
+        elif "last_setup_epoch" in extra:                                          # earlier builds: milestones counted from the last rebuild
+            done = self.current_epoch + (1 if extra.get("epoch_complete", True) else 0)
+            self.sched_steps = max(0, done - int(extra["last_setup_epoch"]))
+        self._apply_lr_schedule()
+        for o, fz in zip((self.opt_main, self.opt_inst), extra.get("frozen", ((), ()))):
+            o.frozen = set(fz)
+        self.last_setup_epoch = int(extra.get("last_setup_epoch", 0))
+        return extra
+
+    # ------------------------------------------------------------------ validation (T:356-400)
+    @torch.no_grad()
+    def validation_step(self, batch, things, stuff, faulty_classes=(0,)):
+        """One validation view through the reference's ``validation_step``: masked MSE + PSNR, the semantic loss of the configured mode, mIoU
+        against the (machine-generated) training labels with class 0 ignored, PQ / SQ / RQ of (semantic argmax, instance argmax), and the same
+        against the ground-truth ``rs_*`` labels.  ``batch``: rays (P, 8), rgbs, semantics, instances, mask, rs_semantics, rs_instances,
+        probabilities, confidences.  Returns the reference's ``metrics_data`` dict (11 floats).  Host-side evaluation: the render is the HIP
+        path, the metrics are numpy / torch on its outputs (golden G21: ``A.val.*``)."""
+        from .inference import ConfusionMatrix, psnr, render_rays
+        from .metrics import panoptic_quality
+        from . import loss as L
+        c, dev = self.config, self.device
+        d = lambda k: batch[k].to(dev)
+        mask = d("mask").bool()
+        rgb, sem, inst, _depth = render_rays(self.model, self.renderer, d("rays"), c.chunk, self.white_bg)
+        rgb, sem = rgb.clone(), sem.clone()
+        rgbs = d("rgbs").clone()
+        rgb[~mask] = 0
+        rgbs[~mask] = 0
+        loss_rgb = torch.mean((rgb - rgbs) ** 2)
+        metric_psnr = psnr(rgb, rgbs)
+        sem[~mask] = 0
+        semantics = d("semantics").long()
+        if getattr(c, "use_symmetric_ce", False):
+            lossf = L.SCELoss(float(c.ce_alpha), float(c.ce_beta), self.class_weights)
+        else:
+            lossf = torch.nn.CrossEntropyLoss(reduction="none", weight=self.class_weights)
+        mode = getattr(c, "probabilistic_ce_mode", "TTAConf")
+        if mode == "TTAConf":
+            loss_sem = (lossf(sem, d("probabilities")) * d("confidences")).mean()
+        elif mode == "NoTTAConf":
+            loss_sem = (lossf(sem, semantics) * d("confidences")).mean()
+        else:
+            loss_sem = lossf(sem, semantics).mean()
+        C = self.model.num_semantic_classes
+        pred_valid = sem.argmax(1)
+        pred_all = pred_valid.clone()
+        pred_valid[semantics == 0] = 0
+        inst_arg = inst.argmax(1)
+        iou = ConfusionMatrix(num_classes=C, ignore_class=[0]).add_batch(pred_valid.cpu().numpy(), semantics.cpu().numpy(), return_miou=True)
+        pq, sq, rq = panoptic_quality(torch.stack([pred_valid, inst_arg], 1), torch.stack([semantics, d("instances").long()], 1), things, stuff,
+                                      allow_unknown_preds_category=True)
+        rs_sem, rs_inst = d("rs_semantics").long(), d("rs_instances").long()
+        rs_iou = ConfusionMatrix(num_classes=C, ignore_class=list(faulty_classes)).add_batch(pred_all.cpu().numpy(), rs_sem.cpu().numpy(), return_miou=True)
+        rs_pq, rs_sq, rs_rq = panoptic_quality(torch.stack([pred_all, inst_arg], 1), torch.stack([rs_sem, rs_inst], 1), things, stuff,
+                                               allow_unknown_preds_category=True)
+        return {"loss_rgb": float(loss_rgb), "loss_sem": float(loss_sem), "psnr": float(metric_psnr), "iou": float(iou), "pq": float(pq), "sq": float(sq),
+                "rq": float(rq), "rs_iou": float(rs_iou), "rs_pq": float(rs_pq), "rs_sq": float(rs_sq), "rs_rq": float(rs_rq)}
 
     def _rng_state(self):
         """Generators the step draws from: torch's CPU generator (white-background coin, R:164), the device's default generator

@@ -23,14 +23,31 @@ class CpuTrainer:
                  instance_loss_mode="slow_fast", temperature=100.0, use_delta=False, lambda_segment=1.2,
                  late_semantic_optimization=0, sce=None, lambda_tv_semantics=0.02, lambda_tv_instances=0.02, instance_optimization_epoch=0):
         self.P = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-        self.cfg, self.chunk, self.epoch = cfg, chunk, epoch
+        self.cfg, self.chunk = cfg, chunk
         self.inst_mode, self.temperature, self.use_delta = instance_loss_mode, temperature, use_delta
         self.l_seg = lambda_segment
         self.sce = sce                                             # (ce_alpha, ce_beta) when config.use_symmetric_ce (T:74-77)
-        self.sem_on = epoch >= late_semantic_optimization          # T:175,198: no semantic term before that epoch
         self.l_rgb, self.l_sem, self.l_tvd, self.l_tva = lambda_rgb, lambda_semantics, lambda_tv_density, lambda_tv_appearance
-        self.l_dist = lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                      # T:447
-        self.l_tvs, self.l_tvi, self.inst_on = lambda_tv_semantics, lambda_tv_instances, epoch >= instance_optimization_epoch
+        self.l_tvs, self.l_tvi = lambda_tv_semantics, lambda_tv_instances
+        self.lambda_dist_reg, self.late_sem, self.inst_epoch = lambda_dist_reg, late_semantic_optimization, instance_optimization_epoch
+        self.lr, self.weight_decay, self.dino = lr, weight_decay, dino
+        self.decay_step, self.decay_gamma = (9, 10), 0.5
+        self.set_epoch(epoch)
+        self.configure_optimizers()
+        C = self.P[[k for k in self.P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".bias")][-1]].shape[0]
+        self.cw = torch.ones(C) if class_weights is None else class_weights
+        if class_weights is None:
+            self.cw[0] = 0.0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        self.sem_on = epoch >= self.late_sem                       # T:175,198: no semantic term before that epoch
+        self.inst_on = epoch >= self.inst_epoch
+        self.l_dist = self.lambda_dist_reg * (1 - math.exp(-0.25 * epoch))                 # T:447
+
+    def configure_optimizers(self):
+        """T:98-103 + trainer/__init__.py:134-139: two Adams over the CURRENT parameter tensors, each with a MultiStepLR."""
+        lr, weight_decay = self.lr, self.weight_decay
         grids = [v for k, v in self.P.items() if k.startswith(GRID_KEYS)]
         nets = [v for k, v in self.P.items() if not k.startswith(GRID_KEYS + INST_GRID_KEYS) and not k.startswith(("render_instance_mlp", "instance_basis_mat"))]
         self.main_params = grids + nets
@@ -42,12 +59,30 @@ class CpuTrainer:
         self.inst_grid = [v for k, v in self.P.items() if k.startswith(INST_GRID_KEYS)]
         self.fast_mlp = list(self.fast)                                   # (the EMA pairs the two MLPs' parameters, T:325-329)
         self.fast = [v for k, v in self.P.items() if k.startswith("instance_basis_mat")] + self.fast
-        groups = ([{"params": self.inst_grid, "lr": lr * 20}] if self.inst_grid else []) + [{"params": self.fast + ([] if dino else self.slow), "lr": lr}]
+        groups = ([{"params": self.inst_grid, "lr": lr * 20}] if self.inst_grid else []) + [{"params": self.fast + ([] if self.dino else self.slow), "lr": lr}]
         self.opt_inst = torch.optim.Adam(groups, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.999))    # T:101-102
-        C = self.P[[k for k in self.P if k.startswith("render_semantic_mlp.mlp.") and k.endswith(".bias")][-1]].shape[0]
-        self.cw = torch.ones(C) if class_weights is None else class_weights
-        if class_weights is None:
-            self.cw[0] = 0.0
+        self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(self.decay_step), gamma=self.decay_gamma) for o in (self.opt_main, self.opt_inst)]
+
+    def on_train_epoch_start(self, epoch, bbox_aabb_reset_epochs=(), grid_upscale_epochs=(), min_grid_dim=128, max_grid_dim=192):
+        """T:446-457.  The parameter dict gets NEW tensors from shrink / upsample (the reference assigns new nn.Parameters, F:162-196); the
+        optimizers are rebuilt only in the upsample branch -- after a shrink alone they keep stepping the tensors that were replaced."""
+        from . import grid_ops
+        self.set_epoch(epoch)
+        if epoch in bbox_aabb_reset_epochs:
+            grid_ops.update_bbox_aabb_and_shrink(self.P, self.cfg)
+        if epoch in grid_upscale_epochs:
+            n_vox = grid_ops.voxel_schedule(min_grid_dim, max_grid_dim, len(grid_upscale_epochs))[list(grid_upscale_epochs).index(epoch)]
+            target = grid_ops.target_resolution(self.cfg, n_vox)
+            self.weight_decay = 0                                  # T:454
+            grid_ops.upsample_volume_grid(self.P, target)
+            self.cfg.grid_dim = tuple(target)
+            self.cfg.refresh()                                     # T:456 update_step_size
+            self.configure_optimizers()                            # T:457
+
+    def end_of_epoch(self):
+        """T:226-228: both schedulers step at the last batch of an epoch."""
+        for s_ in self.scheds:
+            s_.step()
 
     def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None, segments=None):
         """``segments`` = dict(rays, group, conf, jitter, n_groups): the segment-consistency term of T:185-197 (active from

@@ -86,6 +86,23 @@ def install_stand_ins():
     _fake("torch_scatter", scatter_mean=_scatter_mean)
 
 
+def install_quaternion():
+    """pyquaternion is absent from this image: ``Quaternion(w,x,y,z).rotation_matrix`` by the textbook unit-quaternion formula
+    (normalised first, as that package does)."""
+    class Quaternion:
+        def __init__(self, w, x, y, z):
+            q = np.array([w, x, y, z], np.float64)
+            self.q = q / np.linalg.norm(q)
+
+        @property
+        def rotation_matrix(self):
+            w, x, y, z = self.q
+            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                             [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                             [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    sys.modules["pyquaternion"].Quaternion = Quaternion
+
+
 def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
@@ -118,13 +135,13 @@ def look_at(eye, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
 GRAD_STRIDE = 17
 
 
-def grad_digest(prefix, named_grads):
+def grad_digest(prefix, named_grads, stride=GRAD_STRIDE):
     """Small tensors in full, big ones as a strided subsample + L2 norm."""
     out = {}
     for k, g in named_grads.items():
         g = torch.zeros(1) if g is None else g.detach().reshape(-1)
         out[f"{prefix}norm.{k}"] = g.norm()
-        out[f"{prefix}sub.{k}"] = (g if g.numel() <= 4096 else g[::GRAD_STRIDE]).clone()   # clone: parameters are updated in place later
+        out[f"{prefix}sub.{k}"] = (g if g.numel() <= 4096 else g[::stride]).clone()   # clone: parameters are updated in place later
     return out
 
 
@@ -596,6 +613,245 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
     npz(fname, **out)
 
 
+G21_STRIDE = 53
+
+
+def g21_epoch_boundary():
+    """The epoch boundary of the REFERENCE trainer, composed: TensoRFTrainer.on_train_epoch_start (T:446-459: dist-reg ramp -> alpha-mask
+    shrink -> grid upsample -> ``weight_decay = 0`` -> optimizer rebuild), the scheduler step at an epoch's last batch (T:226-228),
+    on_load_checkpoint (T:461-470) and validation_step (T:356-400), all called unbound on the G12 shim.  What Lightning would supply is
+    stubbed: ``trainer.strategy.setup_optimizers(trainer)`` re-runs ``configure_optimizers`` and replaces BOTH the optimizers and the
+    schedulers (pytorch_lightning 2.0.4 ``Strategy.setup_optimizers`` -> ``_init_optimizers_and_lr_schedulers``; the package is absent
+    here, so what depends on exactly that -- the MultiStepLR milestones restarting at every rebuild -- is stored under ``unpinned_`` keys:
+    scenario C).  Scenarios:
+
+      A  five epochs x two steps, bbox_aabb_reset_epochs [1, 2], grid_upscale_epochs [1, 2, 3] (every shrink is followed by an upsample in the
+         same hook, as in every shipped config); a Lightning-layout checkpoint taken in the middle of epoch 2 is restored into a fresh shim
+         (on_load_checkpoint, then the state_dict / optimizer-state loads Lightning performs) and must reproduce the uninterrupted run's next step;
+         one validation_step on a 16 x 16 view at the end.
+      B  a shrink WITHOUT an upsample in the same epoch (bbox_aabb_reset_epochs [1], grid_upscale_epochs [2]): the reference does not rebuild
+         its optimizers there, so Adam keeps stepping the parameter objects ``shrink`` replaced -- the cropped tables receive no updates until
+         the next rebuild, the MLPs keep their moments.
+      C  (unpinned) decay_step [1, 3] with an upsample at epoch 2: learning rates per epoch."""
+    import types as _t
+    import copy
+    import trainer.train_panopli_tensorf as T
+    import model.renderer.panopli_tensoRF_renderer as RR
+    from model.loss.loss import TVLoss
+    g0, C, E = 10, 4, 3
+    res = (g0, g0, g0)
+    aabb0 = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    B, Bi, chunk, seed = 96, 64, 40, 2121
+    make_P = lambda: op.add_blob(op.make_params(seed, res, C, E, grid_scale=0.05), res, amplitude=2.5, sigma_g=0.3)
+    rng0 = np.random.default_rng(seed + 1)
+    K = torch.tensor([[40.0, 0, 16], [0, 40.0, 16], [0, 0, 1]])
+    poses = [look_at((0.0, 0.1, -0.9)), look_at((0.7, -0.4, 0.3)), look_at((-0.5, 0.6, 0.4))]
+    _, pool = make_rays(32, K, poses, 400, rng0)
+    cw = torch.ones(C)
+    cw[0] = 0.0
+
+    class Shim:
+        configure_optimizers = T.TensoRFTrainer.configure_optimizers
+        forward = T.TensoRFTrainer.forward
+        forward_instance = T.TensoRFTrainer.forward_instance
+        training_step = T.TensoRFTrainer.training_step
+        calculate_instance_clustering_loss = T.TensoRFTrainer.calculate_instance_clustering_loss
+        ema_update_slownet = T.TensoRFTrainer.ema_update_slownet
+        on_train_epoch_start = T.TensoRFTrainer.on_train_epoch_start
+        on_load_checkpoint = T.TensoRFTrainer.on_load_checkpoint
+        validation_step = T.TensoRFTrainer.validation_step
+
+        def __call__(self, *a):
+            return self.forward(*a)
+
+        def optimizers(self):
+            return self._opts
+
+        def lr_schedulers(self):
+            return self._scheds
+
+        def manual_backward(self, loss):
+            loss.backward()
+
+        def log(self, name, value, **k):
+            self.logged.setdefault(name, []).append(float(value))
+
+    def make_shim(over):
+        cfg = _t.SimpleNamespace(
+            lr=5e-4, weight_decay=1e-8, decay_step=[9, 10], decay_gamma=0.5, warmup_epochs=0, chunk=chunk, perturb=1.0,
+            optimize_instance_only=False, lambda_rgb=1.0, lambda_semantics=0.1, lambda_feat=0.0, lambda_segment=0.0, lambda_dist_reg=0.005,
+            lambda_tv_density=0.1, lambda_tv_appearance=0.01, lambda_tv_semantics=0.02, lambda_tv_instances=0.02,
+            use_distilled_features_semantic=False, use_distilled_features_instance=False, feature_optimization_end_epoch=0,
+            late_semantic_optimization=1, instance_optimization_epoch=2, segment_optimization_epoch=100, segment_grouping_mode="none",
+            probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E, min_grid_dim=g0, max_grid_dim=16,
+            bbox_aabb_reset_epochs=[1, 2], grid_upscale_epochs=[1, 2, 3])
+        cfg.__dict__.update(over)
+        sh = Shim()
+        sh.config = cfg
+        sh.model = build_reference_model(make_P(), res, C, E, shift=-3.0)
+        sh.renderer = build_reference_renderer(aabb0, res, "softmax")
+        sh.train_set = _t.SimpleNamespace(white_bg=False, things_filtered={2, 3}, stuff_filtered={0, 1}, faulty_classes=[0])
+        sh.loss = torch.nn.MSELoss(reduction="mean")
+        sh.loss_feat = torch.nn.L1Loss(reduction="mean")
+        sh.tv_regularizer = TVLoss()
+        sh.loss_semantics = torch.nn.CrossEntropyLoss(reduction="none", weight=cw)
+        sh.instance_loss_mode, sh.use_DINO_style, sh.temperature, sh.use_delta = "slow_fast", True, 100.0, False
+        sh.loss_instances_cluster = torch.nn.CrossEntropyLoss(reduction="none")
+        sh.device = torch.device("cpu")
+        sh.current_epoch, sh.current_lambda_dist_reg = 0, 0
+        sh.logged, sh.validation_step_outputs, sh.rebuilds = {}, [], 0
+
+        def setup_optimizers(_trainer):
+            sh._opts, sh._scheds = sh.configure_optimizers()
+            sh.rebuilds += 1
+        sh.trainer = _t.SimpleNamespace(is_last_batch=False, current_epoch=0, strategy=_t.SimpleNamespace(setup_optimizers=setup_optimizers))
+        setup_optimizers(sh.trainer)            # (Lightning: strategy.setup() before the first epoch)
+        sh.rebuilds = 0
+        return sh
+
+    def step_batch(e, st):
+        """Inputs of training step ``st`` of epoch ``e``: a function of (e, st) only, so that a resumed run can draw the same batch."""
+        rng = np.random.default_rng(seed * 1000 + e * 10 + st)
+        rays = pool[torch.from_numpy(rng.choice(pool.shape[0], size=B, replace=False))].clone()
+        rgbs = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32))
+        probs = torch.softmax(torch.from_numpy(rng.standard_normal((B, C)).astype(np.float32)), -1)
+        confs = torch.from_numpy(rng.uniform(0, 1, (B,)).astype(np.float32))
+        mask = torch.from_numpy(rng.uniform(0, 1, (B,)) > 0.1)
+        irays = pool[torch.from_numpy(rng.choice(pool.shape[0], size=Bi, replace=False))].clone()
+        labels = torch.from_numpy(rng.integers(1, 5, size=(Bi,)))
+        iconf = torch.from_numpy(rng.uniform(0, 1, (Bi,)).astype(np.float32))
+        return dict(rays=rays, rgbs=rgbs, probs=probs, confs=confs, mask=mask, irays=irays, labels=labels, iconf=iconf)
+
+    real_rl, real_r = RR.torch.rand_like, RR.torch.rand
+    draws = []
+
+    def rec_rand_like(t, *a, **k):
+        v = real_rl(t, *a, **k)
+        draws.append(("jit", v.reshape(-1).clone()))
+        return v
+
+    def rec_rand(*a, **k):
+        v = real_r(*a, **k)
+        draws.append(("coin", v.reshape(-1).clone()))
+        return v
+
+    def one_step(sh, e, st, last, out=None, tag=None):
+        b = step_batch(e, st)
+        if out is not None:
+            out.update({f"{tag}.e{e}.s{st}.{k}": v.clone() for k, v in b.items()})
+        batch = {0: dict(rays=b["rays"], rgbs=b["rgbs"], semantics=b["probs"].argmax(-1), probabilities=b["probs"], confidences=b["confs"],
+                         mask=b["mask"], feats=torch.zeros(B, 1)),
+                 1: dict(rays=[b["irays"]], instances=[b["labels"]], confidences=[b["iconf"]])}
+        draws.clear()
+        torch.manual_seed(seed + 100 * e + st)
+        sh.trainer.is_last_batch = bool(last)
+        with quiet():
+            sh.training_step(batch, st)
+        if out is None:
+            return
+        nmain = (B + chunk - 1) // chunk
+        jits = [v for k, v in draws if k == "jit"]
+        out[f"{tag}.e{e}.s{st}.jitter"] = torch.cat(jits[:nmain])
+        if len(jits) > nmain:
+            out[f"{tag}.e{e}.s{st}.ijitter"] = torch.cat(jits[nmain:])
+        out[f"{tag}.e{e}.s{st}.white"] = (torch.cat([v for k, v in draws if k == "coin"]) < 0.5)
+        out[f"{tag}.e{e}.s{st}.loss_rgb"] = np.float32(sh.logged["train/loss_rgb"][-1])
+        out[f"{tag}.e{e}.s{st}.loss_sem"] = np.float32(sh.logged["train/loss_semantics"][-1])
+        if e >= sh.config.instance_optimization_epoch:
+            out[f"{tag}.e{e}.s{st}.loss_clustering"] = np.float32(sh.logged["train/loss_clustering"][-1])
+        out.update(grad_digest(f"{tag}.e{e}.s{st}.p", {k: p.detach() for k, p in sh.model.named_parameters()}, stride=G21_STRIDE))
+
+    def hook_record(sh, out, tag, e):
+        rr = sh.renderer
+        groups = [(float(g["lr"]), float(g["weight_decay"]), sum(p.numel() for p in g["params"])) for o in sh._opts for g in o.param_groups]
+        out.update({f"{tag}.e{e}.aabb": rr.bbox_aabb.clone(), f"{tag}.e{e}.grid": rr.grid_dim.clone(), f"{tag}.e{e}.n_samples": rr.n_samples,
+                    f"{tag}.e{e}.step_size": rr.step_size.clone(), f"{tag}.e{e}.units": rr.units.clone(),
+                    f"{tag}.e{e}.lambda_dist": np.float64(sh.current_lambda_dist_reg), f"{tag}.e{e}.weight_decay": np.float64(sh.config.weight_decay),
+                    f"{tag}.e{e}.rebuilds": sh.rebuilds,
+                    f"{tag}.e{e}.opt_numel": np.array([g[2] for g in groups]), f"{tag}.e{e}.opt_wd": np.array([g[1] for g in groups], np.float64),
+                    f"unpinned_{tag}.e{e}.opt_lr": np.array([g[0] for g in groups], np.float64)})
+
+    def run(tag, over, epochs, steps, out, snapshot=None):
+        sh = make_shim(over)
+        snap = None
+        for e in range(epochs):
+            sh.current_epoch = sh.trainer.current_epoch = e
+            with quiet():
+                sh.on_train_epoch_start()
+            hook_record(sh, out, tag, e)
+            for st in range(steps):
+                one_step(sh, e, st, st == steps - 1, out, tag)
+                if snapshot == (e, st):          # what a Lightning checkpoint holds of this path (ModelCheckpoint every_n_train_steps: mid-epoch)
+                    sd = {f"model.{k}": v.detach().clone() for k, v in sh.model.state_dict().items()}
+                    sd.update({f"renderer.{k}": v.detach().clone() for k, v in sh.renderer.state_dict().items()})
+                    snap = {"epoch": e, "state_dict": sd, "optimizer_states": [copy.deepcopy(o.state_dict()) for o in sh._opts],
+                            "lr_schedulers": [copy.deepcopy(s.state_dict()) for s in sh._scheds]}
+        return sh, snap
+
+    out = dict(res=np.array(res), C=C, E=E, seed=seed, shift=-3.0, grid_scale=0.05, aabb=aabb0, B=B, Bi=Bi, chunk=chunk, class_weights=cw,
+               stride=G21_STRIDE)
+    RR.torch.rand_like, RR.torch.rand = rec_rand_like, rec_rand
+    try:
+        # ---- A
+        out["A.epochs"], out["A.steps"] = 5, 2
+        out["A.bbox_aabb_reset_epochs"], out["A.grid_upscale_epochs"] = np.array([1, 2]), np.array([1, 2, 3])
+        sh, snap = run("A", {}, 5, 2, out, snapshot=(2, 0))
+        # resume: a fresh shim (what TensoRFTrainer.__init__ builds: min_grid_dim^3 grids, the scene's box), the hook, then Lightning's loads
+        sh2 = make_shim({})
+        sh2.config.weight_decay = 1e-8
+        with quiet():
+            sh2.on_load_checkpoint(snap)
+        out["A.resume.grid_after_hook"] = sh2.renderer.grid_dim.clone()
+        out["A.resume.weight_decay"] = np.float64(sh2.config.weight_decay)
+        sh2.model.load_state_dict({k[len("model."):]: v for k, v in snap["state_dict"].items() if k.startswith("model.")}, strict=True)
+        sh2.renderer.load_state_dict({k[len("renderer."):]: v for k, v in snap["state_dict"].items() if k.startswith("renderer.")}, strict=True)
+        for o, s_ in zip(sh2._opts, snap["optimizer_states"]):
+            o.load_state_dict(s_)
+        for sc, s_ in zip(sh2._scheds, snap["lr_schedulers"]):
+            sc.load_state_dict(s_)
+        sh2.current_epoch = sh2.trainer.current_epoch = 2
+        sh2.current_lambda_dist_reg = sh2.config.lambda_dist_reg * (1 - np.exp(-0.25 * 2))
+        tmp = {}
+        one_step(sh2, 2, 1, True, tmp, "R")
+        worst = max(float((tmp[k] - out["A" + k[1:]]).abs().max()) for k in tmp if ".psub." in k)
+        assert worst < 1e-6, worst                # the reference's own resume reproduces its uninterrupted step
+        out["A.resume.max_abs_diff_vs_uninterrupted"] = np.float64(worst)
+        # validation_step on one 16 x 16 view with the final field of A
+        from util.ray import get_ray_directions_with_intrinsics, get_rays, rays_intersect_sphere
+        Kv = np.array([[20.0, 0, 8], [0, 20.0, 8], [0, 0, 1]])
+        o_, d_ = get_rays(get_ray_directions_with_intrinsics(16, 16, Kv), look_at((0.0, 0.1, -0.9)))
+        vrays = torch.cat([o_, d_, 0.01 * torch.ones_like(o_[:, :1]), rays_intersect_sphere(o_, d_, 1)[:, None]], 1)
+        rngv = np.random.default_rng(seed + 7)
+        n = vrays.shape[0]
+        vb = dict(rays=vrays, rgbs=torch.from_numpy(rngv.uniform(0, 1, (n, 3)).astype(np.float32)),
+                  semantics=torch.from_numpy(rngv.integers(0, C, n)), instances=torch.from_numpy(rngv.integers(0, E + 1, n)),
+                  mask=torch.from_numpy(rngv.uniform(0, 1, n) > 0.1), rs_semantics=torch.from_numpy(rngv.integers(0, C, n)),
+                  rs_instances=torch.from_numpy(rngv.integers(0, E + 1, n)),
+                  probabilities=torch.softmax(torch.from_numpy(rngv.standard_normal((n, C)).astype(np.float32)), -1),
+                  confidences=torch.from_numpy(rngv.uniform(0, 1, n).astype(np.float32)))
+        out.update({f"A.val.{k}": v.clone() for k, v in vb.items()})
+        with torch.no_grad(), quiet():
+            md = sh.validation_step({k: v.clone()[None] for k, v in vb.items()}, 0)
+            rgb_v, sem_v, inst_v, _d, _f, _r = sh(vrays, False)
+        out["A.val.metric_names"] = np.array(list(md.keys()))
+        out["A.val.metrics"] = np.array([md[k] for k in md], np.float64)
+        out["A.val.out_rgb"], out["A.val.out_sem_argmax"], out["A.val.out_inst_argmax"] = rgb_v, sem_v.argmax(1), inst_v.argmax(1)
+        # ---- B: shrink-only epoch
+        out["B.epochs"], out["B.steps"] = 3, 2
+        out["B.bbox_aabb_reset_epochs"], out["B.grid_upscale_epochs"] = np.array([1]), np.array([2])
+        run("B", dict(bbox_aabb_reset_epochs=[1], grid_upscale_epochs=[2]), 3, 2, out)
+        # ---- C: learning-rate schedule across a rebuild (depends on the Lightning stub: unpinned)
+        tmpc = {}
+        run("C", dict(bbox_aabb_reset_epochs=[], grid_upscale_epochs=[2], decay_step=[1, 3]), 6, 1, tmpc)
+        out["unpinned_C.opt_lr"] = np.stack([tmpc[f"unpinned_C.e{e}.opt_lr"] for e in range(6)])
+        out["unpinned_C.decay_step"], out["unpinned_C.grid_upscale_epochs"] = np.array([1, 3]), np.array([2])
+        out.update({"unpinned_" + k: v for k, v in tmpc.items() if k.startswith("C.e5.s0.p")})
+    finally:
+        RR.torch.rand_like, RR.torch.rand = real_rl, real_r
+    npz("g21_epoch_boundary", **out)
+
+
+
 def g13_postprocess():
     """Inference post-processing of the reference: create_instances_from_semantics (RP:422-427), assign_clusters
     (RP:371-419: per thing class nearest cached centroid, disjoint label offsets, one-hot), distance_to_depth
@@ -642,18 +898,7 @@ def g14_mos_dataset():
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
 
-    class Quaternion:
-        def __init__(self, w, x, y, z):
-            q = np.array([w, x, y, z], np.float64)
-            self.q = q / np.linalg.norm(q)
-
-        @property
-        def rotation_matrix(self):
-            w, x, y, z = self.q
-            return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                             [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                             [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
-    sys.modules["pyquaternion"].Quaternion = Quaternion
+    install_quaternion()
     import tempfile
     tmp = tempfile.mkdtemp(prefix="g14_")
     scene_args = dict(n_frames=10, size=24, seed=7, invalid_frames=(0,), trajectory_frames=4)
@@ -942,6 +1187,10 @@ def main():
         sys.exit(f"reference not found at {REF}: golden vectors can only be regenerated in the build container")
     torch.set_num_threads(4)
     install_stand_ins()
+    if only:                     # python make_golden.py g21_epoch_boundary ... : just these generators (no arguments)
+        for name in only:
+            globals()[name]()
+        return
     g1_rays()
     g2_sampling()
     g3_field()
@@ -968,6 +1217,13 @@ def main():
     g19_grid_heads()
     # the allgrid overlay's arrangement: both heads on VM grids, plain contrastive instance loss (optimizer groups of the grid heads, TV on their tables)
     g12_training_steps(mode="contrastive", fname="g12g_training_steps_grid_heads", steps=2, grids=True)
+    g12gs()
+    g21_epoch_boundary()
+
+
+def g12gs():
+    """Both heads on VM grids WITH the slow-fast twin (instance_basis_mat sits before the fast MLP in the optimizer, the EMA pairs the two MLPs only)."""
+    g12_training_steps(mode="slow_fast", fname="g12gs_training_steps_grid_heads_slow_fast", steps=2, grids=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Golden G22: one full SHORT TRAINING SCHEDULE run by the REFERENCE itself (build container only, CPU, several minutes per seed).
+
+    python tests/golden/make_schedule_golden.py [seed ...]          # default seeds 0 1 2; writes g22_short_schedule.json
+
+For every seed: the reference's ``TensoRFTrainer`` (trainer/train_panopli_tensorf.py:38-470, constructed by its own ``__init__`` on the
+synthetic Messy-Rooms-layout scene of tools/make_synthetic_mos.py, datasets = the reference's MOSDataset / InconsistentMOSSingleDataset)
+is driven through the loop Lightning's ``trainer.fit`` would run -- ``on_train_epoch_start``, ``training_step`` over the combined loaders
+(pixel loader exhausted once per epoch, the instance loader cycling), schedulers at the last batch, ``validation_step`` over the validation
+views after every epoch -- then its checkpoint is rendered by the reference's own ``inference/render_panopli.py`` (test views, MeanShift
+clustering) and scored by the reference's scene evaluators (``calculate_panoptic_quality_folders_MOS``: PQ_scene).  Recorded per seed: the
+last validation table (PSNR, mIoU, PQ ...), mIoU_scene / PQ_scene / SQ / RQ; over the seeds: mean and spread.  The product's train / render /
+evaluate CLIs run the same schedule on the GPU in tests/test_gpu_round6.py and must land within max(0.1, the reference's own spread).
+
+Third-party packages absent here are replaced as in make_golden.py (inert stand-ins; ``eff_distloss`` restated: the dist-reg term is UNPINNED);
+what Lightning would supply is a minimal base class.  Visualisation calls are stubbed (no arithmetic of the path)."""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import make_golden as MG                       # noqa: E402  (puts REPO and the reference on sys.path)
+
+REF = MG.REF
+SCHEDULE = dict(experiment="contrastive_lift_MOS", image_dim=64, min_grid_dim=32, max_grid_dim=64, max_epoch=6, batch_size=512, chunk=2048,
+                max_depth=3, max_rays_instances=512, decay_step=[4, 5], n_frames=40, scene_seed=0, bandwidth=0.15)
+
+
+class FakeLightningModule(torch.nn.Module):
+    """What TensoRFTrainer uses of pl.LightningModule."""
+    device = torch.device("cpu")
+    current_epoch = 0
+    global_step = 0
+
+    def save_hyperparameters(self, *a, **k):
+        pass
+
+    def optimizers(self):
+        return self._opts
+
+    def lr_schedulers(self):
+        return self._scheds
+
+    def manual_backward(self, loss):
+        loss.backward()
+
+    def log(self, name, value, **k):
+        self._logged[name] = float(value)
+
+
+def run_seed(seed, threads):
+    import yaml
+    from contrastive_lift_amd.config import load_config, save_config
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+    tmp = tempfile.mkdtemp(prefix=f"g22_s{seed}_")
+    os.symlink(os.path.join(REF, "resources"), os.path.join(tmp, "resources"))       # the datasets read resources/*.csv relative to the cwd
+    scene_dir = gen.make_scene(os.path.join(tmp, "data", "synth_scene"), n_frames=SCHEDULE["n_frames"], size=SCHEDULE["image_dim"], seed=SCHEDULE["scene_seed"])
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        cfg = load_config(os.path.join(REF, "config"), overrides=[f"+experiment={SCHEDULE['experiment']}", f"dataset_root={scene_dir}",
+                          f"image_dim={SCHEDULE['image_dim']}", f"min_grid_dim={SCHEDULE['min_grid_dim']}", f"max_grid_dim={SCHEDULE['max_grid_dim']}",
+                          f"max_epoch={SCHEDULE['max_epoch']}", f"batch_size={SCHEDULE['batch_size']}", f"chunk={SCHEDULE['chunk']}",
+                          f"max_depth={SCHEDULE['max_depth']}", f"max_rays_instances={SCHEDULE['max_rays_instances']}",
+                          f"decay_step={SCHEDULE['decay_step']}", f"seed={seed}", "num_workers=0", "logger=none"])
+        cfg.image_dim = [cfg.image_dim, cfg.image_dim]
+        cfg.experiment = f"g22_seed{seed}"
+        os.makedirs(f"runs/{cfg.experiment}/checkpoints", exist_ok=True)
+        torch.manual_seed(seed)                    # seed_everything(config.seed), trainer/__init__.py:73
+        np.random.seed(seed)
+        __import__("random").seed(seed)
+        import trainer.train_panopli_tensorf as T
+        t0 = time.time()
+        with MG.quiet():
+            model = T.TensoRFTrainer(cfg)
+        model._logged = {}
+        model._opts, model._scheds = model.configure_optimizers()
+
+        def setup_optimizers(_tr):                  # Lightning: Strategy.setup_optimizers -> _init_optimizers_and_lr_schedulers
+            model._opts, model._scheds = model.configure_optimizers()
+        model.trainer = types.SimpleNamespace(is_last_batch=False, current_epoch=0, strategy=types.SimpleNamespace(setup_optimizers=setup_optimizers))
+        with MG.quiet():
+            loaders = model.train_dataloader()
+        val_loader = model.val_dataloader()
+        n_steps = max(len(l) for l in loaders.values())
+        table, gstep = {}, 0
+        for epoch in range(int(cfg.max_epoch)):
+            model.current_epoch = model.trainer.current_epoch = epoch
+            with MG.quiet():
+                model.on_train_epoch_start()
+            its = {k: iter(l) for k, l in loaders.items()}
+            for i in range(n_steps):                # CombinedLoader "max_size_cycle": the shorter loaders restart
+                batch = {}
+                for k in its:
+                    try:
+                        batch[k] = next(its[k])
+                    except StopIteration:
+                        its[k] = iter(loaders[k])
+                        batch[k] = next(its[k])
+                model.trainer.is_last_batch = i == n_steps - 1
+                with MG.quiet():
+                    model.training_step(batch, i)
+                gstep += 1
+                model.global_step = gstep
+            model.validation_step_outputs = []
+            with torch.no_grad(), MG.quiet():
+                for j, vb in enumerate(val_loader):
+                    model.validation_step(vb, j)
+            rows = model.validation_step_outputs
+            table = {k: float(np.mean([r[k] for r in rows])) for k in rows[0]}
+            print(f"seed {seed} epoch {epoch}: {n_steps} steps, train psnr {model._logged.get('train/psnr', float('nan')):.2f}, val psnr {table['psnr']:.3f} "
+                  f"iou {table['iou']:.3f} pq {table['pq']:.3f} grid {model.renderer.grid_dim.tolist()} S {model.renderer.n_samples} "
+                  f"({time.time() - t0:.0f} s)", flush=True)
+        ckpt = f"runs/{cfg.experiment}/checkpoints/epoch={int(cfg.max_epoch) - 1}-step={gstep}.ckpt"
+        torch.save({"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()}, "epoch": int(cfg.max_epoch) - 1, "global_step": gstep}, ckpt)
+        save_config(cfg, f"runs/{cfg.experiment}/config.yaml")
+        # ---- the reference's inference on its own checkpoint: test views, MeanShift clustering of the rendered instance features
+        import inference.render_panopli as RP
+        import dataset.preprocessing.preprocess_scannet as PS
+        import pathlib
+        H = W = SCHEDULE["image_dim"]
+        RP.visualize_panoptic_outputs = lambda *a, **k: torch.zeros(5, 3, H, W)
+        RP.make_grid = lambda stack, **k: torch.zeros(3, H, W)
+        cfg.resume = ckpt
+        cfg.subsample_frames = 1
+        np.random.seed(seed)
+        real_cuda, real_to = torch.Tensor.cuda, None
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        _read = PS.read_and_resize_labels
+        PS.read_and_resize_labels = lambda path, size: _read(path, size).astype(np.int32)      # (environment shim as in make_golden.g16: Pillow's uint16)
+        real_dev = torch.cuda.is_available
+        try:
+            with MG.quiet():
+                RP.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=SCHEDULE["bandwidth"])
+            out_dir = RP.output_dirname(cfg, "trajectory_blender", True, False, False)
+            with MG.quiet():
+                iou = PS.calculate_iou_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(scene_dir) / "semantic", (H, W))
+                pq, sq, rq = PS.calculate_panoptic_quality_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(out_dir, "pred_surrogateid"),
+                                                                       pathlib.Path(scene_dir) / "semantic", pathlib.Path(scene_dir) / "instance", (H, W))
+        finally:
+            torch.Tensor.cuda = real_cuda
+            PS.read_and_resize_labels = _read
+        res = dict(seed=seed, steps=gstep, seconds=time.time() - t0, val=table, scene=dict(iou=float(iou), pq=float(pq), sq=float(sq), rq=float(rq)),
+                   grid=[int(x) for x in model.renderer.grid_dim.tolist()], n_samples=int(model.renderer.n_samples),
+                   aabb=[[float(x) for x in r] for r in model.renderer.bbox_aabb.tolist()])
+        print(f"seed {seed}: scene mIoU {iou:.4f} PQ_scene {pq:.4f} SQ {sq:.4f} RQ {rq:.4f}", flush=True)
+        return res
+    finally:
+        os.chdir(cwd)
+
+
+def main():
+    seeds = [int(x) for x in sys.argv[1:]] or [0, 1, 2]
+    if not os.path.isdir(REF):
+        sys.exit(f"reference not found at {REF}")
+    threads = int(os.environ.get("G22_THREADS", "4"))
+    torch.set_num_threads(threads)
+    MG.install_stand_ins()
+    MG.install_quaternion()
+    torch.cuda.device_count = lambda: 1          # environment shim: dataset/base.py:88 divides by the device count (no GPU in this container)
+    sys.modules["pytorch_lightning"].LightningModule = FakeLightningModule
+    runs = [run_seed(s, threads) for s in seeds]
+    agg = {}
+    for key, get in (("val_psnr", lambda r: r["val"]["psnr"]), ("val_iou", lambda r: r["val"]["iou"]), ("val_pq", lambda r: r["val"]["pq"]),
+                     ("scene_iou", lambda r: r["scene"]["iou"]), ("pq_scene", lambda r: r["scene"]["pq"])):
+        v = np.array([get(r) for r in runs])
+        agg[key] = dict(mean=float(v.mean()), min=float(v.min()), max=float(v.max()), spread=float(v.max() - v.min()))
+    path = os.path.join(HERE, "g22_short_schedule.json")
+    json.dump(dict(schedule=SCHEDULE, unpinned_note="dist-reg term via the restated eff_distloss; Lightning's fit loop emulated (see the docstring)",
+                   runs=runs, summary=agg), open(path, "w"), indent=1)
+    print("wrote", path, json.dumps(agg))
+
+
+if __name__ == "__main__":
+    main()

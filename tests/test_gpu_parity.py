@@ -970,8 +970,9 @@ def test_g12_reference_training_steps_on_gpu(fixture):
     grids = "grid_heads" in fixture                # sixth fixture: both heads on their own VM grids (the allgrid overlay), plain contrastive loss
     P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf, sem_grid=grids, inst_grid=grids), res, 2.5, 0.45)
     if grids:
-        m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_, dim_feature_instance=E,
-                             splus_density_shift=float(g["shift"]), use_semantic_mlp=False, use_instance_mlp=False, slow_fast_mode=False, device=DEV)
+        m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_,
+                             dim_feature_instance=(2 * E if sf else E),
+                             splus_density_shift=float(g["shift"]), use_semantic_mlp=False, use_instance_mlp=False, slow_fast_mode=sf, device=DEV)
         missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
         assert not missing and not unexpected
     else:

@@ -1,0 +1,200 @@
+"""Round 6, GPU: the composed epoch boundary of the reference trainer (golden G21: on_train_epoch_start = dist-reg ramp -> alpha-mask shrink ->
+grid upsample -> weight_decay 0 -> optimizer / scheduler rebuild; scheduler step; on_load_checkpoint; validation_step) replayed through the
+functions the train CLI calls (HotPathTrainer.on_train_epoch_start / scheduler_step / checkpoint_dict / on_load_checkpoint / validation_step)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden, rel_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _g21_trainer(g, tag, **over):
+    import contrastive_lift_amd as cl
+    from oracle import params as op
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from test_gpu_parity import build_model
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, grid_scale=float(g["grid_scale"])), res, 2.5, 0.3)
+    m = build_model(cl, P, res, C_, E, float(g["shift"]))
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+    cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=2, max_instances=E,
+                         min_grid_dim=res[0], max_grid_dim=16, bbox_aabb_reset_epochs=[int(x) for x in g[f"{tag}.bbox_aabb_reset_epochs"]],
+                         grid_upscale_epochs=[int(x) for x in g[f"{tag}.grid_upscale_epochs"]], **over)
+    tr = HotPathTrainer(m, r, cfg, class_weights=T(g["class_weights"]), current_epoch=0)
+    return tr, m, r, P
+
+
+def _g21_step(tr, g, tag, e, st):
+    d = lambda a: (torch.from_numpy(a) if isinstance(a, np.ndarray) else a).to(DEV)
+    k = f"{tag}.e{e}.s{st}."
+    batch0 = dict(rays=d(g[k + "rays"]), rgbs=d(g[k + "rgbs"]), probabilities=d(g[k + "probs"]), confidences=d(g[k + "confs"]), mask=d(g[k + "mask"]))
+    tr.main_pass(batch0, jitter=d(g[k + "jitter"]), white_bg=[bool(x) for x in g[k + "white"]])
+    rel_close(tr.losses[0], g[k + "loss_rgb"], 1e-3, what=k + "loss_rgb")
+    if e >= tr.config.late_semantic_optimization:          # (before it the reference logs the constant 0 it initialises the term with, T:175)
+        rel_close(tr.losses[1], g[k + "loss_sem"], 1e-3, atol=1e-9, what=k + "loss_sem")
+    if e >= tr.config.instance_optimization_epoch:
+        tr.instance_pass([dict(rays=d(g[k + "irays"]), instances=d(g[k + "labels"]), confidences=d(g[k + "iconf"]))], jitter=d(g[k + "ijitter"]))
+        rel_close(tr.losses[3], g[k + "loss_clustering"], 1e-3, what=k + "loss_clustering")
+
+
+def _g21_params(m, g, tag, e, st, steps_done, names):
+    """Every parameter after a step: norm to 1e-3; elementwise within 10 % of an Adam step per step taken -- except a handful of elements whose
+    gradient sits at round-off level (|g| ~ 1e-5 of the tensor's largest, e.g. 2e-8 against 2e-3): Adam divides by sqrt(v), so a sign that
+    differs between two correct fp32 summation orders moves such a weight by up to 2 lr per step (measured on the GPU box with the oracle
+    beside the HIP path: oracle g = +2.3e-8, HIP g = -8.4e-8, 1 of 384 elements).  Those: at most 1 % of a tensor, within 2 lr per step.
+    ``steps_done`` counts the steps since the trainer was last put on the reference trajectory (_sync_from_oracle)."""
+    sd = m.state_dict()
+    for k in names:
+        flat = sd[k].detach().cpu().reshape(-1)
+        sub = flat if flat.numel() <= 4096 else flat[::int(g["stride"])]
+        lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
+        rel_close(flat.norm(), g[f"{tag}.e{e}.s{st}.pnorm.{k}"], 1e-3, atol=1e-6, what=f"{tag} e{e} s{st} |{k}|")
+        want = T(g[f"{tag}.e{e}.s{st}.psub.{k}"]).reshape(-1)
+        assert sub.shape == want.shape, (tag, e, st, k, tuple(sub.shape), tuple(want.shape))
+        diff = (sub - want).abs()
+        out = int((diff > 0.1 * lr * steps_done + 1e-7).sum())
+        assert out <= max(2, int(0.01 * diff.numel())), f"{tag} e{e} s{st} {k}: {out} of {diff.numel()} elements beyond 10 % of an Adam step per step"
+        assert float(diff.max()) <= 2.0 * lr * steps_done + 1e-7, f"{tag} e{e} s{st} {k}: max |diff| {float(diff.max()):.3e} (lr {lr})"
+
+
+def _oracle_trainer(g, P):
+    from oracle import render as orender
+    from oracle.train_step import CpuTrainer
+    res = tuple(int(x) for x in g["res"])
+    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
+    return CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=0, class_weights=T(g["class_weights"]), late_semantic_optimization=1,
+                      instance_optimization_epoch=2)
+
+
+def _oracle_step(ct, g, tag, e, st):
+    k = f"{tag}.e{e}.s{st}."
+    ct.main_pass(T(g[k + "rays"]), T(g[k + "rgbs"]), T(g[k + "probs"]), T(g[k + "confs"]), T(g[k + "jitter"]), [bool(x) for x in g[k + "white"]],
+                 mask=torch.from_numpy(g[k + "mask"]))
+    if e >= 2:
+        ct.instance_pass(T(g[k + "irays"]), torch.from_numpy(g[k + "labels"]), T(g[k + "iconf"]), T(g[k + "ijitter"]))
+
+
+def _sync_from_oracle(tr, m, ct):
+    """Put the HIP trainer on the oracle's state (parameters + Adam moments / step counts).  The oracle replays this very fixture to 5 % of
+    an Adam step over the WHOLE trajectory (tests/test_oracle_golden.py::test_g21_epoch_boundary: same ATen ops in the same order as the
+    reference); the HIP path sums in another order, and Adam's 1 / sqrt(v) turns round-off on the gradient entries that sit at noise level
+    into O(lr) moves that compound chaotically over ten steps (measured: 24 of 19 200 entries of one matrix after six steps, 40 % of the
+    appearance tables after ten -- on a fixture whose colour targets are random).  So every epoch starts from the reference trajectory,
+    and what is compared is what the item under test produces from there: the hook and the two steps that follow it."""
+    missing, unexpected = m.load_state_dict({k: v.detach().to(DEV) for k, v in ct.P.items()}, strict=True)
+    assert not missing and not unexpected
+    for opt, oopt, groups in zip((tr.opt_main, tr.opt_inst), (ct.opt_main, ct.opt_inst), tr.torch_param_groups()):
+        state, pgs, k = {}, [], 0
+        for lr, names in groups:
+            ids = []
+            for n in names:
+                st = oopt.state.get(ct.P[n])
+                if st:
+                    state[k] = {"step": st["step"], "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"]}
+                ids.append(k)
+                k += 1
+            pgs.append({"params": ids})
+        opt.load_torch_state_dict({"state": state, "param_groups": pgs}, groups)
+
+
+def _g21_hook_state(tr, r, g, tag, e):
+    assert [int(x) for x in g[f"{tag}.e{e}.grid"]] == [int(x) for x in r.grid_dim.tolist()], (tag, e, r.grid_dim.tolist())
+    assert int(g[f"{tag}.e{e}.n_samples"]) == int(r.n_samples)
+    rel_close(r.bbox_aabb, g[f"{tag}.e{e}.aabb"], 1e-6, what=f"{tag} e{e} aabb")
+    rel_close(r.step_size, g[f"{tag}.e{e}.step_size"], 1e-6, what=f"{tag} e{e} step size")
+    rel_close(r.units, g[f"{tag}.e{e}.units"], 1e-6, what=f"{tag} e{e} units")
+    rel_close(tr.current_lambda_dist_reg, g[f"{tag}.e{e}.lambda_dist"], 1e-6, atol=1e-12, what=f"{tag} e{e} dist-reg ramp")
+    assert float(g[f"{tag}.e{e}.weight_decay"]) == float(tr.config.weight_decay)
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_g21_epoch_boundary_on_gpu(tag, tmp_path):
+    """Scenario A: five epochs x two steps through HotPathTrainer.on_train_epoch_start with both the shrink and the upsample firing; after
+    every hook the renderer state (box, grid, S, step size, units), the ramp and weight_decay are the reference's, after every step the losses
+    (1e-3) and every parameter (10 % of an Adam step per step taken, norms 1e-3) -- which also shows the Adam moments restart at each rebuild.
+    In the middle of epoch 2 a checkpoint is written, restored into a FRESH trainer by the CLI's ``resume_from`` and the next step must land on
+    the uninterrupted run's parameters; the scheduler position and the torch-layout optimizer state travel with it.  At the end the
+    reference's validation_step metrics on a 16 x 16 view.
+    Scenario B: a shrink with no upsample in the same epoch -- like the reference the cropped tables stay fixed, the MLPs keep training."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    g = load_golden("g21_epoch_boundary")
+    tr, m, r, P = _g21_trainer(g, tag)
+    ct = _oracle_trainer(g, P)
+    names = list(P)
+    shrink_at, up_at = [int(x) for x in g[f"{tag}.bbox_aabb_reset_epochs"]], [int(x) for x in g[f"{tag}.grid_upscale_epochs"]]
+    for e in range(int(g[f"{tag}.epochs"])):
+        if e > 0:
+            _sync_from_oracle(tr, m, ct)           # (see there: every epoch starts on the reference trajectory)
+        tr.current_epoch = e
+        tr.on_train_epoch_start()
+        ct.on_train_epoch_start(e, shrink_at, up_at, min_grid_dim=int(g["res"][0]), max_grid_dim=16)
+        _g21_hook_state(tr, r, g, tag, e)
+        if tag == "B" and e == 1:
+            assert {"grids"} <= tr.opt_main.frozen and "net_app" not in tr.opt_main.frozen
+        for st in range(int(g[f"{tag}.steps"])):
+            _g21_step(tr, g, tag, e, st)
+            _oracle_step(ct, g, tag, e, st)
+            _g21_params(m, g, tag, e, st, st + 1, names)
+            if tag == "A" and (e, st) == (2, 0):
+                ck = str(tmp_path / "mid_epoch.ckpt")
+                tr.save_checkpoint(ck, global_step=5, epoch_complete=False)
+        tr.scheduler_step()
+        ct.end_of_epoch()
+    if tag == "B":
+        return
+    # ---- resume (T:461-470): fresh field at min_grid_dim, the CLI's resume_from, then step 1 of epoch 2
+    spec = importlib.util.spec_from_file_location("clift_train_cli_r6", os.path.join(REPO, "trainer", "train_panopli_tensorf.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    tr2, m2, r2, _ = _g21_trainer(g, "A")
+    tr2.config.weight_decay = 1e-8
+    first, gstep, mid = cli.resume_from(ck, tr2.config, tr2, m2, r2, torch.device(DEV))
+    assert (first, gstep, mid) == (2, 5, True)
+    assert [int(x) for x in r2.grid_dim.tolist()] == [int(x) for x in g["A.resume.grid_after_hook"]]
+    assert float(tr2.config.weight_decay) == float(g["A.resume.weight_decay"]) == 0.0
+    assert tr2.sched_steps == 0 and tr2.opt_main.t["grids"] == 1 and tr2.opt_inst.t["inst_fast"] == 1
+    tr2.current_epoch = first
+    tr2.on_train_epoch_start(maintenance=not mid)
+    _g21_step(tr2, g, "A", 2, 1)
+    _g21_params(m2, g, "A", 2, 1, 2, names)
+    # the checkpoint's optimizer state is torch.optim.Adam's own layout, group by group in the reference's order
+    ckd = torch.load(ck, map_location="cpu", weights_only=False)
+    og = ckd["optimizer_states"][0]["param_groups"]
+    assert [len(x["params"]) for x in og] == [3, 3, 3, 3, 1, 6, 10] and [x["lr"] for x in og[:4]] == [1e-2] * 4
+    assert ckd["optimizer_states"][0]["state"][6]["exp_avg"].shape == (1, 16, 13, 13) and ckd["lr_schedulers"][0]["last_epoch"] == 0
+    # ---- validation_step (T:356-400) on the final field of the uninterrupted run
+    vb = {k[len("A.val."):]: T(v) for k, v in g.items() if k.startswith("A.val.") and k.split(".")[-1] in
+          ("rays", "rgbs", "semantics", "instances", "mask", "rs_semantics", "rs_instances", "probabilities", "confidences")}
+    md = tr.validation_step(vb, {2, 3}, {0, 1}, [0])
+    want = dict(zip([str(x) for x in g["A.val.metric_names"]], [float(x) for x in g["A.val.metrics"]]))
+    assert list(md) == list(want)
+    from contrastive_lift_amd.inference import render_rays
+    rgb, sem, inst, _ = render_rays(m, r, vb["rays"].to(DEV), tr.config.chunk, False)
+    rel_close(rgb, g["A.val.out_rgb"], 2e-3, atol=2e-3, what="validation rgb")
+    # the eleven metrics: PSNR / losses to 1e-3 relative ...; the label metrics are step functions of per-pixel argmaxes: equal when the argmaxes are
+    same_labels = bool((sem.argmax(1).cpu() == T(g["A.val.out_sem_argmax"])).all()) and bool((inst.argmax(1).cpu() == T(g["A.val.out_inst_argmax"])).all())
+    for k in ("loss_rgb", "loss_sem", "psnr"):
+        rel_close(md[k], want[k], 2e-3, what=f"validation {k}")
+    assert abs(md["psnr"] - want["psnr"]) < 0.1
+    if same_labels:
+        for k in ("iou", "pq", "sq", "rq", "rs_iou", "rs_pq", "rs_sq", "rs_rq"):
+            rel_close(md[k], want[k], 1e-6, atol=1e-9, what=f"validation {k}")
+    else:          # a pixel whose two best classes tie to round-off: the label metrics may move by that pixel's share
+        flips = int((sem.argmax(1).cpu() != T(g["A.val.out_sem_argmax"])).sum()) + int((inst.argmax(1).cpu() != T(g["A.val.out_inst_argmax"])).sum())
+        assert flips <= 3, flips
+        for k in ("iou", "pq", "sq", "rq", "rs_iou", "rs_pq", "rs_sq", "rs_rq"):
+            assert abs(md[k] - want[k]) <= 0.1, (k, md[k], want[k])
+
+
+def test_grid_instance_head_with_slow_fast_twin():
+    """with the instance head on its own VM grid AND the slow-fast twin, the EMA pairs the two MLPs only (the basis matrix
+    is its own arena group, stepped by the instance optimizer at the net rate) -- two training_step()s of the reference trainer in that
+    arrangement (golden G12gs)."""
+    from test_gpu_parity import test_g12_reference_training_steps_on_gpu as replay
+    replay("g12gs_training_steps_grid_heads_slow_fast")

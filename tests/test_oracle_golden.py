@@ -233,7 +233,8 @@ def test_g11_metrics_vs_reference():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads",
+                                     "g12gs_training_steps_grid_heads_slow_fast"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -315,3 +316,77 @@ def test_g18_sce_loss_and_semantic_weights():
         rel_close(rows, g[f"{tag}.rows"], 1e-5, atol=1e-6, what=f"sce rows {tag}")
         gr = torch.autograd.grad((rows * T(g[f"{tag}.conf"])).mean(), pred)[0]
         rel_close(gr, g[f"{tag}.grad"], 1e-4, atol=1e-8, what=f"sce grad {tag}")
+
+
+def _g21_check_params(g, tag, e, st, named, rtol, lr_frac, steps_done):
+    for k, v in named.items():
+        flat = v.detach().cpu().reshape(-1)
+        sub = flat if flat.numel() <= 4096 else flat[::int(g["stride"])]
+        lr = 1e-2 if k.split(".")[0].endswith(("_plane", "_line")) else 5e-4
+        rel_close(flat.norm(), g[f"{tag}.e{e}.s{st}.pnorm.{k}"], rtol, atol=1e-6, what=f"{tag} e{e} s{st} |{k}|")
+        want = T(g[f"{tag}.e{e}.s{st}.psub.{k}"]).reshape(-1)
+        assert sub.shape == want.shape, (tag, e, st, k, sub.shape, want.shape)
+        diff = float((sub - want).abs().max())
+        assert diff <= lr_frac * lr * steps_done + 1e-7, f"{tag} e{e} s{st} {k}: max |diff| {diff:.3e} (lr {lr})"
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_g21_epoch_boundary(tag):
+    """The oracle's CpuTrainer + oracle/grid_ops.py replay the REFERENCE trainer's composed epoch boundary (golden G21: on_train_epoch_start =
+    ramp -> alpha-mask shrink -> upsample -> weight_decay 0 -> optimizer rebuild; scheduler step at the last batch): renderer state after
+    every hook exactly, losses to 1e-4, every parameter after every step to a fraction of an Adam step.  Scenario B: a shrink in an epoch with
+    no upsample leaves the optimizer on the replaced table tensors (the reference's behaviour: cropped tables frozen until the next rebuild)."""
+    from oracle.train_step import CpuTrainer
+    g = load_golden("g21_epoch_boundary")
+    res = tuple(int(x) for x in g["res"])
+    C, E = int(g["C"]), int(g["E"])
+    P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, grid_scale=float(g["grid_scale"])), res, 2.5, 0.3)
+    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
+    tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=0, class_weights=T(g["class_weights"]), late_semantic_optimization=1,
+                    instance_optimization_epoch=2)
+    shrink_at, up_at = [int(x) for x in g[f"{tag}.bbox_aabb_reset_epochs"]], [int(x) for x in g[f"{tag}.grid_upscale_epochs"]]
+    done = 0
+    for e in range(int(g[f"{tag}.epochs"])):
+        tr.on_train_epoch_start(e, shrink_at, up_at, min_grid_dim=res[0], max_grid_dim=16)
+        assert tuple(int(x) for x in g[f"{tag}.e{e}.grid"]) == tuple(tr.cfg.grid_dim) and int(g[f"{tag}.e{e}.n_samples"]) == tr.cfg.n_samples
+        rel_close(tr.cfg.aabb, g[f"{tag}.e{e}.aabb"], 1e-6, what=f"{tag} e{e} aabb")
+        rel_close(tr.cfg.step_size, g[f"{tag}.e{e}.step_size"], 1e-6, what=f"{tag} e{e} step size")
+        rel_close(tr.l_dist, g[f"{tag}.e{e}.lambda_dist"], 1e-6, atol=1e-12, what=f"{tag} e{e} dist-reg ramp")
+        assert float(g[f"{tag}.e{e}.weight_decay"]) == float(tr.weight_decay)
+        # the optimizer holds what the reference's holds: after the shrink-only hook of scenario B still the PREVIOUS tables
+        want_numel = sorted(int(x) for x in g[f"{tag}.e{e}.opt_numel"])
+        held = sum(p.numel() for grp in tr.opt_main.param_groups + tr.opt_inst.param_groups for p in grp["params"])
+        assert held == sum(want_numel), (tag, e, held, sum(want_numel))
+        for st in range(int(g[f"{tag}.steps"])):
+            k = f"{tag}.e{e}.s{st}."
+            o = tr.main_pass(T(g[k + "rays"]), T(g[k + "rgbs"]), T(g[k + "probs"]), T(g[k + "confs"]), T(g[k + "jitter"]),
+                             [bool(x) for x in g[k + "white"]], mask=torch.from_numpy(g[k + "mask"]))
+            rel_close(o["loss_rgb"], g[k + "loss_rgb"], 1e-4, what=k + "loss_rgb")
+            rel_close(o["loss_sem"], g[k + "loss_sem"], 1e-4, atol=1e-9, what=k + "loss_sem")
+            if e >= 2:
+                oi = tr.instance_pass(T(g[k + "irays"]), torch.from_numpy(g[k + "labels"]), T(g[k + "iconf"]), T(g[k + "ijitter"]))
+                rel_close(oi["loss"], g[k + "loss_clustering"], 1e-4, what=k + "loss_clustering")
+            done += 1
+            _g21_check_params(g, tag, e, st, tr.P, 1e-4, 0.05, done)
+        tr.end_of_epoch()
+    if tag == "B":          # the cropped tables did not move during the shrink-only epoch; the MLPs did
+        a, b = g["B.e1.s0.psub.density_plane.0"], g["B.e1.s1.psub.density_plane.0"]
+        assert float(np.abs(a - b).max()) == 0.0
+        assert float(np.abs(g["B.e1.s0.psub.render_appearance_mlp.mlp.0.weight"] - g["B.e1.s1.psub.render_appearance_mlp.mlp.0.weight"]).max()) > 0
+
+
+def test_g21_learning_rate_restart_unpinned():
+    """Scenario C of G21 (UNPINNED: it rests on the stub of Lightning's ``strategy.setup_optimizers``, which replaces the scheduler objects):
+    decay_step [1, 3] with a grid upsample at epoch 2 -- the MultiStepLR milestones count epochs since the last rebuild.  The oracle's
+    schedulers and the product's ``scheduler_step`` arithmetic give the same table."""
+    g = load_golden("g21_epoch_boundary")
+    lr = g["unpinned_C.opt_lr"]
+    decay, ups = [int(x) for x in g["unpinned_C.decay_step"]], [int(x) for x in g["unpinned_C.grid_upscale_epochs"]]
+    steps = 0
+    for e in range(lr.shape[0]):
+        if e in ups:
+            steps = 0
+        scale = 0.5 ** sum(1 for m in decay if steps >= m)
+        rel_close(lr[e, 0], 1e-2 * scale, 1e-9, what=f"epoch {e} grid lr")
+        rel_close(lr[e, -1], 5e-4 * scale, 1e-9, what=f"epoch {e} net lr")
+        steps += 1

@@ -24,7 +24,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import contrastive_lift_amd as cl                                        # noqa: E402
 from contrastive_lift_amd.config import load_config, save_config          # noqa: E402
 from contrastive_lift_amd.data import get_scene                            # noqa: E402
-from contrastive_lift_amd.inference import psnr                           # noqa: E402
 from contrastive_lift_amd.trainer import HotPathTrainer                   # noqa: E402
 
 
@@ -38,31 +37,18 @@ def experiment_name(config):
 
 
 def resume_from(path, cfg, tr, model, renderer, dev):
-    """Continue a run from one of its checkpoints (reference: trainer.fit(ckpt_path=config.resume) + on_load_checkpoint, T:461-470).
-    Restores the grids at the checkpoint's resolution (upsample to ``renderer.grid_dim`` first, like RP:91-98 / T:463-466), every
-    weight, the renderer buffers, both Adam states (moments + per-range step counts), epoch and global step.  Returns
-    (first epoch to run, global step, whether that epoch was already in progress, epoch of the last optimizer rebuild)."""
+    """Continue a run from one of its checkpoints -- or from a checkpoint the REFERENCE wrote (same layout, torch-layout optimizer
+    states) -- reference: trainer.fit(ckpt_path=config.resume) + on_load_checkpoint, T:461-470.  ``HotPathTrainer.on_load_checkpoint``
+    restores tables at the checkpoint's resolution, every weight, the renderer buffers, both Adam states and the scheduler position.
+    Returns (first epoch to run, global step, whether that epoch was already in progress)."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    sd = ckpt["state_dict"]
-    grid = [int(x) for x in sd["renderer.grid_dim"].tolist()]
-    model.upsample_volume_grid(grid)                                      # shapes first; the values are overwritten below
-    missing, unexpected = model.load_state_dict({k[len("model."):]: v.to(dev) for k, v in sd.items() if k.startswith("model.")}, strict=True)
-    renderer.bbox_aabb.data = sd["renderer.bbox_aabb"].to(dev)
-    renderer.update_step_size(grid)
-    epoch = int(ckpt["epoch"])
-    extra = ckpt.get("clift", {})
-    complete = bool(extra.get("epoch_complete", True))
-    first = epoch + 1 if complete else epoch
-    ups = [int(e) for e in cfg.grid_upscale_epochs]
-    done_ups = [e for e in ups if e < first or (e == first and not complete)]
-    if done_ups:
-        cfg.weight_decay = 0                                               # T:454,467
     tr.config = cfg
-    tr.setup_optimizers()                                                  # buffers in the (possibly resized) arena layout
-    if "optimizer_states" in ckpt and len(ckpt["optimizer_states"]) == 2 and "m" in ckpt["optimizer_states"][0]:
-        if ckpt["optimizer_states"][0]["m"].numel() == tr.opt_main.m.numel():
-            tr.opt_main.load_state_dict(ckpt["optimizer_states"][0])
-            tr.opt_inst.load_state_dict(ckpt["optimizer_states"][1])
+    extra = tr.on_load_checkpoint(ckpt)
+    epoch = int(ckpt["epoch"])
+    # a Lightning checkpoint carries no "epoch finished" flag of its own: ModelCheckpoint(every_n_train_steps) writes in the middle of an
+    # epoch, so a checkpoint without this repo's record is taken as mid-epoch (the epoch's hook already ran before it was written)
+    complete = bool(extra.get("epoch_complete", False))
+    first = epoch + 1 if complete else epoch
     # Only rank 0 writes checkpoints, so the RNG record (CPU / device generators, pixel-batch generator) is ITS streams: restoring it on
     # every rank would make all ranks draw the same pixel batches and jitter from here on (the all-reduced gradient would be that of one
     # batch).  The other ranks re-seed from (seed, rank, global step): decorrelated from rank 0 and from each other, reproducible.
@@ -78,7 +64,31 @@ def resume_from(path, cfg, tr, model, renderer, dev):
         g = getattr(tr, "pixel_generator", None)
         if g is not None:
             g.manual_seed(mix)
-    return first, int(ckpt.get("global_step", 0)), (not complete), int(extra.get("last_setup_epoch", max(done_ups) if done_ups else 0))
+    return first, int(ckpt.get("global_step", 0)), (not complete)
+
+
+VAL_KEYS = ("loss_rgb", "loss_sem", "psnr", "iou", "pq", "sq", "rq", "rs_iou", "rs_pq", "rs_sq", "rs_rq")
+
+
+def validation_epoch(tr, val, limit=None):
+    """validation_step over the validation views + the table of on_validation_epoch_end (T:356-408): the mean of every metric over the
+    views, printed with tabulate like the reference.  Returns {metric: mean}."""
+    rows = []
+    idxs = list(val.val_indices)
+    if limit:
+        idxs = idxs[:max(1, int(round(len(idxs) * float(limit))))] if float(limit) <= 1 else idxs[:int(limit)]
+    for i in idxs:
+        batch = dict(rays=val.rays_for(i), **val.load_targets(i), **val.load_rs_targets(i))
+        rows.append(tr.validation_step(batch, val.things_filtered, val.stuff_filtered, val.faulty_classes))
+    if not rows:
+        return {}
+    means = {k: float(np.mean([r[k] for r in rows])) for k in VAL_KEYS}
+    try:
+        from tabulate import tabulate
+        print(tabulate([VAL_KEYS, tuple(means[k] for k in VAL_KEYS)], headers="firstrow", tablefmt="fancy_grid"), flush=True)
+    except ImportError:
+        print(" ".join(f"{k} {means[k]:.4f}" for k in VAL_KEYS), flush=True)
+    return means
 
 
 def main(argv):
@@ -141,11 +151,9 @@ def main(argv):
     # of an epoch by the world size -- the LR / EMA / epoch schedules of the configs are tuned for that
     per_rank = int(cfg.batch_size)
     steps_per_epoch = int(cfg.get("steps_per_epoch") or max(1, scene.tables["rays"].shape[0] // (int(cfg.batch_size) * world)))
-    voxels = torch.round(torch.exp(torch.linspace(np.log(cfg.min_grid_dim ** 3), np.log(cfg.max_grid_dim ** 3),
-                                                  len(cfg.grid_upscale_epochs) + 1))).long().tolist()[1:]           # T:451
-    gstep, start_epoch, resumed_mid_epoch, last_setup_epoch = 0, 0, False, 0
+    gstep, start_epoch, resumed_mid_epoch = 0, 0, False
     if cfg.get("resume"):
-        start_epoch, gstep, resumed_mid_epoch, last_setup_epoch = resume_from(str(cfg.resume), cfg, tr, model, renderer, dev)
+        start_epoch, gstep, resumed_mid_epoch = resume_from(str(cfg.resume), cfg, tr, model, renderer, dev)
         if rank == 0:
             print(f"resumed {cfg.resume}: continuing at epoch {start_epoch} (global step {gstep}), grid {renderer.grid_dim.tolist()}", flush=True)
     # the interpreter's first full garbage collection walks everything the imports and the set-up created (35 - 60 ms, i.e. ten training steps);
@@ -153,27 +161,13 @@ def main(argv):
     import gc
     gc.collect()
     gc.freeze()
+    val_every = max(1, int(cfg.get("val_check_interval") or 1))              # trainer/__init__.py:104-105: every n-th epoch (fractions: every epoch)
+    last_val = {}
     for epoch in range(start_epoch, int(cfg.max_epoch)):
         tr.current_epoch = epoch
-        tr.on_train_epoch_start()
-        # a checkpoint written in the middle of an epoch already holds that epoch's shrunk / upsampled grids
-        maintenance = not (resumed_mid_epoch and epoch == start_epoch)
-        if maintenance and epoch in list(cfg.bbox_aabb_reset_epochs):
-            renderer.update_bbox_aabb_and_shrink(model)
-            tr.setup_optimizers()                                          # the arena was re-packed: moments follow the new layout
-        if maintenance and epoch in list(cfg.grid_upscale_epochs):
-            target = renderer.get_target_resolution(voxels[list(cfg.grid_upscale_epochs).index(epoch)])
-            cfg.weight_decay = 0
-            model.upsample_volume_grid(target)
-            renderer.update_step_size(target)
-            tr.setup_optimizers()
-            last_setup_epoch = epoch                                       # T:456 setup_optimizers: fresh MultiStepLR schedulers as well
-        # MultiStepLR(milestones=decay_step) is stepped once per epoch and is RE-CREATED by setup_optimizers at every grid upscale, so
-        # its milestones count epochs since the last rebuild (with the template's decay_step [9, 10] and the last upscale at epoch 4 a
-        # 10-epoch run never decays)
-        lr_scale = float(cfg.decay_gamma) ** sum(1 for m in cfg.decay_step if epoch - last_setup_epoch >= m)
-        tr.opt_main.lr_scale = tr.opt_inst.lr_scale = lr_scale
-        tr.last_setup_epoch = last_setup_epoch
+        # T:446-457 (golden G21): ramp, shrink, upsample + weight_decay 0 + optimizer / scheduler rebuild.  A checkpoint written in the
+        # middle of an epoch already holds that epoch's shrunk / upsampled tables: only the ramp then
+        tr.on_train_epoch_start(maintenance=not (resumed_mid_epoch and epoch == start_epoch))
         order = torch.randperm(max(1, len(inst_scene.instance_images)), generator=torch.Generator().manual_seed(seed * 31 + epoch)).tolist()   # DataLoader(shuffle=True), T:436
         for it in range(steps_per_epoch):
             batch = {0: scene.pixel_batch(per_rank, gen)}
@@ -193,15 +187,13 @@ def main(argv):
                       f"loss_sem {l[1]:.4f} tv {l[2]:.5f} clustering {l[3]:.4f}"
                       + (f" segment {float(tr.loss_segment[0]):.4f}" if 2 in batch else "")
                       + (f" overflow_steps {tr.overflow_steps}" if tr.nosync else "")
-                      + f" S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
+                      + f" lr x{tr.opt_main.lr_scale:g} S={renderer.n_samples} grid={renderer.grid_dim.tolist()}", flush=True)
+        tr.scheduler_step()                                                # T:226-228: both MultiStepLR schedulers, at the epoch's last batch
         if rank == 0:
             tr.save_checkpoint(str(run_dir / "checkpoints" / f"epoch={epoch}-step={gstep}.ckpt"), gstep, epoch_complete=True)
-            from contrastive_lift_amd.inference import render_rays
-            ps = []
-            for i in val.val_indices[:4]:
-                rgb, *_ = render_rays(model, renderer, val.rays_for(i), 8192, False)
-                ps.append(float(psnr(rgb, val.load_targets(i)["rgbs"].to(dev))))
-            print(f"epoch {epoch} val psnr {np.mean(ps):.2f}", flush=True)
+            if (epoch + 1) % val_every == 0:                               # the reference's validation table (T:356-408)
+                last_val = validation_epoch(tr, val, cfg.get("val_check_percent"))
+    main.last_validation = last_val
     if world > 1:
         dist.destroy_process_group()
     return str(run_dir)
