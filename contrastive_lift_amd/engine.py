@@ -252,7 +252,11 @@ class Branches:
     side stream (via _lib.set_launch_stream); ALL allocations stay on torch's current stream, and every temporary of a
     branch is kept alive in ``self.keep`` until ``join`` so that no block is recycled into another in-flight branch."""
 
-    def __init__(self, enabled=True):
+    def __init__(self, enabled=True, model=None):
+        # a head on its own VM grid (engine.grid_head_fwd / _bwd) issues torch ops -- zero fills, add_ -- which live on torch's CURRENT stream, not
+        # on the branch's side stream: such a field keeps every branch on the main stream (ADVICE r5)
+        if model is not None and (getattr(model, "semantic_plane", None) is not None or getattr(model, "instance_plane", None) is not None):
+            enabled = False
         self.enabled = enabled and MULTI_STREAM
         self.keep = []
         self.used = []
@@ -878,7 +882,7 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
                 ctx.sem_acts = xyz_mlp_fwd(sem_layers, xa, M, sem_s, Ccls, keep_first="sem" in grad_heads, out_act=sm)
             ctx.sem_s = sem_s
 
-        br = Branches()
+        br = Branches(model=model)
         if want_rgb:
             br.run(0, app_chain)
         if want_sem:
@@ -982,7 +986,7 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
                  ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
                  ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
                  ptr(g_w), ptr(g_op), st)
-        br = Branches()
+        br = Branches(model=model)
         if density_grad:
             model.xcd_workspace_for("density")
         if d_rgb is not None:
@@ -1176,7 +1180,7 @@ def feature_forward(model, renderer, rays, jitter, head, grad_heads=("app", "sem
         else:
             E = model.render_instance_mlp.output_channels
             ctx.inst_s = torch.empty((M, D), dtype=torch.float32, device=dev)
-            br = Branches()
+            br = Branches(model=model)
 
             def fast_chain(keep):
                 ctx.inst_fast_acts = xyz_mlp_fwd(_lin_params(None, "render_instance_mlp.mlp", views), xa, M, ctx.inst_s, D, 0,

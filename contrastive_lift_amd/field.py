@@ -102,6 +102,9 @@ class TensorVMSplit(nn.Module):
         if use_distilled_features_semantic or use_distilled_features_instance or use_proj or use_feature_reg:
             raise NotImplementedError("clift: distilled-feature grids / projection head / feature regulariser are off "
                                       "in every shipped contrastive-lift config and are not built")
+        for flag, width, what in ((use_semantic_mlp, dim_mlp_semantics, "dim_mlp_semantics"), (use_instance_mlp, dim_mlp_instance, "dim_mlp_instance")):
+            if not flag and width % 4 != 0:      # the hidden activations of a grid head's MLP are the next layer's GEMM operand: rows must be 16-byte multiples
+                raise NotImplementedError(f"clift: {what} of a head on its own VM grid must be a multiple of 4 (got {width})")
         if pe_sem != 0 or pe_ins != 0:
             raise NotImplementedError("clift: pe_sem / pe_ins > 0 not built (0 in every shipped config)")
         if len(set(num_density_comps)) != 1 or len(set(num_appearance_comps)) != 1:

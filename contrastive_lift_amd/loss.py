@@ -60,7 +60,7 @@ def slow_fast_loss(instance_features, labels_gt, confidences, return_grad=False)
 def create_virtual_gt_with_linear_assignment(labels_gt, predicted_scores):
     """T:332-344: match the (sorted, first E) 2-D instance ids of an image to the E output slots: cost[id][slot] = -(sum of the slot's softmax
     probability over the id's rays / (count + 1e-4)), Hungarian method on the HOST like the reference (scipy; an L x E matrix, L <= E), every
-    ray of a matched id gets that slot as its class, every other ray class 0.  The per-id sums are one index_add on the device; what crosses
+    ray of a matched id gets that slot as its class, every other ray class 0.  The per-id sums are one one-hot product on the device; what crosses
     the bus is the L x E cost matrix."""
     import numpy as np
     import scipy.optimize
@@ -69,8 +69,11 @@ def create_virtual_gt_with_linear_assignment(labels_gt, predicted_scores):
     prob = torch.softmax(predicted_scores.detach().to(torch.float32), dim=-1)
     slot_of = torch.searchsorted(ids, labels_gt.contiguous())
     slot_of = torch.where((slot_of < ids.numel()) & (ids[slot_of.clamp_max(ids.numel() - 1)] == labels_gt), slot_of, torch.full_like(slot_of, ids.numel()))
-    sums = torch.zeros((ids.numel() + 1, E), dtype=torch.float32, device=prob.device).index_add_(0, slot_of, prob)
-    cnt = torch.zeros(ids.numel() + 1, dtype=torch.float32, device=prob.device).index_add_(0, slot_of, torch.ones_like(slot_of, dtype=torch.float32))
+    # per-id sums as a float64 one-hot product: a fixed summation order (an index_add_ is a race of atomics on the device, and a near-tie in
+    # the cost matrix could flip the assignment from run to run).  This mode synchronises with the host (the .cpu() below, like the
+    # reference's own scipy call): ``nosync`` steps do not apply to it.
+    member = torch.zeros((ids.numel() + 1, slot_of.numel()), dtype=torch.float64, device=prob.device).scatter_(0, slot_of.reshape(1, -1), 1.0)
+    sums, cnt = (member @ prob.to(torch.float64)).to(torch.float32), member.sum(1).to(torch.float32)
     cost = (-(sums[:-1] / (cnt[:-1, None] + 1e-4))).cpu().numpy().astype(np.float64)
     rows, cols = scipy.optimize.linear_sum_assignment(np.nan_to_num(cost))
     table = torch.zeros(ids.numel() + 1, dtype=labels_gt.dtype)

@@ -636,9 +636,16 @@ class HotPathTrainer:
         if self.nosync:
             engine.reset_rows_limit(self.device)
         self._pass_fold("inst_fast")
-        if c.instance_loss_mode == "linear_assignment" and self.world == 1 and not contributed:
-            return           # (reference: the loss is a constant, every .grad stays None and torch's Adam skips every parameter, step counts included;
-                             #  in a data-parallel run another rank may have contributed: the exchange and the step then happen on all ranks)
+        if c.instance_loss_mode == "linear_assignment":
+            # reference: when the loss is the constant 0 every .grad stays None and torch's Adam skips every parameter, step counts and weight
+            # decay included.  In a data-parallel run that holds only if NO rank contributed: one flag is summed over the ranks (this mode
+            # synchronises with the host anyway, loss.create_virtual_gt_with_linear_assignment)
+            if self.world > 1:
+                flag = torch.tensor([1.0 if contributed else 0.0], device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+                contributed = bool(flag.item() > 0)
+            if not contributed:
+                return
         self._allreduce(self.inst_range)
         self.opt_inst.step()
 
