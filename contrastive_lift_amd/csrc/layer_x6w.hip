@@ -7,9 +7,14 @@
 // Shape: 64 row ranges x 4 quadrant workgroups (128 n x 128 k each; the four of a range have block ids 8 apart = one XCD, so dY / X come
 // from HBM once), EIGHT waves = 4 n-tiles x 2 pairs of k-tiles, two per SIMD.  BOTH operands are streamed, and the MFMA contraction index is
 // the ROW index m, so a fragment is 8 consecutive rows of one column.  The split does the transposition: rows travel by LDS-DMA into fp32
-// staging (wave v owns rows 4 v .. 4 v + 3 of a 32-row tile, both operands, 4 KB), each lane reads COLUMN runs of its wave's 4 rows
-// (4 x ds_read_b32, lanes along the columns: conflict-free), splits the 4 values (22 VALU) and writes three 8-byte pieces into TRANSPOSED
-// bf16 plane images [operand][plane][column][32 m], column pitch 80 bytes (fragment reads and the writes conflict-free: 80 = 5 x 16).
+// staging (wave v owns rows 8 (v >> 1) .. + 7 of a 32-row tile x columns 64 (v & 1) .. + 63 of the quadrant, both operands, 4 KB), each lane
+// reads COLUMN runs of 4 rows (4 x ds_read_b32, lanes along the columns: conflict-free), splits the 4 values (22 VALU) and writes three 8-byte
+// pieces into TRANSPOSED bf16 plane images [operand][plane][column][32 m], column pitch 80 bytes.  Fragment reads (ds_read_b128: banks mod 64,
+// 16-lane groups whose columns cover every residue mod 16; 80 = 5 x 16) are conflict-free at that pitch.  The WRITES (ds_write_b64: banks
+// mod 32, groups of 16 CONTIGUOUS lanes) are not when every lane of a wave writes the same rows: columns 8 apart are 640 bytes = 5 x 128 apart,
+// the same banks -- 2-way, 24 % of the kernel's LDS cycles in round 5 (profiles/r05_pmc_tables.txt) and no 16-byte-multiple pitch removes it.
+// So lanes l and l + 8 write DIFFERENT rows: in run u a lane takes the row quad ((lane >> 3) & 1) ^ u of its wave's eight rows, i.e. 8 bytes
+// further into its column than its neighbour eight lanes away -- the 16 lanes of a group then cover the 32 banks exactly once (round 6).
 // A wave multiplies the dY fragments of its 32 n against the X fragments of its two k-tiles: 24 MFMAs per tile in two groups of 12 that
 // alternate between two accumulators.  Rows past the end of a range are zeroed in the split (a clamped copy would be counted twice).
 // Memory instructions per tile and wave: X rows x 2 (group 0), dY rows x 2 (group 1) -- every wait is vmcnt(2).
@@ -78,61 +83,69 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     const float* __restrict__ X = g.B + 128 * qk;       // X columns of its k-half
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
 
-    // ---- rows by LDS-DMA: piece j (0, 1) of operand o = rows 2 j, 2 j + 1 of this wave's four (rows 4 wave .. 4 wave + 3 of the tile), 512 B each
-    auto dma = [&](int t, int o, int j) {
-        if (GENX && o == 1) {                               // positions of rows 2 j, 2 j + 1: lanes 0..7 = (row, component), the other lanes repeat them
-            const int prow = min(rbeg + t * XW_ROWS + 4 * wave + 2 * j + ((lane >> 2) & 1), rend - 1);
-            __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)prow * 4 + (lane & 3), (lds_ptr_t)(lds + XW_RAW + wave * 4096 + 2048 + j * 1024), 4, 0, 0);
-            return;
-        }
-        const int rr = 2 * j + lh;
-        const int row = min(rbeg + t * XW_ROWS + 4 * wave + rr, rend - 1);       // (rows past the range: any valid row; the split zeroes them)
-        const float* src = (o ? X + (size_t)row * g.ldb : Y + (size_t)row * g.lda) + 4 * li;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + o * 2048 + j * 1024), 16, 0, 0);
+    // ---- rows by LDS-DMA.  The wave owns rows 8 ro .. 8 ro + 7 of the tile x columns 64 ch .. 64 ch + 63 of the quadrant; piece j (0, 1) of operand o =
+    // rows 4 j .. 4 j + 3 of those eight, 256 B each: lane = (row lane >> 4, 16-byte chunk lane & 15), staged as [8 rows][256 B] per operand
+    const int ro = wave >> 1, ch = wave & 1, lq = (lane >> 3) & 1;
+    // Buffer loads (raw, stride 0) with the descriptor cut to THIS range's rows: a row at or past the end of the range is out of bounds and
+    // arrives as zeros -- no clamping, no masking in the split (a zero dY row contributes nothing to gW or gb, whatever the X row holds; GENX:
+    // the generated X of a zero position is finite) -- and the per-lane part of the address is one 32-bit offset computed once: a DMA costs
+    // no vector instruction besides itself (round 6: the loop was bound by its vector issue slots, 189 per wave and tile for 24 MFMAs).
+    const int nrows = __builtin_amdgcn_readfirstlane(rend - rbeg);
+    auto uniform_rsrc = [](const float* base, unsigned bytes) {        // descriptor inputs made PROVABLY wave-uniform (no waterfall loop around the loads)
+        const unsigned long long a = (unsigned long long)(uintptr_t)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), 0,
+                                                 (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
     };
-    // ---- a column run: the 4 rows of this wave at column lane + 64 u of operand o
+    const __amdgpu_buffer_rsrc_t rs_y = uniform_rsrc(Y + (size_t)rbeg * g.lda, (unsigned)((((size_t)(nrows - 1)) * g.lda + 128) * 4));
+    const __amdgpu_buffer_rsrc_t rs_x = GENX ? uniform_rsrc(gx.x4 + (size_t)rbeg * 4, (unsigned)nrows * 16u)
+                                             : uniform_rsrc(X + (size_t)rbeg * g.ldb, (unsigned)((((size_t)(nrows - 1)) * g.ldb + 128) * 4));
+    const int vo_y = ((lane >> 4) * g.lda + 64 * ch + 4 * (lane & 15)) * 4;             // byte offsets of this lane's 16 bytes within a piece
+    const int vo_x = GENX ? (lane & 3) * 16 : ((lane >> 4) * g.ldb + 64 * ch + 4 * (lane & 15)) * 4;
+    const int so_y = g.lda * 16, so_x = GENX ? 64 : g.ldb * 16;                         // bytes per 4 rows
+    auto dma = [&](int t, int o, int j) {
+        const int piece = __builtin_amdgcn_readfirstlane(t * (XW_ROWS / 4) + 2 * ro + j);     // 4-row piece of the range (scalar)
+        if (o) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + 2048 + j * 1024), 16, vo_x, piece * so_x, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + j * 1024), 16, vo_y, piece * so_y, 0, 0);
+    };
+    // ---- a column run: 4 rows (quad lq ^ u of the wave's eight) at column 64 ch + lane of operand o
     float v[4];
-    f32x4 pz[4];                                        // GENX: the positions of the wave's four rows
-    float gw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // GENX: W0 row and bias of this lane's X columns lane + 64 u (of this quadrant's k-half)
+    f32x4 pz[4];                                        // GENX: the positions of the quad's four rows
+    float gw[4] = {0.f, 0.f, 0.f, 0.f};                 // GENX: W0 row and bias of this lane's X column (of this quadrant's k-half)
     if (GENX) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = 128 * qk + lane + 64 * u;
-            const float* wr0 = gx.W0 + (size_t)col * gx.ldw0;
-            gw[u][0] = wr0[0]; gw[u][1] = wr0[1]; gw[u][2] = wr0[2]; gw[u][3] = gx.b0[col];
-        }
+        const int col = 128 * qk + 64 * ch + lane;
+        const float* wr0 = gx.W0 + (size_t)col * gx.ldw0;
+        gw[0] = wr0[0]; gw[1] = wr0[1]; gw[2] = wr0[2]; gw[3] = gx.b0[col];
     }
     auto run_read = [&](int o, int u) {
-        if (GENX && o == 1) {
-            const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + 2048);
+        const int q = lq ^ u;
+        if (GENX && o == 1) {                               // quad 1 reads the copy held by lanes 4..7 of its piece (+ 64 B: other banks than quad 0's)
+            const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + 2048 + q * (1024 + 64));
             asm volatile("ds_read_b128 %0, %1" : "=v"(pz[0]) : "v"(a) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(pz[1]) : "v"(a) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(pz[2]) : "v"(a) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:1040" : "=v"(pz[3]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(pz[2]) : "v"(a) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(pz[3]) : "v"(a) : "memory");
             return;
         }
-        const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + o * 2048 + (lane + 64 * u) * 4);
+        const unsigned a = lds0 + (unsigned)(XW_RAW + wave * 4096 + o * 2048 + q * 1024 + lane * 4);
         asm volatile("ds_read_b32 %0, %1" : "=v"(v[0]) : "v"(a) : "memory");
-        asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v[1]) : "v"(a) : "memory");
-        asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(v[2]) : "v"(a) : "memory");
-        asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(v[3]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(v[1]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v[2]) : "v"(a) : "memory");
+        asm volatile("ds_read_b32 %0, %1 offset:768" : "=v"(v[3]) : "v"(a) : "memory");
     };
     auto run_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory"); };
     auto gen_wait = [&](int u) {                        // GENX, operand X: wait for the positions, then this lane's column of the four rows
+        (void)u;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]) : : "memory");
 #pragma unroll
         for (int e = 0; e < 4; ++e)     // same order as k_linear_k3_fwd / k_layer_x6<GEN>
-            v[e] = fmaxf(fmaf(gw[u][2], pz[e][2], fmaf(gw[u][1], pz[e][1], fmaf(gw[u][0], pz[e][0], gw[u][3]))), 0.f);
+            v[e] = fmaxf(fmaf(gw[2], pz[e][2], fmaf(gw[1], pz[e][1], fmaf(gw[0], pz[e][0], gw[3]))), 0.f);
     };
-    float bs0 = 0.f, bs1 = 0.f;                         // bias gradient of columns lane, lane + 64 (this wave's rows)
+    float bs0 = 0.f;                                    // bias gradient of column 64 ch + lane (this wave's rows)
     unsigned sh[2], sm[2], sl[2];
-    auto run_mask = [&](int valid, int o, int u) {      // rows at or past `valid` contribute nothing (a clamped copy would be counted twice)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (4 * wave + e < valid) ? v[e] : 0.f;
-        if (o == 0) {
-            const float s = (v[0] + v[1]) + (v[2] + v[3]);
-            if (u == 0) bs0 += s; else bs1 += s;
-        }
+    auto run_mask = [&](int valid, int o, int u) {      // (rows past the end of the range arrive as zeros: nothing to mask)
+        (void)valid; (void)u;
+        if (o == 0) bs0 += (v[0] + v[1]) + (v[2] + v[3]);
     };
     auto run_split = [&](int q) {                       // pair q (rows 2 q, 2 q + 1 of the run)
         const float a = v[2 * q], c = v[2 * q + 1];
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto run_write = [&](unsigned stage, int o, int u) {
-        const unsigned a = lds0 + stage + (unsigned)(o * 3 * XW_PLANE + (lane + 64 * u) * XW_PITCH + wave * 8);
+        const unsigned a = lds0 + stage + (unsigned)(o * 3 * XW_PLANE + (64 * ch + lane) * XW_PITCH + (2 * ro + (lq ^ u)) * 8);
         const u32x2 dh = {sh[0], sh[1]}, dm = {sm[0], sm[1]}, dl = {sl[0], sl[1]};
         asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(dh) : "memory");
         asm volatile("ds_write_b64 %0, %1 offset:10240" : : "v"(a), "v"(dm) : "memory");
@@ -260,10 +273,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             const int n = 128 * qn + 32 * wn + 8 * (r >> 2) + 4 * lh + (r & 3), k = 128 * qk + 64 * kp + 32 * x + li;
             unsafeAtomicAdd(g.C + (size_t)n * g.ldc + k, acc[x][r]);
         }
-    if (g.colsum && qk == 0) {                          // both k-quadrants saw the same dY: one of them adds the bias gradient
-        unsafeAtomicAdd(g.colsum + 128 * qn + lane, bs0);
-        unsafeAtomicAdd(g.colsum + 128 * qn + 64 + lane, bs1);
-    }
+    if (g.colsum && qk == 0)                            // both k-quadrants saw the same dY: one of them adds the bias gradient
+        unsafeAtomicAdd(g.colsum + 128 * qn + 64 * ch + lane, bs0);
 }
 
 // row ranges = a quarter of the CUs the persistent launches may use (clift_set_cu_reserve leaves CUs to a running all-reduce); the four

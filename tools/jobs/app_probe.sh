@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing probes of the appearance front end: variants of libclift.so whose k_app_front_fwd leaves phases out (AF_ABL bit mask in csrc/heads_io.hip;
 # results garbage by construction) into tools/_scratch/abl/, timed by tools/app_probe.py.
-#   bash tools/app_probe.sh build   (here: hipcc cross-compiles)      bash tools/app_probe.sh run   (on the GPU box)
+#   bash tools/jobs/app_probe.sh build   (here: hipcc cross-compiles)      bash tools/jobs/app_probe.sh run   (on the GPU box)
 cd "$(dirname "$0")/.." || exit 1
 C=contrastive_lift_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-function"

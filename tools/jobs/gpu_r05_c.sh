@@ -13,7 +13,7 @@ timeout 1500 python -m pytest "tests/test_gpu_parity.py" tests/test_gpu_round3.p
 echo "pytest around rc=$?"; tail -8 $out/pytest_around.log | cut -c1-300
 timeout 800 python tools/last2_soak.py 90 exact_infer,exact_infer,exact_keep,x6_infer,x6_keep > $out/last2_soak.log 2>&1
 echo "last2 soak rc=$?"; grep -E "RESULT|launch" $out/last2_soak.log | cut -c1-400
-bash tools/gpu_ab_flags.sh $(basename $out)/ab 2 "" "APP_X6=False" > /dev/null 2>&1
+bash tools/jobs/gpu_ab_flags.sh $(basename $out)/ab 2 "" "APP_X6=False" > /dev/null 2>&1
 cat $out/ab/summary.txt
 prof() {  # name, command...
   name=$1; shift
@@ -26,8 +26,8 @@ prof fp32x6 python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-extras --s
 prof bf16 python "$GRAFT_REPO_ROOT/bench.py" --dtype bf16 --no-cpu-baseline --no-extras --steps 20 --warmup 3
 prof rays1024 python "$GRAFT_REPO_ROOT/bench.py" --rays 1024 --inst-rays 1024 --no-cpu-baseline --no-extras --steps 20 --warmup 3
 prof inference python "$GRAFT_REPO_ROOT/tools/inference_probe.py" fp32x6 32768
-bash tools/gpu_timeline.sh $(basename $out)/tl1024 --rays 1024 --inst-rays 1024 > /dev/null 2>&1; tail -1 $out/tl1024/timeline.txt
-bash tools/gpu_timeline.sh $(basename $out)/tl1024_nosync --rays 1024 --inst-rays 1024 --nosync > /dev/null 2>&1; tail -1 $out/tl1024_nosync/timeline.txt
+bash tools/jobs/gpu_timeline.sh $(basename $out)/tl1024 --rays 1024 --inst-rays 1024 > /dev/null 2>&1; tail -1 $out/tl1024/timeline.txt
+bash tools/jobs/gpu_timeline.sh $(basename $out)/tl1024_nosync --rays 1024 --inst-rays 1024 --nosync > /dev/null 2>&1; tail -1 $out/tl1024_nosync/timeline.txt
 for n in fp32x6 bf16 rays1024; do python -c "
 import json; d=json.loads(open('$out/$n.out').read().strip().splitlines()[-1]); print('$n ms_per_step', d['ms_per_step'], 'median', d.get('step_ms_median'), 'frac', d['roofline']['frac'])"; done
 tail -2 $out/inference.out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing probes of the eight-wave fp32x6 layer kernel: builds variants of libclift.so whose k_layer_x6 leaves work out (X6_ABL bit mask in
 # csrc/layer_x6.hip; results garbage by construction) into tools/_scratch/, for tools/x6_ablation.py to time on the GPU box.
-#   bash tools/x6_ablation.sh build      (here: hipcc cross-compiles)        bash tools/x6_ablation.sh run   (on the GPU box)
+#   bash tools/jobs/x6_ablation.sh build      (here: hipcc cross-compiles)        bash tools/jobs/x6_ablation.sh run   (on the GPU box)
 cd "$(dirname "$0")/.." || exit 1
 C=contrastive_lift_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=off -Wall -Wno-unused-function -fno-slp-vectorize"

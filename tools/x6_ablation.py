@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times k_layer_x6 (plain forward, output-fused without hidden store, first-two-layers backward) of one ablated library variant
-(tools/x6_ablation.sh).   python tools/x6_ablation.py <X6_ABL bits>"""
+(tools/jobs/x6_ablation.sh).   python tools/x6_ablation.py <X6_ABL bits>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 v, sg = int(sys.argv[1]), int(sys.argv[2])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fixed cost of the persistent fp32x6 launches: time against rows, time(M) = fixed + M x per_row (least squares over M = 4096 t, t tiles per
-row range), per kernel form -- and, with a variant library (tools/x6_ablation.sh, X6_ABL bits 64 .. 1024), what the fixed part is made of.
+row range), per kernel form -- and, with a variant library (tools/jobs/x6_ablation.sh, X6_ABL bits 64 .. 1024), what the fixed part is made of.
     python tools/x6_fixed_probe.py [X6_ABL bits of the variant library = 0: the shipped one]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
