@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclift.so")
+LIB_PATH = os.environ.get("CLIFT_LIB_PATH") or os.path.join(_HERE, "libclift.so")      # (the override: timing probes of variant builds, tools/jobs)
 CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 18
 

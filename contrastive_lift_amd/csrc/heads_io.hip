@@ -234,6 +234,9 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd(MarchP m, VmP t, VmG gr
 //   phase 2: the serial walk: the table values and dF rows of AU_U steps are loaded together (one memory round trip per AU_U steps,
 //            nothing but the six gradient sums carried from step to step), then per step <= 6 atomics, 6 restarts, ~12 FMAs.
 // Per-sample terms: the bilinear sum runs in slot order instead of corner order (fp32 round-off apart from the walk above).
+#ifndef AU_ABL
+#define AU_ABL 0          // timing probes (tools/jobs/app_probe.sh): 1 = no plane atomics, 2 = no table loads, 4 = three blocks of eight waves per CU
+#endif
 constexpr int AU_SEG = 32;
 constexpr int AU_U = 4;                // steps whose loads are issued together
 struct alignas(16) WalkRec {
@@ -248,8 +251,14 @@ struct alignas(16) WalkRec {
 template <bool LDS_LINES>
 __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M, const float* __restrict__ dF, const float* __restrict__ xa,
                                                               int seg_len) {
+    // Round 6: a block walks ONE plane (blockIdx.x % 3): its LDS line slab holds that plane's line only -- a third of the three-line slab
+    // (24.5 instead of 73.7 KB at 128^3 x 48) -- so two or three blocks fit a CU where one did; the walk is a chain of dependent
+    // LDS / memory round trips per wave, i.e. its throughput is the number of resident waves (16 -> 24 per CU: profiles/r06_scatter_probes.txt).
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
-    const int nl = LDS_LINES ? line_lds_floats(t.res, t.comps) : 0;
+    const int i = blockIdx.x % 3;
+    int a, b, v;
+    vm_axes(i, a, b, v);
+    const int nl = LDS_LINES ? t.res[v] * t.comps : 0;
     if (LDS_LINES) scatter_zero_lines(lds_lines, nl);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     WalkRec* const recs = reinterpret_cast<WalkRec*>(lds_lines + (nl + 3) / 4 * 4) + wave * AU_SEG;
@@ -258,14 +267,13 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
     const int C = t.comps, G = 3 * C;
     const int c = lane < C ? lane : C - 1;           // lanes >= comps idle through phase 2 (they repeat the last channel's loads, never write)
     const bool live = lane < C;
-    M = limit_rows(M);
-    const long items = 3L * ((M + seg_len - 1) / seg_len);
-    for (long it = (long)blockIdx.x * nwaves + wave; it < items; it += (long)gridDim.x * nwaves) {
-        const int seg = (int)(it / 3), i = (int)(it - 3L * seg);
+    M = __builtin_amdgcn_readfirstlane(limit_rows(M));
+    const int nseg = (M + seg_len - 1) / seg_len, pblocks = gridDim.x / 3;      // (the grid is a multiple of 3 blocks)
+    for (int seg = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / 3) * nwaves + wave); seg < nseg; seg += pblocks * nwaves) {
         int a, b, v;
         vm_axes(i, a, b, v);
         const int W = t.res[a];
-        const int s0 = seg * seg_len, n = min(seg_len, M - s0);
+        const int s0 = seg * seg_len, n = __builtin_amdgcn_readfirstlane(min(seg_len, M - s0));
         // ---------------- phase 1
         {
             const int p = lane;
@@ -315,76 +323,98 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase 2
         // wave-uniform bases + 32-bit byte offsets (record offset + 4 c): one add per access, no 64-bit multiplies
-        const float* pp = t.plane[i];
-        const float* lp = t.line[i];
-        float* gp = gr.plane[i] + xoff;
-        float* ll = lds_lines + line_lds_offset(t, i);
-        float* gl = gr.line[i] + xoff;
-        const float* dcol = dF + (size_t)s0 * G + i * C + c;
+        auto sptr = [](auto* q) {                        // a pointer the compiler can see is wave-uniform (a table picked by a run-time plane index is not, to it)
+            const unsigned long long a = (unsigned long long)(uintptr_t)q;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            return reinterpret_cast<decltype(q)>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+        };
+        const float* pp = sptr(t.plane[i]);
+        const float* lp = sptr(t.line[i]);
+        float* gp = sptr(gr.plane[i] + xoff);
+        float* ll = lds_lines;                           // (this block's slab is line i)
+        float* gl = sptr(gr.line[i] + xoff);
+        const float* dcol0 = sptr(dF + (size_t)s0 * G + i * C);       // (+ 4 c bytes per lane)
         const int c4 = 4 * c;
         auto at = [](auto* base, int off) {            // (pointer arithmetic, not integer casts: the address space must stay visible)
             typedef typename std::conditional<std::is_const<typename std::remove_pointer<decltype(base)>::type>::value, const char, char>::type B;
             return reinterpret_cast<decltype(base)>(reinterpret_cast<B*>(base) + (unsigned)off);
         };
-        auto plane_out = [&](int key, float val) {
-            if (!live) return;
-            if (xcd) __hip_atomic_fetch_add(at(gp, key + c4), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(at(gp, key + c4), val);
+        // Round 6: the record of a step is the same for every lane of the wave (lane = channel), so its keys and control bits are taken into
+        // SCALAR registers (v_readfirstlane): the "write out" / "restart" tests are scalar branches, a table access is <scalar base + key> +
+        // <4 c in a VGPR> -- no vector instruction per address, per test or per clamp (the walk was bound by its vector issue slots:
+        // profiles/r05_pmc_tables.txt).  An out-of-range tap has weight 0 and a clamped (valid) load address: its term is an exact + 0.
+        auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+        // (hand-issued: the compiler folds <base + 4 c> into a vector pair and adds the scalar key with a vector instruction instead)
+        auto ld_s = [](const float* sbase, int voff) {   // global_load_dword <4 c>, <scalar base + key>
+            float v;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+            return v;
+        };
+        auto plane_out = [&](int key, float val) {       // key: scalar.  (XCD-private copies or the table itself: the same instruction either way)
+            if (!live || (AU_ABL & 1)) return;
+            asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(c4), "v"(val), "s"(sptr(at(gp, key))) : "memory");
         };
         auto line_out = [&](int key, float val) {
             if (!live) return;
-            if (LDS_LINES) atomicAdd(at(ll, key + c4), val);
-            else if (xcd) __hip_atomic_fetch_add(at(gl, key + c4), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else unsafeAtomicAdd(at(gl, key + c4), val);
+            if (LDS_LINES) atomicAdd(at(at(ll, key), c4), val);
+            else asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(c4), "v"(val), "s"(sptr(at(gl, key))) : "memory");
         };
+        (void)xcd;
         int ck[4] = {-1, -1, -1, -1}, lk[2] = {-1, -1};
         float ca[4] = {0.f, 0.f, 0.f, 0.f}, lacc[2] = {0.f, 0.f};
         for (int p0 = 0; p0 < n; p0 += AU_U) {
-            int4 kq[AU_U];
-            int2 kzz[AU_U];
+            int ks[AU_U][4], kz[AU_U][2];
             float tv[AU_U][4], tl[AU_U][2], td[AU_U];
 #pragma unroll
             for (int u = 0; u < AU_U; ++u) {
                 const int4* src = reinterpret_cast<const int4*>(recs + min(p0 + u, n - 1));
-                kq[u] = src[0];
-                kzz[u] = *reinterpret_cast<const int2*>(src + 2);
+                const int4 k4 = src[0];
+                const int2 k2 = *reinterpret_cast<const int2*>(src + 2);
+                ks[u][0] = uni(k4.x); ks[u][1] = uni(k4.y); ks[u][2] = uni(k4.z); ks[u][3] = uni(k4.w);
+                kz[u][0] = uni(k2.x); kz[u][1] = uni(k2.y);
+            }
+#pragma unroll
+            for (int u = 0; u < AU_U; ++u) {             // seven loads per step, in this order (the waits below count them)
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) tv[u][sl] = ld_s(at(pp, (AU_ABL & 2) ? 0 : max(ks[u][sl], 0)), c4);
+                tl[u][0] = ld_s(at(lp, max(kz[u][0], 0)), c4); tl[u][1] = ld_s(at(lp, max(kz[u][1], 0)), c4);
+                td[u] = ld_s(dcol0 + (size_t)min(p0 + u, n - 1) * G, c4);
             }
 #pragma unroll
             for (int u = 0; u < AU_U; ++u) {
-                tv[u][0] = *at(pp, max(kq[u].x, 0) + c4); tv[u][1] = *at(pp, max(kq[u].y, 0) + c4);
-                tv[u][2] = *at(pp, max(kq[u].z, 0) + c4); tv[u][3] = *at(pp, max(kq[u].w, 0) + c4);
-                tl[u][0] = *at(lp, max(kzz[u].x, 0) + c4); tl[u][1] = *at(lp, max(kzz[u].y, 0) + c4);
-                td[u] = dcol[(size_t)min(p0 + u, n - 1) * G];
-            }
+                // this step's seven values have landed when at most the 7 (AU_U - 1 - u) younger loads are outstanding (atomics issued since
+                // then are younger still: they only make the wait stricter)
+                if (u == 0) asm volatile("s_waitcnt vmcnt(21)" : "+v"(tv[0][0]), "+v"(tv[0][1]), "+v"(tv[0][2]), "+v"(tv[0][3]), "+v"(tl[0][0]), "+v"(tl[0][1]), "+v"(td[0]) : : "memory");
+                if (u == 1) asm volatile("s_waitcnt vmcnt(14)" : "+v"(tv[1][0]), "+v"(tv[1][1]), "+v"(tv[1][2]), "+v"(tv[1][3]), "+v"(tl[1][0]), "+v"(tl[1][1]), "+v"(td[1]) : : "memory");
+                if (u == 2) asm volatile("s_waitcnt vmcnt(7)" : "+v"(tv[2][0]), "+v"(tv[2][1]), "+v"(tv[2][2]), "+v"(tv[2][3]), "+v"(tl[2][0]), "+v"(tl[2][1]), "+v"(td[2]) : : "memory");
+                if (u == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[3][0]), "+v"(tv[3][1]), "+v"(tv[3][2]), "+v"(tv[3][3]), "+v"(tl[3][0]), "+v"(tl[3][1]), "+v"(td[3]) : : "memory");
+                if (p0 + u < n) {                                              // uniform
+                    const int4* src = reinterpret_cast<const int4*>(recs + (p0 + u));
+                    const int4 r1 = src[1], r2 = src[2];
+                    const int ctrl = uni(src[3].x);
+                    const float ws[4] = {__int_as_float(r1.x), __int_as_float(r1.y), __int_as_float(r1.z), __int_as_float(r1.w)};
+                    const float wz[2] = {__int_as_float(r2.z), __int_as_float(r2.w)};
 #pragma unroll
-            for (int u = 0; u < AU_U; ++u) {
-                if (p0 + u >= n) break;                                        // uniform
-                const int4* src = reinterpret_cast<const int4*>(recs + (p0 + u));
-                const int4 r1 = src[1], r2 = src[2];
-                const int ctrl = src[3].x;
-                const int ks[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, kz[2] = {kzz[u].x, kzz[u].y};
-                const float ws[4] = {__int_as_float(r1.x), __int_as_float(r1.y), __int_as_float(r1.z), __int_as_float(r1.w)};
-                const float wz[2] = {__int_as_float(r2.z), __int_as_float(r2.w)};
+                    for (int sl = 0; sl < 4; ++sl) {
+                        if (ctrl & (1 << sl)) plane_out(ck[sl], ca[sl]);
+                        if (ctrl & (1 << (8 + sl))) ca[sl] = 0.f;
+                        ck[sl] = ks[u][sl];
+                    }
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    if (ctrl & (1 << sl)) plane_out(ck[sl], ca[sl]);
-                    if (ctrl & (1 << (8 + sl))) ca[sl] = 0.f;
-                    ck[sl] = ks[sl];
+                    for (int sl = 0; sl < 2; ++sl) {
+                        if (ctrl & (1 << (4 + sl))) line_out(lk[sl], lacc[sl]);
+                        if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
+                        lk[sl] = kz[u][sl];
+                    }
+                    float P = 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], tv[u][sl], P);
+                    const float L = fmaf(wz[1], tl[u][1], wz[0] * tl[u][0]);
+                    const float gP = td[u] * L, gL = td[u] * P;
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
+                    lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
                 }
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    if (ctrl & (1 << (4 + sl))) line_out(lk[sl], lacc[sl]);
-                    if (ctrl & (1 << (12 + sl))) lacc[sl] = 0.f;
-                    lk[sl] = kz[sl];
-                }
-                float P = 0.f;
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) P = fmaf(ws[sl], ks[sl] >= 0 ? tv[u][sl] : 0.f, P);
-                const float L = fmaf(wz[1], kz[1] >= 0 ? tl[u][1] : 0.f, wz[0] * (kz[0] >= 0 ? tl[u][0] : 0.f));
-                const float gP = td[u] * L, gL = td[u] * P;
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) ca[sl] = fmaf(ws[sl], gP, ca[sl]);
-                lacc[0] = fmaf(wz[0], gL, lacc[0]); lacc[1] = fmaf(wz[1], gL, lacc[1]);
             }
         }
 #pragma unroll
@@ -395,7 +425,14 @@ __global__ __launch_bounds__(1024) void k_app_gather_bwd_u(VmP t, VmG gr, int M,
             if (ck[q] >= 0) plane_out(ck[q], ca[q]);
         __builtin_amdgcn_wave_barrier();               // the next item's phase 1 overwrites the records
     }
-    if (LDS_LINES) scatter_flush_lines(t, gr, lds_lines, xoff);
+    if (LDS_LINES) {                                     // flush this block's line slab
+        __syncthreads();
+        float* dst = gr.line[i] + xoff;
+        for (int e = threadIdx.x; e < nl; e += blockDim.x) {
+            const float val = lds_lines[e];
+            if (val != 0.f) unsafeAtomicAdd(dst + e, val);
+        }
+    }
 }
 
 extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* h_app, const clift_vm_grad_t* h_grad,
@@ -410,15 +447,20 @@ extern "C" int clift_app_gather_bwd(const clift_march_t* h_m, const clift_vm_t* 
     if (xa != nullptr && h_app->comps <= 64) {          // (otherwise: the lane-per-(plane, channel) walk, the only form without xa / for comps > 64)
         // one wave per (segment, plane): the line slab + a 2 KB record slot per wave; as many waves per CU as that allows
         const int rec_bytes = AU_SEG * (int)sizeof(WalkRec);
-        const int slab = (lds_bytes + 15) / 16 * 16;
-        int wpb = 16, bpc = 1;                                         // waves per block, blocks per CU
+        int rmax = h_app->res[0] > h_app->res[1] ? h_app->res[0] : h_app->res[1];
+        rmax = rmax > h_app->res[2] ? rmax : h_app->res[2];
+        const int slab = (rmax * h_app->comps * 4 + 15) / 16 * 16;      // ONE line per block (the longest: every block gets the same allocation)
+        int wpb = (AU_ABL & 32) ? 9 : (AU_ABL & 64) ? 7 : 8, bpc = (AU_ABL & 64) ? 4 : 3;   // waves per block, blocks per CU: 24 resident waves
         bool lds_l = true;
         const int useg = AU_SEG;
-        if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 16; bpc = 2; }
-        else if (2 * (slab + 8 * rec_bytes) <= 160 * 1024 - 1024) { wpb = 8; bpc = 2; }
-        const long items = 3L * cdiv(M, useg);
-        const int want = cdiv(items, wpb);
-        const int blocks = want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc;
+        if (3 * (slab + 8 * rec_bytes) > 160 * 1024 - 1536) { wpb = 12; bpc = 2; }
+        if (bpc == 2 && 2 * (slab + 12 * rec_bytes) > 160 * 1024 - 1024) { wpb = 16; bpc = 1; }
+        if (bpc == 1 && slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 8; bpc = 3; }
+        const int nseg = cdiv(M, useg);
+        int blocks = 3 * cdiv(nseg, wpb);
+        const int cap = (clift_persistent_cus() * bpc) / 3 * 3;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 3) blocks = 3;
         const int dyn = (lds_l ? slab : 0) + wpb * rec_bytes;
         if (lds_l) {
             if (dyn > 48 * 1024)

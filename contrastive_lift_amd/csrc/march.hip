@@ -412,7 +412,10 @@ __global__ __launch_bounds__(1024) void k_density_bwd(MarchP m, VmP t, VmG gr, c
 //            <= 6 atomics, 6 restarts, ~12 FMAs.
 // Per-sample terms: the bilinear sum runs in slot order instead of corner order and (with sigma) the derivative is 1 - exp(-softplus)
 // instead of the sigmoid: fp32 round-off apart from the walk above.
-constexpr int DU_SEG = 32;
+#ifndef DU_ABL
+#define DU_ABL 0          // timing probes: 1 = 16-sample chunks, 12 waves x 2 blocks per CU; 2 = no plane atomics; 4 = 16-sample chunks, 8 waves x 3 blocks
+#endif
+constexpr int DU_SEG = (DU_ABL & 5) ? 16 : 32;
 constexpr int DU_U = 4;                // steps whose loads are issued together
 struct alignas(16) DensRec {
     int ks[4];          // texels by parity slot, as BYTE offsets (y * W + x) * comps * 4 into the channels-last table; -1 = tap out of range
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_density_bwd_u(MarchP m, VmP t, VmG gr,
             return reinterpret_cast<decltype(base)>(reinterpret_cast<B*>(base) + (unsigned)off);
         };
         auto plane_out = [&](int key, float val) {
-            if (!live) return;
+            if (!live || (DU_ABL & 2)) return;
             if (xcd) __hip_atomic_fetch_add(at(gp, key), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else unsafeAtomicAdd(at(gp, key), val);
         };
@@ -614,6 +617,8 @@ extern "C" int clift_density_bwd(const clift_march_t* h_m, const clift_vm_t* h_d
         int wpb = 16, bpc = 1;
         bool lds_l = true;
         if (slab + 16 * rec_bytes > 160 * 1024 - 512) { lds_l = false; wpb = 8; bpc = 3; }
+        else if (DU_ABL & 1) { wpb = 12; bpc = 2; }
+        else if (DU_ABL & 4) { wpb = 8; bpc = 3; }
         const long items = (long)N * cdiv(h_m->n_samples, DU_SEG);
         const long want = cdiv(items, wpb);
         const int blocks = (int)(want < clift_persistent_cus() * bpc ? want : clift_persistent_cus() * bpc);
