@@ -32,8 +32,9 @@ sys.path.insert(0, HERE)
 import make_golden as MG                       # noqa: E402  (puts REPO and the reference on sys.path)
 
 REF = MG.REF
-SCHEDULE = dict(experiment="contrastive_lift_MOS", image_dim=64, min_grid_dim=32, max_grid_dim=64, max_epoch=6, batch_size=512, chunk=2048,
-                max_depth=3, max_rays_instances=512, decay_step=[4, 5], n_frames=40, scene_seed=0, bandwidth=0.15)
+SCHEDULE = dict(experiment="contrastive_lift_MOS", image_dim=64, min_grid_dim=32, max_grid_dim=64, max_epoch=6, batch_size=256, chunk=2048,
+                max_depth=3, max_rays_instances=512, decay_step=[4, 5], n_frames=40, scene_seed=0, bandwidth=0.15,
+                infer_dim=240)      # the test views are rendered at 240 x 240: the reference's clustering draws 50 000 thing pixels without replacement (RP:213-214)
 
 
 class FakeLightningModule(torch.nn.Module):
@@ -58,13 +59,56 @@ class FakeLightningModule(torch.nn.Module):
         self._logged[name] = float(value)
 
 
-def run_seed(seed, threads):
+def _infer(seed, cfg, ckpt, scene_dir, table, gstep, t0, final):
+    """The reference's inference on its own checkpoint: test views, MeanShift clustering of the rendered instance features, scene evaluators."""
+    if True:
+        import inference.render_panopli as RP
+        import dataset.preprocessing.preprocess_scannet as PS
+        import pathlib
+        H = W = SCHEDULE["infer_dim"]
+        cfg.image_dim = [H, W]
+        class _TorchOnCpu:                          # environment shim: render_panopli.py:48 hard-codes torch.device("cuda:0"); no GPU in this container
+            def __getattr__(self, n):
+                return getattr(torch, n)
+
+            def device(self, *a, **k):
+                return torch.device("cpu")
+        RP.torch = _TorchOnCpu()
+        RP.visualize_panoptic_outputs = lambda *a, **k: torch.zeros(5, 3, H, W)
+        RP.make_grid = lambda stack, **k: torch.zeros(3, H, W)
+        cfg.resume = ckpt
+        cfg.subsample_frames = 1
+        np.random.seed(seed)
+        real_cuda, real_to = torch.Tensor.cuda, None
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        _read = PS.read_and_resize_labels
+        PS.read_and_resize_labels = lambda path, size: _read(path, size).astype(np.int32)      # (environment shim as in make_golden.g16: Pillow's uint16)
+        real_dev = torch.cuda.is_available
+        try:
+            with (contextlib.nullcontext() if os.environ.get("G22_VERBOSE") else MG.quiet()):
+                RP.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=SCHEDULE["bandwidth"])
+            out_dir = RP.output_dirname(cfg, "trajectory_blender", True, False, False)
+            with MG.quiet():
+                iou = PS.calculate_iou_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(scene_dir) / "semantic", (H, W))
+                pq, sq, rq = PS.calculate_panoptic_quality_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(out_dir, "pred_surrogateid"),
+                                                                       pathlib.Path(scene_dir) / "semantic", pathlib.Path(scene_dir) / "instance", (H, W))
+        finally:
+            torch.Tensor.cuda = real_cuda
+            PS.read_and_resize_labels = _read
+        res = dict(seed=seed, steps=gstep, seconds=time.time() - t0, val=table, scene=dict(iou=float(iou), pq=float(pq), sq=float(sq), rq=float(rq)), **final)
+        print(f"seed {seed}: scene mIoU {iou:.4f} PQ_scene {pq:.4f} SQ {sq:.4f} RQ {rq:.4f}", flush=True)
+        return res
+
+
+def run_seed(seed, threads, reuse=None):
+    """``reuse``: a work directory of an earlier call whose training finished (train.json + checkpoint present): only the inference stage runs."""
     import yaml
     from contrastive_lift_amd.config import load_config, save_config
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
-    tmp = tempfile.mkdtemp(prefix=f"g22_s{seed}_")
-    os.symlink(os.path.join(REF, "resources"), os.path.join(tmp, "resources"))       # the datasets read resources/*.csv relative to the cwd
+    tmp = reuse or tempfile.mkdtemp(prefix=f"g22_s{seed}_")
+    if not reuse:
+        os.symlink(os.path.join(REF, "resources"), os.path.join(tmp, "resources"))   # the datasets read resources/*.csv relative to the cwd
     scene_dir = gen.make_scene(os.path.join(tmp, "data", "synth_scene"), n_frames=SCHEDULE["n_frames"], size=SCHEDULE["image_dim"], seed=SCHEDULE["scene_seed"])
     cwd = os.getcwd()
     os.chdir(tmp)
@@ -77,6 +121,13 @@ def run_seed(seed, threads):
         cfg.image_dim = [cfg.image_dim, cfg.image_dim]
         cfg.experiment = f"g22_seed{seed}"
         os.makedirs(f"runs/{cfg.experiment}/checkpoints", exist_ok=True)
+        done = os.path.join(tmp, "train.json")
+        if os.path.exists(done):
+            st = json.load(open(done))
+            table, gstep, ckpt, t0 = st["table"], st["gstep"], st["ckpt"], time.time() - st["seconds"]
+            state = torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"]
+            final = dict(grid=[int(x) for x in state["renderer.grid_dim"].tolist()], aabb=[[float(x) for x in r] for r in state["renderer.bbox_aabb"].tolist()])
+            return _infer(seed, cfg, ckpt, scene_dir, table, gstep, t0, final)
         torch.manual_seed(seed)                    # seed_everything(config.seed), trainer/__init__.py:73
         np.random.seed(seed)
         __import__("random").seed(seed)
@@ -125,37 +176,9 @@ def run_seed(seed, threads):
         ckpt = f"runs/{cfg.experiment}/checkpoints/epoch={int(cfg.max_epoch) - 1}-step={gstep}.ckpt"
         torch.save({"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()}, "epoch": int(cfg.max_epoch) - 1, "global_step": gstep}, ckpt)
         save_config(cfg, f"runs/{cfg.experiment}/config.yaml")
-        # ---- the reference's inference on its own checkpoint: test views, MeanShift clustering of the rendered instance features
-        import inference.render_panopli as RP
-        import dataset.preprocessing.preprocess_scannet as PS
-        import pathlib
-        H = W = SCHEDULE["image_dim"]
-        RP.visualize_panoptic_outputs = lambda *a, **k: torch.zeros(5, 3, H, W)
-        RP.make_grid = lambda stack, **k: torch.zeros(3, H, W)
-        cfg.resume = ckpt
-        cfg.subsample_frames = 1
-        np.random.seed(seed)
-        real_cuda, real_to = torch.Tensor.cuda, None
-        torch.Tensor.cuda = lambda self, *a, **k: self
-        _read = PS.read_and_resize_labels
-        PS.read_and_resize_labels = lambda path, size: _read(path, size).astype(np.int32)      # (environment shim as in make_golden.g16: Pillow's uint16)
-        real_dev = torch.cuda.is_available
-        try:
-            with MG.quiet():
-                RP.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=SCHEDULE["bandwidth"])
-            out_dir = RP.output_dirname(cfg, "trajectory_blender", True, False, False)
-            with MG.quiet():
-                iou = PS.calculate_iou_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(scene_dir) / "semantic", (H, W))
-                pq, sq, rq = PS.calculate_panoptic_quality_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(out_dir, "pred_surrogateid"),
-                                                                       pathlib.Path(scene_dir) / "semantic", pathlib.Path(scene_dir) / "instance", (H, W))
-        finally:
-            torch.Tensor.cuda = real_cuda
-            PS.read_and_resize_labels = _read
-        res = dict(seed=seed, steps=gstep, seconds=time.time() - t0, val=table, scene=dict(iou=float(iou), pq=float(pq), sq=float(sq), rq=float(rq)),
-                   grid=[int(x) for x in model.renderer.grid_dim.tolist()], n_samples=int(model.renderer.n_samples),
-                   aabb=[[float(x) for x in r] for r in model.renderer.bbox_aabb.tolist()])
-        print(f"seed {seed}: scene mIoU {iou:.4f} PQ_scene {pq:.4f} SQ {sq:.4f} RQ {rq:.4f}", flush=True)
-        return res
+        json.dump(dict(table=table, gstep=gstep, ckpt=os.path.abspath(ckpt), seconds=time.time() - t0), open(done, "w"))
+        final = dict(grid=[int(x) for x in model.renderer.grid_dim.tolist()], aabb=[[float(x) for x in r] for r in model.renderer.bbox_aabb.tolist()])
+        return _infer(seed, cfg, ckpt, scene_dir, table, gstep, t0, final)
     finally:
         os.chdir(cwd)
 
@@ -170,7 +193,18 @@ def main():
     MG.install_quaternion()
     torch.cuda.device_count = lambda: 1          # environment shim: dataset/base.py:88 divides by the device count (no GPU in this container)
     sys.modules["pytorch_lightning"].LightningModule = FakeLightningModule
-    runs = [run_seed(s, threads) for s in seeds]
+    sys.modules["hdbscan"].HDBSCAN = MG._Inert
+    reuse = dict(kv.split("=") for kv in os.environ.get("G22_REUSE", "").split(",") if kv)      # seed=workdir: skip the training of that seed
+    work = os.environ.get("G22_WORK", "/tmp/g22_work")
+    os.makedirs(work, exist_ok=True)
+    runs = []
+    for s_ in seeds:                                  # one result file per seed: an interrupted generation resumes where it stopped
+        f = os.path.join(work, f"seed{s_}.json")
+        if not os.path.exists(f):
+            json.dump(run_seed(s_, threads, reuse.get(str(s_))), open(f, "w"))
+        runs.append(json.load(open(f)))
+    if os.environ.get("G22_NO_AGGREGATE"):
+        return
     agg = {}
     for key, get in (("val_psnr", lambda r: r["val"]["psnr"]), ("val_iou", lambda r: r["val"]["iou"]), ("val_pq", lambda r: r["val"]["pq"]),
                      ("scene_iou", lambda r: r["scene"]["iou"]), ("pq_scene", lambda r: r["scene"]["pq"])):

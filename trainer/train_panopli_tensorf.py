@@ -169,8 +169,9 @@ def main(argv):
         # middle of an epoch already holds that epoch's shrunk / upsampled tables: only the ramp then
         tr.on_train_epoch_start(maintenance=not (resumed_mid_epoch and epoch == start_epoch))
         order = torch.randperm(max(1, len(inst_scene.instance_images)), generator=torch.Generator().manual_seed(seed * 31 + epoch)).tolist()   # DataLoader(shuffle=True), T:436
+        pixels = scene.epoch_order(seed, epoch, rank, world)               # DataLoader(train_set, shuffle=True, drop_last=True), T:434: every pixel once per epoch
         for it in range(steps_per_epoch):
-            batch = {0: scene.pixel_batch(per_rank, gen)}
+            batch = {0: scene.pixel_batch_at(pixels, it, per_rank)}
             if epoch >= cfg.instance_optimization_epoch and inst_scene.instance_images:
                 batch[1] = inst_scene.instance_batch(int(cfg.max_rays_instances), order[(it * world + rank) % len(order)])
             if seg_scene is not None and epoch >= cfg.segment_optimization_epoch:                                   # T:458-459
