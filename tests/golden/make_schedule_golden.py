@@ -106,8 +106,9 @@ def run_seed(seed, threads, reuse=None):
     from contrastive_lift_amd.config import load_config, save_config
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import make_synthetic_mos as gen
-    tmp = reuse or tempfile.mkdtemp(prefix=f"g22_s{seed}_")
-    if not reuse:
+    tmp = reuse or os.path.join(os.environ.get("G22_WORK", "/tmp/g22_work"), f"seed{seed}")
+    os.makedirs(tmp, exist_ok=True)
+    if not os.path.exists(os.path.join(tmp, "resources")):
         os.symlink(os.path.join(REF, "resources"), os.path.join(tmp, "resources"))   # the datasets read resources/*.csv relative to the cwd
     scene_dir = gen.make_scene(os.path.join(tmp, "data", "synth_scene"), n_frames=SCHEDULE["n_frames"], size=SCHEDULE["image_dim"], seed=SCHEDULE["scene_seed"])
     cwd = os.getcwd()
@@ -145,8 +146,27 @@ def run_seed(seed, threads, reuse=None):
             loaders = model.train_dataloader()
         val_loader = model.val_dataloader()
         n_steps = max(len(l) for l in loaders.values())
-        table, gstep = {}, 0
-        for epoch in range(int(cfg.max_epoch)):
+        table, gstep, first_epoch = {}, 0, 0
+        state_file = os.path.join(tmp, "epoch_state.pt")
+        if os.path.exists(state_file):          # an interrupted generation continues at the last finished epoch (states of everything that carries over)
+            st = torch.load(state_file, map_location="cpu", weights_only=False)
+            grid = [int(x) for x in st["renderer"]["grid_dim"].tolist()]
+            with MG.quiet():
+                if grid != [int(x) for x in model.renderer.grid_dim.tolist()]:
+                    model.model.upsample_volume_grid(grid)
+                model.renderer.bbox_aabb.data = st["renderer"]["bbox_aabb"].clone()
+                model.renderer.update_step_size(torch.tensor(grid))
+            model.model.load_state_dict(st["model"], strict=True)
+            cfg.weight_decay = st["weight_decay"]
+            model._opts, model._scheds = model.configure_optimizers()
+            for o, s_ in zip(model._opts, st["opts"]):
+                o.load_state_dict(s_)
+            for o, s_ in zip(model._scheds, st["scheds"]):
+                o.load_state_dict(s_)
+            torch.set_rng_state(st["rng_torch"]); np.random.set_state(st["rng_numpy"]); __import__("random").setstate(st["rng_python"])
+            table, gstep, first_epoch, t0 = st["table"], st["gstep"], st["epoch"] + 1, time.time() - st["seconds"]
+            print(f"seed {seed}: resuming after epoch {st['epoch']}", flush=True)
+        for epoch in range(first_epoch, int(cfg.max_epoch)):
             model.current_epoch = model.trainer.current_epoch = epoch
             with MG.quiet():
                 model.on_train_epoch_start()
@@ -173,6 +193,12 @@ def run_seed(seed, threads, reuse=None):
             print(f"seed {seed} epoch {epoch}: {n_steps} steps, train psnr {model._logged.get('train/psnr', float('nan')):.2f}, val psnr {table['psnr']:.3f} "
                   f"iou {table['iou']:.3f} pq {table['pq']:.3f} grid {model.renderer.grid_dim.tolist()} S {model.renderer.n_samples} "
                   f"({time.time() - t0:.0f} s)", flush=True)
+            torch.save(dict(epoch=epoch, gstep=gstep, table=table, seconds=time.time() - t0, weight_decay=cfg.weight_decay,
+                            model={k: v.detach().clone() for k, v in model.model.state_dict().items()},
+                            renderer={k: v.detach().clone() for k, v in model.renderer.state_dict().items()},
+                            opts=[o.state_dict() for o in model._opts], scheds=[s_.state_dict() for s_ in model._scheds],
+                            rng_torch=torch.get_rng_state(), rng_numpy=np.random.get_state(), rng_python=__import__("random").getstate()), state_file + ".tmp")
+            os.replace(state_file + ".tmp", state_file)
         ckpt = f"runs/{cfg.experiment}/checkpoints/epoch={int(cfg.max_epoch) - 1}-step={gstep}.ckpt"
         torch.save({"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()}, "epoch": int(cfg.max_epoch) - 1, "global_step": gstep}, ckpt)
         save_config(cfg, f"runs/{cfg.experiment}/config.yaml")

@@ -32,7 +32,7 @@ def test_gpus_flag_self_launches_that_many_ranks():
     assert line["n_gpus"] == 2 and line["requested_gpus"] == 2
     assert line["allreduce_of_ones"] == 2.0          # both ranks took part in the collective
     # the comparison the N > 1 bench line's `data_parallel_self_check` is built on tells equal from unequal ranks
-    assert line["self_check_primitive"] == {"identical_tensor_delta": 0.0, "rank_dependent_tensor_delta": 1.0}
+    assert line["self_check_primitive"] == {"identical_tensor_delta": 0.0, "rank_dependent_tensor_delta": 1.0, "soak_reduction": [1.0, 0.0, 0.5]}
 
 
 def test_gpus_8_launch_check_reports_eight_ranks_over_gloo():
@@ -68,6 +68,20 @@ def test_bench_two_ranks_on_one_gpu_reports_two():
     assert chk["params_identical_across_ranks"] and chk["param_max_abs_delta_across_ranks"] == 0.0, chk
     assert chk["overlap_grad_equal"] and chk["overlap_grad"]["finite"], chk
     assert line["dtype"] == "f32" and "three bf16 terms" in line["config"]["mlp_arithmetic"]
+    assert "6x" in line["scaling_note"]
+
+
+@pytest.mark.gpu
+def test_bench_soak_two_ranks_on_one_gpu():
+    """`--soak K`: K replays of one training step with the asynchronous exchange forced on; the rendered outputs of every
+    replay are bit-identical to the first one's on every rank, the gradients within the noise of the floating-point atomics."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays", "1024",
+                        "--inst-rays", "256", "--grid", "64", "--no-extras", "--no-cpu-baseline", "--soak", "6"], capture_output=True, text=True,
+                       timeout=900, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    sk = _last_json(r.stdout)["soak"]
+    assert sk["replays"] == 6 and sk["overlap_forced_on"] and sk["replays_with_different_outputs"] == 0, sk
+    assert sk["replays_with_gradients_beyond_atomics_noise"] == 0, sk
 
 
 @pytest.mark.gpu
