@@ -150,3 +150,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, f32x16 (&acc)[BM /
     }
     if (do_colsum && tid < BM && m0 + tid < g.M) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
 }
+
+// Marks for the build's listing check (tools/isa_asm_load_check.py, "counted waits"): CLIFT_MARK_DMA(tag) stands in front of a hand-issued LDS-DMA
+// (it has no destination register the register guard could follow), CLIFT_MARK_USE(tag, allow) in front of the first read of the LDS slot that
+// DMA fills, behind the counted s_waitcnt vmcnt(N) that publishes it: replaying the listing's vector-memory stream in order, at most `allow`
+// DMAs of that tag may still be in flight there.  Comments in the listing: no instruction, no operand.
+#define CLIFT_MARK_DMA(tag) asm volatile("; @dma " tag)
+#define CLIFT_MARK_USE(tag, allow) asm volatile("; @use " tag " " allow)

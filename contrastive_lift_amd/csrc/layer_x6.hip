@@ -89,8 +89,11 @@ static __device__ __forceinline__ void x6_wait_vm() { asm volatile("s_waitcnt vm
 
 constexpr int X6_XCH = X6_RAW + X6_ROWS * 1024;     // exchange area: [tile parity][wave][2][lane] float4 = 2 x 16 KB
 // vmcnt before the read-back of staged row i (tools/x6_vmcnt_model.py replays each stream and prints these tables), by variant:
+#ifndef X6_VM00
+#define X6_VM00 5           // (tests/test_abi.py builds the listing once with 6 here: the guard must fail it)
+#endif
 constexpr int X8_VM[6][4] = {
-    {5, 4, 3, 3},       // 0 forward:                        D0 D1 S0 D2 S1 D3 per tile
+    {X6_VM00, 4, 3, 3}, // 0 forward:                        D0 D1 S0 D2 S1 D3 per tile
     {5, 5, 5, 5},       // 1 dgrad:                    m0 m1 D0 D1 S0 D2 S1 D3; the masks are needed after 6 younger instructions
     {6, 4, 4, 4},       // 2 forward + output layer:         D0 P D1 S0 D2 S1 D3 (P = the store of the output layer's partial sums)
     {4, 2, 3, 3},       // 3 the same, hidden not written:   D0 P D1 D2 D3
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     auto dma_piece = [&](int t, int i) {
         if (X6_ABL & 8) return;
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * i, rend - 1);
+        if (i == 0) CLIFT_MARK_DMA("piece0"); if (i == 1) CLIFT_MARK_DMA("piece1"); if (i == 2) CLIFT_MARK_DMA("piece2"); if (i == 3) CLIFT_MARK_DMA("piece3");
         __builtin_amdgcn_global_load_lds(g.A + (size_t)gr * g.lda + 4 * lane, (lds_ptr_t)(lds + X6_RAW + (wave * 4 + i) * 1024), 16, 0, (X6_NT & 1) ? 2 : 0);
     };
     // GEN: positions of this wave's rows wave + 8 i of tile t -> staging slot (t & 1): lanes 0..15 = (row i, component), the other lanes repeat them
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
     auto pos_dma = [&](int t) {
         if (X6_ABL & 8) return;
         const int gr = min(rbeg + t * X6_ROWS + wave + 8 * ((lane >> 2) & 3), rend - 1);
+        CLIFT_MARK_DMA("pos");
         __builtin_amdgcn_global_load_lds(gx.x4 + (size_t)gr * 4 + (lane & 3), (lds_ptr_t)(lds + X6_RAW + (t & 1) * 2048 + wave * 256), 4, 0, 0);
     };
     float gw0[4] = {0.f, 0.f, 0.f, 0.f}, gw1[4] = {0.f, 0.f, 0.f, 0.f}, gw2[4] = {0.f, 0.f, 0.f, 0.f}, gbb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -467,6 +472,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_x6(GemmP g, int rows_per_range
                 // GEN: the positions of tile t+1 left during tile t-1 (one DMA, before that tile's two stores); younger than it at any of the four
                 // read-backs: those two stores, this tile's position DMA (from i = 2 on) and first store (i = 3) -- vmcnt(2) covers all four
                 if (X6_ABL & 8) { } else if (GEN) x6_wait_vm<BM ? 3 : 2>(); else x8_wait_piece<VMV>(i);
+                // (marks for the build's listing check: the staged slot read next must not have its DMA in flight -- GEN: the positions of
+                //  tile t + 2 may be, from i = 2 on)
+                if (GEN) { if (i < 2) CLIFT_MARK_USE("pos", "0"); else CLIFT_MARK_USE("pos", "1"); }
+                else { if (i == 0) CLIFT_MARK_USE("piece0", "0"); if (i == 1) CLIFT_MARK_USE("piece1", "0"); if (i == 2) CLIFT_MARK_USE("piece2", "0"); if (i == 3) CLIFT_MARK_USE("piece3", "0"); }
                 raw_read(i, t + 1);
             } else {
                 if (j == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(sp_x) : : "memory");

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     const int so_y = g.lda * 16, so_x = GENX ? 64 : g.ldb * 16;                         // bytes per 4 rows
     auto dma = [&](int t, int o, int j) {
         const int piece = __builtin_amdgcn_readfirstlane(t * (XW_ROWS / 4) + 2 * ro + j);     // 4-row piece of the range (scalar)
+        if (o) CLIFT_MARK_DMA("x"); else CLIFT_MARK_DMA("y");
         if (o) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + 2048 + j * 1024), 16, vo_x, piece * so_x, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr_t)(lds + XW_RAW + wave * 4096 + j * 1024), 16, vo_y, piece * so_y, 0, 0);
     };
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
             if (s == 0) rd(1);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // this operand's rows (DMA'd during the previous tile) have landed
+            if (o) CLIFT_MARK_USE("x", "0"); else CLIFT_MARK_USE("y", "0");
             run_read(o, 0);
             acc[0] = xw_mfma(a[0], b0[0], acc[0]);
             __builtin_amdgcn_sched_barrier(0);

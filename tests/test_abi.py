@@ -76,6 +76,44 @@ def test_in_flight_register_guard():
         assert r.returncode == 0, (s, r.stdout[-2000:])
 
 
+def test_counted_wait_guard():
+    """The second check of tools/isa_asm_load_check.py (round 6): an LDS-DMA has no destination register, so a hand-counted ``s_waitcnt
+    vmcnt(N)`` that is one too large is invisible to the register guard.  The kernels mark the DMA (``; @dma tag``) and the first read of the
+    slot it fills (``; @use tag allow``); the build replays every marked loop's vector-memory stream in order.  Here: a synthetic loop with
+    the right and a wrong count, and the REAL thing -- csrc/layer_x6.hip compiled with its hand-counted table entry X8_VM[0][0] = 6 instead
+    of 5 must fail the check (the listing alone: a few seconds, no link)."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    tool = os.path.join(REPO, "tools", "isa_asm_load_check.py")
+
+    def loop(n):            # per trip: wait, use of the slot DMA'd in the previous trip, then its refill and two stores younger than it
+        return "\n".join(["_Z1kv:", ".LBB0_1:", f"\ts_waitcnt vmcnt({n})", "\t; @use slot 0", "\tds_read_b128 v[4:7], v1", "\t; @dma slot",
+                          "\tglobal_load_lds_dwordx4 v[2:3], off", "\tglobal_store_dwordx4 v[2:3], v[8:11], off", "\tglobal_store_dwordx4 v[2:3], v[8:11], off",
+                          "\ts_cbranch_scc1 .LBB0_1", ".Lfunc_end0:", ""])
+    with tempfile.TemporaryDirectory() as d:
+        for name, text, rc in (("good.s", loop(2), 0), ("bad.s", loop(3), 1), ("orphan.s", loop(2).replace("global_load_lds_dwordx4 v[2:3], off", "global_load_dwordx4 v[12:15], v[2:3], off"), 1)):
+            p = os.path.join(d, name)
+            open(p, "w").write(text)
+            r = subprocess.run([sys.executable, tool, p], capture_output=True, text=True)
+            assert r.returncode == rc, (name, r.stdout)
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            return
+        csrc = os.path.join(REPO, "contrastive_lift_amd", "csrc")
+        for define, rc in (("-DX6_VM00=6", 1), ("-DX6_VM00=5", 0)):
+            out = os.path.join(d, "x6.s")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-fno-slp-vectorize", define,
+                                "-I" + csrc, "-I" + os.path.join(REPO, "include"), "-S", "--cuda-device-only", os.path.join(csrc, "layer_x6.hip"), "-o", out],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            r = subprocess.run([sys.executable, tool, out], capture_output=True, text=True)
+            assert r.returncode == rc, (define, r.stdout[-1500:])
+            if rc:
+                assert "@use piece0" in r.stdout
+
+
 def test_head_acts_keep_sign_bytes_with_their_activation():
     """engine.HeadActs: the sign bytes of a persistent fp32x6 forward travel with the activation list, keyed by the activation's index,
     and are refused when they do not belong to it (wrong row count) -- host logic, no GPU."""
