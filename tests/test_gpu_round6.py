@@ -255,3 +255,26 @@ def test_short_schedule_lands_where_the_reference_trainer_does(tmp_path, monkeyp
         want, spread = ref["summary"][key]["mean"], ref["summary"][key]["spread"]
         print(f"{key}: HIP mean {mine:.4f}, reference mean {want:.4f} (spread over seeds {spread:.4f})")
         assert abs(mine - want) <= max(0.1, spread), (key, mine, want, spread)
+
+
+@pytest.mark.parametrize("M", [70001, 33, 249003])
+def test_wgrad_x6_reads_nothing_past_its_rows(M):
+    """csrc/layer_x6w.hip fetches its rows by range-bounded buffer loads (round 6): a row past the end of a block's row range must arrive as
+    zeros -- neither the next range's rows (they would be counted twice) nor whatever follows the tensor.  dY and X are the first M rows of
+    larger buffers whose tails are NaN: one NaN in gW / gb means a row past the end was read."""
+    from contrastive_lift_amd import engine
+    g = torch.Generator().manual_seed(7 + M)
+    pad = 4096
+    big_y = torch.full((M + pad, 256), float("nan"), device=DEV)
+    big_x = torch.full((M + pad, 256), float("nan"), device=DEV)
+    dY = big_y[:M]
+    X = big_x[:M]
+    dY.copy_(torch.randn(M, 256, generator=g).to(DEV))
+    X.copy_(torch.relu(torch.randn(M, 256, generator=g)).to(DEV))
+    gW, gb = torch.zeros(256, 256, device=DEV), torch.zeros(256, device=DEV)
+    with engine._Precision(engine._PRECISIONS["fp32x6"]):
+        engine.wgrad(256, 256, M, dY, 256, X, 256, gW, gb)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(gW).all()) and bool(torch.isfinite(gb).all())
+    ref = dY.double().cpu().t() @ X.double().cpu()
+    assert float((gW.double().cpu() - ref).abs().max()) / float(ref.abs().max()) <= 2e-6
