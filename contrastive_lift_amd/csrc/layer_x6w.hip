@@ -189,27 +189,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
     const unsigned fa = lds0 + (unsigned)((32 * wn + li) * XW_PITCH + 16 * lh);
     const unsigned fb = lds0 + (unsigned)(3 * XW_PLANE + (64 * kp + li) * XW_PITCH + 16 * lh);
 
+    // ONE barrier per tile, and not at the top: a wave's last plane-image write of tile t + 1 happens two MFMAs before the end of tile t, so the
+    // barrier stands there and the first fragments of tile t + 1 (k-step 0: their registers are free during the second group) are read behind
+    // it, under the tile's last MFMAs -- the loop top used to expose barrier skew + the latency of nine ds_read_b128 every tile
+    // (SQ_WAIT_INST_LDS 18 % of the wave cycles, profiles/r06_pmc_tables.txt).  Every wave has finished its own fragment reads of tile t when
+    // it arrives (it waited for them at the start of the second group), so the writes of tile t + 1 into tile t's stage are safe behind it.
+    u32x4 A[2][3], B[2][2][3];                          // dY fragments of k-step s; X fragments of k-step s, k-tiles 2 kp, 2 kp + 1
+    auto rd = [&](int s, unsigned cur) {
+        const unsigned a = fa + cur + (unsigned)(32 * s);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(A[s][0]) : "v"(a) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(A[s][1]) : "v"(a) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A[s][2]) : "v"(a) : "memory");
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const unsigned c = fb + cur + (unsigned)(x * 32 * XW_PITCH + 32 * s);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(B[s][x][0]) : "v"(c) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(B[s][x][1]) : "v"(c) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(B[s][x][2]) : "v"(c) : "memory");
+        }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rd(0, 0u);
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         const unsigned cur = (unsigned)((t & 1) * XW_STAGE), nxt = (unsigned)(((t + 1) & 1) * XW_STAGE);
         const int valid = valid_of(t + 1);
-        u32x4 A[2][3], B[2][2][3];                      // dY fragments of k-step s; X fragments of k-step s, k-tiles 2 kp, 2 kp + 1
-        auto rd = [&](int s) {
-            const unsigned a = fa + cur + (unsigned)(32 * s);
-            asm volatile("ds_read_b128 %0, %1" : "=v"(A[s][0]) : "v"(a) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(A[s][1]) : "v"(a) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(A[s][2]) : "v"(a) : "memory");
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const unsigned c = fb + cur + (unsigned)(x * 32 * XW_PITCH + 32 * s);
-                asm volatile("ds_read_b128 %0, %1" : "=v"(B[s][x][0]) : "v"(c) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(B[s][x][1]) : "v"(c) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:20480" : "=v"(B[s][x][2]) : "v"(c) : "memory");
-            }
-        };
-        rd(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int o = s == 0 ? 1 : 0;                                        // the operand whose two runs are split during this group: X, then dY
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]) : : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 0) rd(1);
+            if (s == 0) rd(1, cur);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // this operand's rows (DMA'd during the previous tile) have landed
             if (o) CLIFT_MARK_USE("x", "0"); else CLIFT_MARK_USE("y", "0");
             run_read(o, 0);
@@ -254,6 +259,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             acc[1] = xw_mfma(a[0], b1[2], acc[1]);
             __builtin_amdgcn_sched_barrier(0);
             run_write(nxt, o, 1);
+            if (s == 1) {                                                         // the next stage is complete on this wave: meet the others, then its first fragments
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                rd(0, nxt);
+            }
             acc[0] = xw_mfma(a[2], b0[0], acc[0]);
             __builtin_amdgcn_sched_barrier(0);
             dma(t + 2, o, 0); dma(t + 2, o, 1);                                  // both runs of this operand are read: refill its rows with tile t + 2's
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_x6(GemmP g, int rows_per_range
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the fragments read ahead for a tile that does not exist)
     // lane (li, lh) holds gW rows n = 128 qn + 32 wn + 8 q + 4 lh + e, column k = 128 qk + 64 kp + 32 x + li
     // The loop issues its LDS-DMA unconditionally (clamped rows past the end), so the newest ones are still in flight here.  A wave must NOT end with
     // vector-memory loads outstanding: the hardware frees its registers at s_endpgm and the late data beats land in whatever wave owns them next
