@@ -159,7 +159,7 @@ class HotPathTrainer:
     def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
         # config variants of the reference that this trainer does not implement fail loudly instead of being ignored
-        unsupported = [(k, v) for k, v in (("probabilistic_ce_mode", "TTAConf"), ("optimize_instance_only", False),
+        unsupported = [(k, v) for k, v in (("optimize_instance_only", False),
                                             ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
                                             ("use_proj", False), ("use_feature_regularization", False))
                        if getattr(config, k, v) != v]
@@ -502,6 +502,14 @@ class HotPathTrainer:
         mask = batch.get("mask")
         maskf = mask.to(torch.float32) if mask is not None else None        # T:156-158 (masked pixels contribute nothing)
         self.losses.zero_()
+        # T:177-182: "TTAConf" = soft targets x confidences; "NoTTAConf" = the label map as the target (class indices = one-hot rows for the
+        # same kernel) x confidences
+        ce_mode = getattr(c, "probabilistic_ce_mode", "TTAConf")
+        if ce_mode == "NoTTAConf":
+            batch = dict(batch)
+            batch["probabilities"] = torch.nn.functional.one_hot(batch["semantics"].long(), sem.shape[1]).to(torch.float32)
+        elif ce_mode != "TTAConf":       # (the unweighted form also counts masked pixels, T:182: not built)
+            raise NotImplementedError(f"HotPathTrainer: probabilistic_ce_mode={ce_mode!r} (TTAConf and NoTTAConf are built)")
         if getattr(c, "use_symmetric_ce", False):       # T:74-77: SCELoss(ce_alpha, ce_beta, weights) replaces the cross entropy
             _lib.call("clift_pixel_losses_sce", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
                       _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,

@@ -278,3 +278,30 @@ def test_wgrad_x6_reads_nothing_past_its_rows(M):
     assert bool(torch.isfinite(gW).all()) and bool(torch.isfinite(gb).all())
     ref = dY.double().cpu().t() @ X.double().cpu()
     assert float((gW.double().cpu() - ref).abs().max()) / float(ref.abs().max()) <= 2e-6
+
+
+def test_nottaconf_semantic_loss_mode():
+    """probabilistic_ce_mode "NoTTAConf" (T:179-180): the label map is the target, still weighted by the confidences -- the same step as
+    "TTAConf" fed with one-hot probabilities of those labels (same kernel, same bits)."""
+    import contrastive_lift_amd as cl
+    from oracle import params as op
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from test_gpu_parity import build_model
+    g = load_golden("g12_training_steps")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    out = []
+    for mode in ("TTAConf", "NoTTAConf"):
+        P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
+        m = build_model(cl, P, res, C_, E, float(g["shift"]))
+        r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+        tr = HotPathTrainer(m, r, default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, probabilistic_ce_mode=mode, max_instances=E),
+                            class_weights=T(g["class_weights"]), current_epoch=4)
+        labels = d(g["s0.probs"]).argmax(-1)
+        probs = torch.nn.functional.one_hot(labels, C_).float() if mode == "TTAConf" else d(g["s0.probs"])
+        tr.main_pass(dict(rays=d(g["s0.rays"]), rgbs=d(g["s0.rgbs"]), probabilities=probs, confidences=d(g["s0.confs"]), mask=d(g["s0.mask"]), semantics=labels),
+                     jitter=d(g["s0.jitter"]), white_bg=bool(g["s0.white"][0]))
+        out.append((float(tr.losses[1]), m.param_flat.detach().clone()))
+    assert out[0][0] == out[1][0] and out[0][0] > 0
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-6

@@ -19,8 +19,8 @@ FAM = [  # (regex on the kernel name, family label, bound, algorithmic traffic p
     (r"k_layer_n6<8, 5, true", "appearance input gradient 128 -> 160", "bf16 MFMA + HBM stream", "512 B in, 640 B out per row"),
     (r"k_wgrad_n6", "appearance weight gradients 128 x {128, 160}", "bf16 MFMA + 2 HBM streams", "1 - 1.1 KB in per row"),
     (r"k_app_front_fwd", "appearance front end: VM gather + basis Linear (fp32 MFMA) + input encoding (`clift_app_front_fwd_x`)", "L2 / LDS (table taps), VALU (sincos)", "16 B + 576 B of taps (L2) in, 640 B + 112 B (+ 576 B products when kept) out per row"),
-    (r"k_app_gather_bwd", "appearance table scatter (`clift_app_gather_bwd`)", "instruction stream + L2 atomics", "576 B in per row, XCD-local atomics"),
-    (r"k_density_bwd", "density table scatter (`clift_density_bwd`)", "instruction stream + L2 atomics", "8 B in per sample, XCD-local atomics"),
+    (r"k_app_gather_bwd", "appearance table scatter (`clift_app_gather_bwd`)", "L2 atomics (~28 %) + dependent LDS / memory round trips at 24 waves per CU", "576 B in per row, XCD-local atomics"),
+    (r"k_density_bwd", "density table scatter (`clift_density_bwd`)", "L2 atomics (~28 %) + dependent LDS / memory round trips at 16 waves per CU", "8 B in per sample, XCD-local atomics"),
     (r"k_density_fwd", "density lookup + softplus (`clift_density_fwd`)", "L1 / L2 table reads", "4 B out per sample, 9 x 64 B taps (L2)"),
     (r"k_xcd_reduce", "fold of the eight XCD-private table-gradient copies", "HBM / L2", "8 x table size in"),
     (r"k_dgrad_narrow_stream<3", "semantic output layer backward: weight + masked input gradient in one pass (`clift_out_layer_bwd`)", "HBM stream", "1 KB + 96 B in, 1 KB out per row"),
