@@ -163,6 +163,8 @@ class HotPathTrainer:
                                             ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
                                             ("use_proj", False), ("use_feature_regularization", False))
                        if getattr(config, k, v) != v]
+        if getattr(config, "probabilistic_ce_mode", "TTAConf") not in ("TTAConf", "NoTTAConf"):
+            unsupported.append(("probabilistic_ce_mode", "TTAConf / NoTTAConf"))
         if unsupported:
             raise NotImplementedError("HotPathTrainer: config options outside the contrastive-lift hot path: " +
                                       ", ".join(f"{k}={getattr(config, k)!r} (only {v!r} is built)" for k, v in unsupported))

@@ -253,7 +253,8 @@ def test_trainer_rejects_unbuilt_config_variants():
     r = cl.TensoRFRenderer(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), [6, 7, 8], semantic_weight_mode="softmax")
     HotPathTrainer(m, r, default_config())                                   # the shipped settings construct fine
     HotPathTrainer(m, r, default_config(use_symmetric_ce=True))             # SCELoss is built (round 2)
-    for k, v in (("probabilistic_ce_mode", "NoTTAConf"), ("optimize_instance_only", True)):
+    HotPathTrainer(m, r, default_config(probabilistic_ce_mode="NoTTAConf"))  # the label map as the target (round 6)
+    for k, v in (("probabilistic_ce_mode", "NoConf"), ("optimize_instance_only", True)):
         with pytest.raises(NotImplementedError):
             HotPathTrainer(m, r, default_config(**{k: v}))
 
