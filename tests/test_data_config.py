@@ -282,3 +282,23 @@ def test_linear_assignment_matching_on_the_host():
             y = torch.randint(1, L + 1, (n,), generator=g)
             f = 3.0 * torch.randn(n, E, generator=g)
             assert torch.equal(prod(y, f), orc(y, f)), (E, L, n)
+
+
+def test_epoch_order_is_one_permutation_shared_by_the_ranks():
+    """SceneTables.epoch_order (the reference's DataLoader(shuffle=True, drop_last=True) under Lightning's DistributedSampler, T:434): one
+    permutation of all training pixels per epoch, identical on every rank, of which rank r takes entries r, r + world, ...: every pixel exactly
+    once per epoch across the ranks, another order the next epoch; pixel_batch_at slices it (and wraps when asked for more steps)."""
+    from contrastive_lift_amd.data.mos import SceneTables
+    sc = SceneTables.__new__(SceneTables)
+    sc.device = torch.device("cpu")
+    n = 1003
+    sc.tables = {"rays": torch.arange(n, dtype=torch.float32)[:, None].repeat(1, 8), "rgbs": torch.zeros(n, 3)}
+    shards = [sc.epoch_order(5, 2, r, 4) for r in range(4)]
+    assert sorted(torch.cat(shards).tolist()) == list(range(n)) and max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    assert all(torch.equal(a, b) for a, b in zip(shards, [sc.epoch_order(5, 2, r, 4) for r in range(4)]))
+    assert not torch.equal(sc.epoch_order(5, 2), sc.epoch_order(5, 3)) and not torch.equal(sc.epoch_order(5, 2), sc.epoch_order(6, 2))
+    full = sc.epoch_order(5, 2)
+    seen = torch.cat([sc.pixel_batch_at(full, it, 100)["rays"][:, 0] for it in range(n // 100)])
+    assert len(set(seen.tolist())) == 100 * (n // 100)                       # drop_last: no pixel twice within an epoch
+    b = sc.pixel_batch_at(full, n // 100 + 3, 100)                           # a longer steps_per_epoch wraps around the same order
+    assert b["rays"].shape == (100, 8) and torch.equal(b["rays"][:, 0].long(), full[((n // 100 + 3) * 100 + torch.arange(100)) % n])
