@@ -195,9 +195,9 @@ class SceneTables:
         trainer/__init__.py:97) -- ONE permutation of all training pixels per epoch, the same on every rank (seeded by seed and epoch),
         of which rank r takes the entries r, r + world, ...  Every pixel is visited exactly once per epoch across the ranks."""
         n = self.tables["rays"].shape[0]
-        g = torch.Generator(device=self.device)
+        g = torch.Generator()                             # a CPU generator, like the DataLoader's RandomSampler
         g.manual_seed((int(seed) * 1000003 + int(epoch)) * 7919 + 17)
-        return torch.randperm(n, device=self.device, generator=g)[rank::world]
+        return torch.randperm(n, generator=g)[rank::world].to(self.device)
 
     def pixel_batch_at(self, order, it, batch_size):
         """Batch ``it`` of an epoch order (drop_last: the CLI runs len(order) // batch_size steps; a longer ``steps_per_epoch`` wraps around)."""

@@ -35,6 +35,8 @@ def default_config(**over):
              nosync=False,         # this build's extension key: sync-free steps (no read-back of the active-sample count; exact-fp32 path)
              skip_discarded_instance_heads=False,    # extension key: do not evaluate the instance heads in the main pass, where the reference
                                                      # computes and discards them (T:155) -- same results, ~12 % less work; the train CLI sets it
+             host_rng=False,       # extension key: draw the per-ray jitter from torch's CPU generator like the reference's renderer (R:808-810) instead of the
+                                   # device generator; the train CLI sets it (the drop-in's random sources are the reference's), the benchmark does not
              grad_shards=True)     # extension key: MLP gradients accumulate in eight per-XCD copies, folded once per pass (include/clift.h, ABI 12)
     c.update(over)
     return types.SimpleNamespace(**c)
@@ -297,6 +299,16 @@ class HotPathTrainer:
         a, b = self.model.arena.range_of(*groups)
         _lib.call("clift_grad_shards_fold", _lib.ptr(self._shard_record), a - self._shard_range[0], b - a, 1, _lib.stream())
 
+    def _jitter(self, n):
+        """One U[0, 1) per ray (R:808-810), or None when perturb is 0.  ``host_rng``: from torch's CPU generator, exactly the reference's draw."""
+        c = self.config
+        if c.perturb == 0:
+            return None
+        if bool(getattr(c, "host_rng", False)):
+            return (c.perturb * torch.rand(n, 1)).reshape(-1).to(self.device, non_blocking=True)
+        j = torch.rand(n, device=self.device)
+        return j if c.perturb == 1 else c.perturb * j
+
     def on_train_epoch_start(self, maintenance=True):
         """T:446-457, in the reference's order: the dist-reg weight ramps as lambda * (1 - exp(-0.25 epoch)); at ``bbox_aabb_reset_epochs`` the
         box shrinks to the alpha mask and the tables are cropped; at ``grid_upscale_epochs`` the tables are resampled to the next entry of the
@@ -474,10 +486,8 @@ class HotPathTrainer:
         rays = batch["rays"]
         B = rays.shape[0]
         self._pass_begin(self.main_range)
-        if jitter is None and c.perturb != 0:
-            jitter = torch.rand(B, device=self.device)
-            if c.perturb != 1:
-                jitter = c.perturb * jitter
+        if jitter is None:
+            jitter = self._jitter(B)
         chunk = c.chunk if c.chunk and c.chunk > 0 else B
         ctxs, outs = [], []
         for i in range(0, B, chunk):
@@ -576,8 +586,8 @@ class HotPathTrainer:
         n = rays.shape[0]
         if n == 0:
             return
-        if jitter is None and c.perturb != 0:
-            jitter = c.perturb * torch.rand(n, device=self.device)
+        if jitter is None:
+            jitter = self._jitter(n)
         feats, ctx = engine.feature_forward(m, r, rays, jitter, "semantic", grad_heads=("sem",), cap=self._capacity("seg", n))
         self._follow("seg", n, ctx)
         C = feats.shape[1]
@@ -606,10 +616,8 @@ class HotPathTrainer:
             rays = img["rays"]
             n = rays.shape[0]
             jit = jitter
-            if jit is None and c.perturb != 0:
-                jit = torch.rand(n, device=self.device)
-                if c.perturb != 1:
-                    jit = c.perturb * jit
+            if jit is None:
+                jit = self._jitter(n)
             (inst, xyz), ctx = engine.feature_forward(m, r, rays, jit, "instance", grad_heads=("fast",),     # slow half: detached (T:268)
                                                       cap=self._capacity("inst", n),
                                                       want_xyz=c.instance_loss_mode == "contrastive" and bool(getattr(c, "use_delta", False)))

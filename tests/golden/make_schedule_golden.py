@@ -235,7 +235,8 @@ def main():
     for key, get in (("val_psnr", lambda r: r["val"]["psnr"]), ("val_iou", lambda r: r["val"]["iou"]), ("val_pq", lambda r: r["val"]["pq"]),
                      ("scene_iou", lambda r: r["scene"]["iou"]), ("pq_scene", lambda r: r["scene"]["pq"])):
         v = np.array([get(r) for r in runs])
-        agg[key] = dict(mean=float(v.mean()), min=float(v.min()), max=float(v.max()), spread=float(v.max() - v.min()))
+        agg[key] = dict(mean=float(v.mean()), median=float(np.median(v)), min=float(v.min()), max=float(v.max()), spread=float(v.max() - v.min()),
+                        values=[float(x) for x in v])
     path = os.path.join(HERE, "g22_short_schedule.json")
     json.dump(dict(schedule=SCHEDULE, unpinned_note="dist-reg term via the restated eff_distloss; Lightning's fit loop emulated (see the docstring)",
                    runs=runs, summary=agg), open(path, "w"), indent=1)

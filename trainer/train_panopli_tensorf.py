@@ -113,6 +113,8 @@ def main(argv):
     if getattr(cfg, "skip_discarded_instance_heads", None) is None:
         # the reference's main pass evaluates the instance heads and throws the result away (T:155: `_`); same training either way
         cfg.skip_discarded_instance_heads = True
+    if getattr(cfg, "host_rng", None) is None:
+        cfg.host_rng = True                                                # jitter from torch's CPU generator, like the reference's renderer (R:808-810)
     seed = cfg.seed if cfg.seed is not None else 0
     torch.manual_seed(seed)                                                # identical initial weights on every rank
     cfg.instance_optimization_epoch = cfg.instance_optimization_epoch + cfg.late_semantic_optimization     # T:46
