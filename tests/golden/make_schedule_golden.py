@@ -85,8 +85,17 @@ def _infer(seed, cfg, ckpt, scene_dir, table, gstep, t0, final):
         PS.read_and_resize_labels = lambda path, size: _read(path, size).astype(np.int32)      # (environment shim as in make_golden.g16: Pillow's uint16)
         real_dev = torch.cuda.is_available
         try:
-            with (contextlib.nullcontext() if os.environ.get("G22_VERBOSE") else MG.quiet()):
-                RP.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=SCHEDULE["bandwidth"])
+            scene = None
+            try:
+                with (contextlib.nullcontext() if os.environ.get("G22_VERBOSE") else MG.quiet()):
+                    RP.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=SCHEDULE["bandwidth"])
+            except ValueError as e:
+                # RP:213-214 draws 50 000 thing pixels WITHOUT replacement: a field that has not separated the objects yet predicts fewer and the
+                # reference's own script stops here -- such a run has no PQ_scene on the reference's side
+                if "larger sample than population" not in str(e):
+                    raise
+                print(f"seed {seed}: the reference's render_panopli.py raised ({e}): no scene metrics for this run", flush=True)
+                return dict(seed=seed, steps=gstep, seconds=time.time() - t0, val=table, scene=None, scene_note="render_panopli.py:214 raised: fewer than 50 000 predicted thing pixels", **final)
             out_dir = RP.output_dirname(cfg, "trajectory_blender", True, False, False)
             with MG.quiet():
                 iou = PS.calculate_iou_folders_MOS(pathlib.Path(out_dir, "pred_semantics"), pathlib.Path(scene_dir) / "semantic", (H, W))
@@ -234,7 +243,7 @@ def main():
     agg = {}
     for key, get in (("val_psnr", lambda r: r["val"]["psnr"]), ("val_iou", lambda r: r["val"]["iou"]), ("val_pq", lambda r: r["val"]["pq"]),
                      ("scene_iou", lambda r: r["scene"]["iou"]), ("pq_scene", lambda r: r["scene"]["pq"])):
-        v = np.array([get(r) for r in runs])
+        v = np.array([get(r) for r in runs if not (key in ("scene_iou", "pq_scene") and r["scene"] is None)])      # (scene metrics: the runs the reference's script finished)
         agg[key] = dict(mean=float(v.mean()), median=float(np.median(v)), min=float(v.min()), max=float(v.max()), spread=float(v.max() - v.min()),
                         values=[float(x) for x in v])
     path = os.path.join(HERE, "g22_short_schedule.json")

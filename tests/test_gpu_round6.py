@@ -248,15 +248,24 @@ def test_short_schedule_lands_where_the_reference_trainer_does(tmp_path, monkeyp
         np.random.seed(seed)
         out = rp.render_panopli_checkpoint(cfg, "trajectory_blender", test_only=True, bandwidth=sc["bandwidth"])
         iou, pq, sq, rq = ev.evaluate_mos(str(out), scene_dir, (sc["infer_dim"], sc["infer_dim"]))
-        ours.append(dict(seed=seed, val_psnr=val["psnr"], scene_iou=float(iou), pq_scene=float(pq)))
-        print(f"seed {seed}: HIP val psnr {val['psnr']:.3f}  PQ_scene {float(pq):.4f}  scene mIoU {float(iou):.4f}", flush=True)
+        # the reference's render_panopli.py draws 50 000 thing pixels without replacement (RP:213-214) and stops when a field predicts fewer (its late
+        # runs: `scene: null` in the fixture); the product clusters whatever there is -- the scene metrics are compared over the runs the
+        # reference's script would have finished, on both sides
+        tf = np.load(out / "thing_features.npy")
+        tf = tf[np.isneginf(tf[:, 0]), 1:]                                           # RP:198-206: thing pixels, then the 3-sigma outlier filter
+        things = int(np.all(np.abs(tf - tf.mean(0)) < 3 * tf.std(0), axis=1).sum()) if tf.shape[0] else 0
+        ours.append(dict(seed=seed, val_psnr=val["psnr"], scene_iou=float(iou), pq_scene=float(pq), things=things))
+        print(f"seed {seed}: HIP val psnr {val['psnr']:.3f}  PQ_scene {float(pq):.4f}  scene mIoU {float(iou):.4f}  thing pixels {things}", flush=True)
+    n_ref_scene = sum(1 for run in ref["runs"] if run["scene"] is not None)
+    print(f"runs with scene metrics: reference {n_ref_scene} of {len(ref['runs'])}, HIP {sum(1 for o in ours if o['things'] >= 50000)} of {len(ours)}")
     for key in ("val_psnr", "pq_scene", "scene_iou"):
-        mine = sorted(o[key] for o in ours)
+        mine = sorted(o[key] for o in ours if key == "val_psnr" or o["things"] >= 50000)
+        assert len(mine) >= 6, (key, ours)
         r = ref["summary"][key]
         print(f"{key}: HIP median {np.median(mine):.4f} (min {mine[0]:.3f}, max {mine[-1]:.3f}); reference median {r['median']:.4f} "
               f"(min {r['min']:.3f}, max {r['max']:.3f}, {len(r['values'])} seeds)")
         assert abs(float(np.median(mine)) - r["median"]) <= max(0.1, r["spread"]), (key, mine, r)
-        assert mine[-3] >= r["median"] - max(0.1, 0.25 * r["spread"]), (key, mine, r)       # the best quarter of the runs is at the reference's typical level
+        assert mine[-(len(mine) // 4)] >= r["median"] - max(0.1, 0.25 * r["spread"]), (key, mine, r)       # the best quarter of the runs is at the reference's typical level
 
 
 @pytest.mark.parametrize("M", [70001, 33, 249003])
