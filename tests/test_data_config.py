@@ -302,3 +302,53 @@ def test_epoch_order_is_one_permutation_shared_by_the_ranks():
     assert len(set(seen.tolist())) == 100 * (n // 100)                       # drop_last: no pixel twice within an epoch
     b = sc.pixel_batch_at(full, n // 100 + 3, 100)                           # a longer steps_per_epoch wraps around the same order
     assert b["rays"].shape == (100, 8) and torch.equal(b["rays"][:, 0].long(), full[((n // 100 + 3) * 100 + torch.arange(100)) % n])
+
+
+def test_checkpoint_optimizer_state_is_torch_adams_own_layout():
+    """HotPathTrainer.checkpoint_dict writes both Adam states in torch.optim.Adam's own ``state_dict`` layout with the REFERENCE's parameter-group
+    order (tensoRF.py:199-246; the group sizes are pinned by golden G12's ``opt_groups``), loadable into a torch.optim.Adam built over the
+    reference's groups, and ``load_torch_state_dict`` restores exactly what was written; a shrink without an optimizer rebuild carries the MLPs'
+    moments to their new arena offsets and freezes the cropped tables (ArenaAdam.carry_from: the reference's behaviour, golden G21 scenario B)."""
+    import numpy as np
+    import contrastive_lift_amd as cl
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    g = np.load(os.path.join(REPO, "tests", "golden", "g12_training_steps.npz"))
+    res, C_, E = [int(x) for x in g["res"]], int(g["C"]), int(g["E"])
+    m = cl.TensorVMSplit(res, num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_, dim_feature_instance=2 * E,
+                         use_semantic_mlp=True, use_instance_mlp=True, slow_fast_mode=True, device="cpu")
+    r = cl.TensoRFRenderer(torch.tensor(g["aabb"]), res, semantic_weight_mode="softmax")
+    tr = HotPathTrainer(m, r, default_config(max_instances=E), current_epoch=4)
+    main, inst = tr.torch_param_groups()
+    og = g["opt_groups"]                                            # rows: lr, weight_decay, beta1, beta2, numel -- main groups first
+    numel = lambda names: sum(m.arena.by_name[n].shape[0] * int(np.prod(m.arena.by_name[n].shape[1:])) for n in names)
+    assert [numel(ns) for _, ns in main + inst] == [int(x) for x in og[:, 4]]
+    assert [lr for lr, _ in main + inst] == [float(x) for x in og[:, 0]]
+    # pretend two steps happened: fill the moments, set the counts, write, load into a fresh optimizer, compare
+    gen = torch.Generator().manual_seed(3)
+    for opt in (tr.opt_main, tr.opt_inst):
+        opt.m.copy_(torch.randn(opt.m.shape, generator=gen)); opt.v.copy_(torch.rand(opt.v.shape, generator=gen))
+        opt.t = {k: 2 for k in opt.t}
+    tr.opt_main.t["net_sem"] = 0                                    # the semantic MLP has not been stepped yet: no state entries, like torch's lazy state
+    ck = tr.checkpoint_dict(global_step=2, epoch_complete=False)
+    sd = ck["optimizer_states"][0]
+    n_sem = len(main[-1][1])
+    assert len(sd["state"]) == sum(len(ns) for _, ns in main) - n_sem and sd["param_groups"][0]["betas"] == (0.9, 0.99)
+    ref_params = [[torch.nn.Parameter(torch.zeros(m.arena.by_name[n].shape)) for n in ns] for _, ns in main]
+    topt = torch.optim.Adam([{"params": ps, "lr": lr} for ps, (lr, _) in zip(ref_params, main)], lr=5e-4, betas=(0.9, 0.99))
+    topt.load_state_dict(sd)                                        # torch accepts it: same group structure, same per-parameter shapes
+    assert float(topt.state[ref_params[2][0]]["step"]) == 2.0 and topt.state[ref_params[2][0]]["exp_avg"].shape == m.arena.by_name["density_plane.0"].shape
+    tr2 = HotPathTrainer(m, r, default_config(max_instances=E), current_epoch=4)
+    tr2.opt_main.load_torch_state_dict(sd, main)
+    tr2.opt_inst.load_torch_state_dict(ck["optimizer_states"][1], inst)
+    mv, mv2 = m.arena.views(tr.opt_main.m), m.arena.views(tr2.opt_main.m)
+    assert all(torch.equal(mv[n], mv2[n]) for _, ns in main[:-1] for n in ns) and tr2.opt_main.t == {"grids": 2, "net_app": 2, "net_sem": 0}
+    assert float(m.arena.views(tr2.opt_main.m)["render_semantic_mlp.mlp.0.weight"].abs().max()) == 0.0
+    assert tr2.opt_inst.t["inst_fast"] == 2 and ck["lr_schedulers"][0]["last_epoch"] == 0
+    # a shrink without a rebuild: the arena is re-packed, the MLPs' moments follow, the cropped tables leave the optimizer
+    before = mv["render_appearance_mlp.mlp.0.weight"].clone()
+    m.shrink([1, 1, 1], [r_ - 1 for r_ in res])
+    tr.setup_optimizers(carry=True)
+    assert "grids" in tr.opt_main.frozen and "net_app" not in tr.opt_main.frozen and tr.opt_main.t["net_app"] == 2
+    assert torch.equal(m.arena.views(tr.opt_main.m)["render_appearance_mlp.mlp.0.weight"], before)
+    tr.setup_optimizers()
+    assert not tr.opt_main.frozen and tr.opt_main.t["net_app"] == 0 and float(tr.opt_main.m.abs().max()) == 0.0
