@@ -172,7 +172,10 @@ def main(argv):
         tr.on_train_epoch_start(maintenance=not (resumed_mid_epoch and epoch == start_epoch))
         order = torch.randperm(max(1, len(inst_scene.instance_images)), generator=torch.Generator().manual_seed(seed * 31 + epoch)).tolist()   # DataLoader(shuffle=True), T:436
         pixels = scene.epoch_order(seed, epoch, rank, world)               # DataLoader(train_set, shuffle=True, drop_last=True), T:434: every pixel once per epoch
-        for it in range(steps_per_epoch):
+        # a checkpoint written in the middle of an epoch continues at ITS batch: the epoch's pixel order is a function of (seed, epoch), so the
+        # remaining batches are exactly the ones the interrupted run would have drawn (Lightning's fit loop restores its batch progress likewise)
+        first_it = (gstep % steps_per_epoch) if (resumed_mid_epoch and epoch == start_epoch) else 0
+        for it in range(first_it, steps_per_epoch):
             batch = {0: scene.pixel_batch_at(pixels, it, per_rank)}
             if epoch >= cfg.instance_optimization_epoch and inst_scene.instance_images:
                 batch[1] = inst_scene.instance_batch(int(cfg.max_rays_instances), order[(it * world + rank) % len(order)])
