@@ -185,3 +185,31 @@ def test_resume_continues_a_run(tmp_path, monkeypatch):
         ps.append(float(inf.psnr(rgb, scene.load_targets(i)["rgbs"].cuda())))
     print("PSNR straight / resumed:", ps)
     assert abs(ps[0] - ps[1]) < 0.5, ps
+
+
+def test_mid_epoch_checkpoint_continues_at_its_batch(tmp_path, monkeypatch):
+    """A checkpoint written in the middle of an epoch (``save_every_n_train_steps``, what the reference's ModelCheckpoint writes) carries no
+    "epoch finished" mark: the resumed run does not repeat that epoch's hook (the tables are already shrunk / upsampled) and continues at the
+    checkpoint's batch of the epoch's pixel order -- the run ends at the same global step as an uninterrupted one."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import make_synthetic_mos as gen
+    scene_dir = gen.make_scene(str(tmp_path / "data" / "synth_scene"), n_frames=24, size=48)
+    monkeypatch.chdir(tmp_path)
+    train = _load(os.path.join(REPO, "trainer", "train_panopli_tensorf.py"), "clift_train_cli_m")
+    common = ["+experiment=contrastive_lift_MOS", f"dataset_root={scene_dir}", "image_dim=48", "min_grid_dim=24", "max_grid_dim=40", "steps_per_epoch=40",
+              "batch_size=1024", "chunk=0", "max_depth=3", "seed=5", "max_rays_instances=256", "late_semantic_optimization=1", "instance_optimization_epoch=1"]
+    monkeypatch.setenv("experiment", "midrun")
+    run = train.main(common + ["max_epoch=2", "save_every_n_train_steps=50"])
+    cks = sorted(os.listdir(os.path.join(run, "checkpoints")))
+    assert "epoch=1-step=50.ckpt" in cks and "epoch=1-step=80.ckpt" in cks
+    mid = torch.load(os.path.join(run, "checkpoints", "epoch=1-step=50.ckpt"), map_location="cpu", weights_only=False)
+    assert mid["epoch"] == 1 and mid["global_step"] == 50 and not mid["clift"]["epoch_complete"]
+    grid_mid = mid["state_dict"]["renderer.grid_dim"].tolist()
+    os.remove(os.path.join(run, "checkpoints", "epoch=1-step=80.ckpt"))
+    monkeypatch.delenv("experiment")
+    run2 = train.main(common + ["max_epoch=2", "save_every_n_train_steps=1000000", f"resume={os.path.join(run, 'checkpoints', 'epoch=1-step=50.ckpt')}"])
+    assert run2 == run
+    end = torch.load(os.path.join(run, "checkpoints", "epoch=1-step=80.ckpt"), map_location="cpu", weights_only=False)
+    assert end["global_step"] == 80 and end["epoch"] == 1 and end["clift"]["epoch_complete"]
+    assert end["state_dict"]["renderer.grid_dim"].tolist() == grid_mid             # epoch 1's shrink + upsample were not applied a second time
+    assert float(end["optimizer_states"][0]["state"][0]["step"]) == 40.0            # 10 steps before the checkpoint + 30 after it since epoch 1's rebuild
