@@ -915,7 +915,18 @@ def render_forward(model, renderer, rays, jitter, white_bg, want_rgb=True, want_
     sem_raw = fresh((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
     sem_map = torch.empty((N, Ccls), dtype=torch.float32, device=dev) if want_sem else None
     inst_map = fresh((N, D), dtype=torch.float32, device=dev) if D > 0 else None
-    if M > 0:
+    ctx.w_feat = None
+    if M > 0 and renderer.semantic_weight_mode == "argmax" and (want_sem or D > 0):
+        # renderer.py:142-143: the semantic / instance sums take the one-hot of each ray's heaviest sample (of ALL its samples: a heaviest
+        # sample below the threshold is not in the list and the ray's sums stay 0, as in the reference, whose heads are 0 there); the colours
+        # keep the weights -- two passes of the compositing kernels, one per weight array
+        ctx.w_feat = torch.zeros_like(ctx.w).scatter_(1, ctx.w.argmax(dim=1, keepdim=True), 1.0)
+        if want_rgb:
+            call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, 0, 0, ptr(ctx.rgb_s), None, None, ptr(ctx.ray_out), 0,
+                 ctx.white_bg, ptr(rgb_raw), ptr(rgb_map), None, None, None, st)
+        call("clift_composite_fwd", ptr(ctx.w_feat), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D, None, ptr(ctx.sem_s),
+             ptr(ctx.inst_s), ptr(ctx.ray_out), softmax_mode, 0, None, None, ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
+    elif M > 0:
         call("clift_composite_fwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, Ccls if want_sem else 0, D,
              ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.ray_out), softmax_mode, ctx.white_bg,
              ptr(rgb_raw), ptr(rgb_map), ptr(sem_raw), ptr(sem_map), ptr(inst_map), st)
@@ -973,19 +984,35 @@ def render_backward(model, ctx, gviews, g_rgb=None, g_sem=None, g_inst=None, g_d
             d_inst = torch.empty((M, ldp_inst), dtype=torch.float32, device=dev) if g_inst is not None else None
             d_inst_slow = (torch.empty((M, ldp_inst), dtype=torch.float32, device=dev)
                            if (g_inst is not None and model.slow_fast_mode and slow_grad) else None)
-            call("clift_composite_bwd_act", ptr(ctx.w), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
-                 ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
-                 ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge),
-                 2 if (model.render_semantic_mlp is not None and model.render_semantic_mlp.softmax) else 0, ptr(d_rgb), 4, ptr(d_sem), ldp_sem,
-                 ptr(d_inst), ptr(d_inst_slow), ldp_inst, E_inst, ptr(g_w), ptr(g_op), st)
+            sem_kind = 2 if (model.render_semantic_mlp is not None and model.render_semantic_mlp.softmax) else 0
+            if getattr(ctx, "w_feat", None) is not None:
+                # "argmax" weights (render_forward): the colours against the weights (with the weight / opacity gradients), then the semantic and
+                # instance rows against the one-hot array, which carries no gradient
+                call("clift_composite_bwd_act", ptr(ctx.w), ptr(ctx.act_idx), N, S, M, 0, 0, ptr(ctx.rgb_s), None, None, ptr(ctx.rgb_raw), None, 0,
+                     ctx.white_bg, 1, ptr(g_rgb), None, None, ptr(ge), 0, ptr(d_rgb), 4, None, 4, None, None, 4, 0, ptr(g_w), ptr(g_op), st)
+                call("clift_composite_bwd_act", ptr(ctx.w_feat), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D, None, ptr(ctx.sem_s),
+                     ptr(ctx.inst_s), None, ptr(ctx.sem_raw), ctx.softmax_mode, 0, 1, None, ptr(g_sem), ptr(g_inst), ptr(ge), sem_kind, None, 4,
+                     ptr(d_sem), ldp_sem, ptr(d_inst), ptr(d_inst_slow), ldp_inst, E_inst, None, None, st)
+            else:
+                call("clift_composite_bwd_act", ptr(ctx.w), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
+                     ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
+                     ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), sem_kind, ptr(d_rgb), 4, ptr(d_sem), ldp_sem,
+                     ptr(d_inst), ptr(d_inst_slow), ldp_inst, E_inst, ptr(g_w), ptr(g_op), st)
         else:
             d_rgb = torch.empty((M, 3), dtype=torch.float32, device=dev) if g_rgb is not None else None
             d_sem = torch.empty((M, Ccls), dtype=torch.float32, device=dev) if g_sem is not None else None
             d_inst = torch.empty((M, D), dtype=torch.float32, device=dev) if g_inst is not None else None
-            call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
-                 ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
-                 ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
-                 ptr(g_w), ptr(g_op), st)
+            if getattr(ctx, "w_feat", None) is not None:      # "argmax" weights: as above
+                call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, 0, 0, ptr(ctx.rgb_s), None, None,
+                     ptr(ctx.rgb_raw), None, 0, ctx.white_bg, 1, ptr(g_rgb), None, None, ptr(ge), ptr(d_rgb), None, None, ptr(g_w), ptr(g_op), st)
+                call("clift_composite_bwd", ptr(ctx.w_feat), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D, None,
+                     ptr(ctx.sem_s), ptr(ctx.inst_s), None, ptr(ctx.sem_raw), ctx.softmax_mode, 0, 1, None, ptr(g_sem), ptr(g_inst), ptr(ge), None,
+                     ptr(d_sem), ptr(d_inst), None, None, st)
+            else:
+                call("clift_composite_bwd", ptr(ctx.w), ptr(ctx.ray_start), ptr(ctx.act_idx), N, S, M, Ccls if want_sem else 0, D,
+                     ptr(ctx.rgb_s), ptr(ctx.sem_s), ptr(ctx.inst_s), ptr(ctx.rgb_raw), ptr(ctx.sem_raw), ctx.softmax_mode,
+                     ctx.white_bg, ctx.stop_grad, ptr(g_rgb), ptr(g_sem), ptr(g_inst), ptr(ge), ptr(d_rgb), ptr(d_sem), ptr(d_inst),
+                     ptr(g_w), ptr(g_op), st)
         br = Branches(model=model)
         if density_grad:
             model.xcd_workspace_for("density")

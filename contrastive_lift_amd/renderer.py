@@ -74,8 +74,7 @@ class TensoRFRenderer(nn.Module):
         self.register_buffer("grid_dim", torch.LongTensor(list(grid_dim)))
         self.register_buffer("inv_box_extent", torch.zeros([3]))
         self.register_buffer("units", torch.zeros([3]))
-        if semantic_weight_mode == "argmax":
-            raise NotImplementedError("clift: semantic_weight_mode='argmax' is not built (unused by shipped configs)")
+        # "softmax" (R:160) and "argmax" (R:142) are compared for; any other string renders as "none", as in the reference
         self.semantic_weight_mode = semantic_weight_mode
         self.parent_renderer_ref = parent_renderer_ref
         self.step_ratio = step_ratio

@@ -18,7 +18,7 @@ class RenderCfg:
     distance_scale: float = 25.0
     weight_thres: float = 1e-4
     density_shift: float = -10.0
-    semantic_weight_mode: str = "softmax"   # "softmax" | "none"
+    semantic_weight_mode: str = "softmax"   # "softmax" | "none" | "argmax"
     stop_semantic_grad: bool = True
     units: torch.Tensor = _dc_field(default=None)
     step_size: torch.Tensor = _dc_field(default=None)
@@ -135,7 +135,11 @@ def render_forward(P, rays, cfg, jitter=None, white_bg=False, explicit=False, re
         inst[act] = fld.instance_head(P, xa, explicit)
     opacity = w.sum(-1)
     rgb_map = (w[..., None] * rgb).sum(-2)
-    ws = w[..., None].detach() if cfg.stop_semantic_grad else w[..., None]
+    ws = w[..., None]
+    if cfg.semantic_weight_mode == "argmax":                                          # renderer.py:142-143: one-hot of the heaviest sample
+        ws = torch.nn.functional.one_hot(w.argmax(dim=1), num_classes=S).to(w.dtype)[..., None]
+    if cfg.stop_semantic_grad:
+        ws = ws.detach()
     sem_map = _softmax_log((ws * sem).sum(-2), cfg)
     inst_map = (ws * inst).sum(-2)
     if white_bg:

@@ -268,7 +268,7 @@ def _scene(seed, res, C, E, aabb, n_rays, shift=-3.0):
     return P, rays, rng
 
 
-def g6_forward():
+def g6_forward(modes=("softmax", "none"), fname="g6_forward"):
     res, C, E = (9, 13, 17), 4, 3
     aabb = torch.tensor([[-0.9, -0.7, -0.5], [0.8, 0.7, 0.6]])
     P, rays, rng = _scene(61, res, C, E, aabb, 96)
@@ -279,7 +279,7 @@ def g6_forward():
     out = dict(res=np.array(res), C=C, E=E, seed=61, shift=-3.0, aabb=aabb, rays=rays, jitter=jitter,
                cot_rgb=cot["rgb"], cot_sem=cot["sem"], cot_inst=cot["inst"])
     import model.renderer.panopli_tensoRF_renderer as RR
-    for mode in ("softmax", "none"):
+    for mode in modes:
         for white in (False, True):
             tag = f"{mode}_{'w' if white else 'b'}"
             m = build_reference_model(P, res, C, E, shift=-3.0, softmax=(mode == "softmax"))
@@ -300,7 +300,13 @@ def g6_forward():
             out.update({f"{tag}.rgb": rgb, f"{tag}.sem": sem, f"{tag}.inst": inst, f"{tag}.depth": depth,
                         f"{tag}.feats": feats, f"unpinned_{tag}.dist_reg": dreg})
             out.update(grad_digest(f"{tag}.g", {k: p.grad for k, p in m.named_parameters()}))
-    npz("g6_forward", **out)
+    npz(fname, **out)
+
+
+def g6a_forward_argmax():
+    """semantic_weight_mode "argmax" (R:142-143: the semantic / instance sums take the one-hot of each ray's heaviest sample; the colours keep
+    the weights).  Same scene, rays, jitter and cotangents as g6_forward."""
+    g6_forward(modes=("argmax",), fname="g6a_forward_argmax")
 
 
 def g7_instance_segment():
@@ -1219,6 +1225,7 @@ def main():
     g12_training_steps(mode="contrastive", fname="g12g_training_steps_grid_heads", steps=2, grids=True)
     g12gs()
     g21_epoch_boundary()
+    g6a_forward_argmax()
 
 
 def g12gs():

@@ -543,12 +543,12 @@ def _run_forward_backward(cl, m, r, rays, jitter, white, cots):
     return (rgb, sem, inst, depth, feats, dreg), {n: g for (n, _), g in zip(m.named_parameters(), grads)}
 
 
-@pytest.mark.parametrize("mode", ["softmax", "none"])
+@pytest.mark.parametrize("mode", ["softmax", "none", "argmax"])
 @pytest.mark.parametrize("white", [False, True])
 def test_forward_backward_golden_g6(mode, white):
-    """Against the reference's own outputs and gradients (tests/golden/g6_forward.npz)."""
+    """Against the reference's own outputs and gradients (tests/golden/g6_forward.npz; g6a_forward_argmax.npz for R:142-143's one-hot weights)."""
     cl, op, *_ = _import()
-    g = load_golden("g6_forward")
+    g = load_golden("g6a_forward_argmax" if mode == "argmax" else "g6_forward")
     res = tuple(int(x) for x in g["res"])
     C_, E = int(g["C"]), int(g["E"])
     P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
@@ -580,7 +580,7 @@ def test_forward_backward_golden_g6(mode, white):
     assert n >= 30
 
 
-@pytest.mark.parametrize("mode,white", [("softmax", False), ("none", True)])
+@pytest.mark.parametrize("mode,white", [("softmax", False), ("none", True), ("argmax", True)])
 def test_forward_backward_vs_oracle_mid(mode, white):
     """A larger anisotropic scene (grid 40x48x56, 900 rays, C=22) including the dist-reg gradient path."""
     cl, op, orender, ofld, olosses, orays = _import()

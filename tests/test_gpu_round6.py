@@ -316,3 +316,54 @@ def test_nottaconf_semantic_loss_mode():
         out.append((float(tr.losses[1]), m.param_flat.detach().clone()))
     assert out[0][0] == out[1][0] and out[0][0] > 0
     assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_argmax_semantic_weight_mode(fused, monkeypatch):
+    """semantic_weight_mode "argmax" (R:142-143): semantic and instance sums take the one-hot of each ray's heaviest sample, colours keep the
+    weights.  The golden (g6a) pins the small case in tests/test_gpu_parity.py; here 900 rays of the 40 x 48 x 56 scene against the oracle through
+    BOTH compositing backward forms (activations folded in / separate), and the no-gradient frame form (grad_heads=()) against the training form.
+    A ray whose two heaviest samples are within round-off of each other may pick either: such rays are left out (and counted)."""
+    import test_gpu_parity as tp
+    from conftest import grad_close
+    from contrastive_lift_amd import engine
+    cl, op, orender, ofld, olosses, orays = tp._import()
+    res, C_, E, n_rays = (40, 48, 56), 22, 3, 900
+    aabb = torch.tensor([[-0.9, -0.8, -0.7], [0.8, 0.9, 0.75]])
+    P, rays, rng = tp.scene(op, orays, 23, res, C_, E, n_rays, amp=2.2, sg=0.4)
+    jitter = torch.from_numpy(rng.uniform(0, 1, n_rays).astype(np.float32))
+    cots = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((n_rays, 3), (n_rays, C_), (n_rays, 2 * E))]
+    Pg = op.clone_params(P, requires_grad=True)
+    cfg = orender.RenderCfg(aabb, res, density_shift=-3.0, semantic_weight_mode="argmax")
+    o, aux = orender.render_forward(Pg, rays, cfg, jitter, True, return_aux=True)
+    top2 = aux["w"].detach().topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * top2[:, 0].clamp_min(1e-12)
+    assert int((~clear).sum()) <= 0.45 * n_rays          # (rays that miss the box have all-zero weights: no heaviest sample, sums 0 either way)
+    assert int((top2[:, 0] > cfg.weight_thres).sum()) > 200
+    for c in cots[1:]:
+        c[~clear] = 0
+    L = (o[0] * cots[0]).sum() + (o[1] * cots[1]).sum() + (o[2] * cots[2]).sum() + 3.0 * o[5]
+    L.backward()
+    monkeypatch.setattr(engine, "COMPOSITE_ACT_FUSED", fused)
+    m = tp.build_model(cl, P, res, C_, E, -3.0, "argmax")
+    r = cl.TensoRFRenderer(aabb, list(res), semantic_weight_mode="argmax").to(DEV)
+    outs, grads = tp._run_forward_backward(cl, m, r, rays, jitter, True, cots + [3.0])
+    rel_close(outs[0], o[0].detach(), 1e-3, what="rgb")
+    rel_close(outs[1].cpu()[clear], o[1].detach()[clear], 1e-3, what="sem")
+    rel_close(outs[2].cpu()[clear], o[2].detach()[clear], 1e-3, what="inst")
+    # the one-hot sums are single head outputs: a semantic row of a ray that hits something is one sample's logits, not a blend
+    hit = clear & (top2[:, 0] > cfg.weight_thres)
+    for k, gr in grads.items():
+        ref = Pg[k].grad
+        ref = torch.zeros_like(Pg[k]) if ref is None else ref
+        got = torch.zeros_like(ref) if gr is None else gr.detach().cpu()
+        grad_close(got, ref, what=f"grad {k}", rtol=2e-3, scale_atol=1e-4,
+                   outlier_frac=(5e-3 if k.split(".")[0].endswith(("_plane", "_line")) else 1e-2 if k.startswith("appearance_basis") else 1e-3),
+                   outlier_cap=1e-3)
+    assert float(Pg["render_semantic_mlp.mlp.2.weight"].grad.abs().max()) > 0
+    if fused:
+        with torch.no_grad():
+            frame, _ = engine.render_forward(m, r, rays.to(DEV), jitter.to(DEV), True, grad_heads=())
+        rel_close(frame["semantics"].cpu(), outs[1].detach().cpu(), 1e-5, what="frame semantics")
+        rel_close(frame["instances"].cpu(), outs[2].detach().cpu(), 1e-5, what="frame instances")
+        assert int(hit.sum()) > 200

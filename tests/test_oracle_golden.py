@@ -92,10 +92,10 @@ def _digest_check(g, prefix, grads, tol=1e-4, stride=17):
     return n
 
 
-@pytest.mark.parametrize("mode", ["softmax", "none"])
+@pytest.mark.parametrize("mode", ["softmax", "none", "argmax"])
 @pytest.mark.parametrize("white", [False, True])
 def test_g6_forward_and_grads(mode, white):
-    g = load_golden("g6_forward")
+    g = load_golden("g6a_forward_argmax" if mode == "argmax" else "g6_forward")
     res = tuple(int(x) for x in g["res"])
     C, E = int(g["C"]), int(g["E"])
     P = op.clone_params(op.add_blob(op.make_params(int(g["seed"]), res, C, E), res, 2.5, 0.45), requires_grad=True)
