@@ -449,18 +449,23 @@ int clift_dgrad_narrow_stream_launch(const GemmP& p, int half, hipStream_t st) {
 // ============================================================================ forward of a narrow output layer (+ row softmax)
 // out[m][0..no) = act( H[m][0..256) W^T + b ),  no <= 32 (22 semantic classes), act 0 = none, 2 = softmax over the row (tensoRF.py:591-594,37):
 // ONE read of the 256-wide hidden activation -- an HBM stream -- instead of the tiled 256 x 32 GEMM (which re-streams it at < half the
-// stream rate) followed by a row-activation launch over the logits.  Persistent blocks, 32-row tiles by LDS-DMA two tiles ahead (source-side
-// bank swizzle as in layer_f32.hip: 16-byte chunk c of row r sits in slot c ^ (r & 15)); wave w contracts k = 32 w .. +31 for all 32 rows x
-// 32 (padded) classes: weights first, so a lane owns one row -- 4 ds_read_b128 + 16 v_mfma_f32_32x32x2_f32 per tile and wave, its 16 weights in
-// registers; the eight k-slices meet through LDS (4 KB per wave), 16 threads per row add them in slice order + bias, fold max / sum of the
-// softmax with xor shuffles inside the 16 lanes (the association of clift_rows_act_fwd's tree) and store two classes each: a tile's outputs
-// are one contiguous run of 32 x no floats.  Two barriers per tile.
-constexpr int OF_ROWS = 32, OF_STAGE = OF_ROWS * 1024, OF_STAGES = 3, OF_PART = OF_STAGES * OF_STAGE;      // bytes
+// stream rate) followed by a row-activation launch over the logits.  Persistent blocks, 32-row tiles by LDS-DMA three tiles ahead (source-side
+// bank swizzle as in layer_f32.hip: 16-byte chunk c of row r sits in slot c ^ (r & 15)).
+// Round 6: PRODUCER waves 0 - 3 and CONSUMER waves 4 - 7 (waves w and w + 4 share a SIMD).  Producer w issues the DMA of 8 rows per tile and
+// contracts k = 64 w .. +63 for all 32 rows x 32 (padded) classes: weights first, so a lane owns one row -- 8 ds_read_b128 + 32
+// v_mfma_f32_32x32x2_f32 per tile, its 32 weights in registers -- and parks its slice (4 KB) in one of TWO areas.  The consumers reduce the tile
+// before: 8 threads per row add the four slices in slice order + bias, fold max / sum of the softmax over their 4 classes and with xor shuffles
+// over the 8 lanes, and store 4 classes each.  One barrier per tile.  Before (two barriers, every wave contracting a 32-wide slice and then
+// reducing, every wave in the same phase): 7100 cycles per tile for a 32 KB stream that needs ~4400; by ablation the MFMAs, the slice reads +
+// softmax, and the wait for the stores' acknowledgement (vmcnt is one in-order counter) each cost their full time, 20 - 28 % of the kernel
+// apiece (docs/history/round6.md).  Now the matrix pipe of a SIMD belongs to one wave (2048 cycles per tile), the reduce runs beside it on the
+// vector pipe, stores are the consumers' only vector-memory operations and nothing waits for them, and four stages keep 96 KB in flight.
+constexpr int OF_ROWS = 32, OF_STAGE = OF_ROWS * 1024, OF_STAGES = 4, OF_PART = OF_STAGES * OF_STAGE, OF_AREA = 4 * 4096;      // bytes
 
 __global__ __launch_bounds__(512, 2) void k_out_narrow_fwd(const float* __restrict__ H, int ldh, const float* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, int no, int M, int rows_per_block, float* __restrict__ out,
                                                            int ldo, int act) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[OF_PART + 8 * 4096];            // 128 KB, the only LDS object
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[OF_PART + 2 * OF_AREA];         // 160 KB, the only LDS object
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     if (rows_limited()) {
         M = limit_rows(M);
@@ -470,96 +475,124 @@ __global__ __launch_bounds__(512, 2) void k_out_narrow_fwd(const float* __restri
     if (rbeg >= rend) return;
     const int ntiles = (rend - rbeg + OF_ROWS - 1) / OF_ROWS;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    auto dma = [&](int t) {                             // this wave: rows 4 wave .. +3 of tile t, one 1 KB row per instruction
-        unsigned char* st = lds + (t % OF_STAGES) * OF_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 4 + i, gr = min(rbeg + t * OF_ROWS + row, rend - 1);
-            __builtin_amdgcn_global_load_lds(H + (size_t)gr * ldh + ((lane ^ (row & 15)) << 2), (lds_ptr_t)(st + row * 1024), 16, 0, 0);
-        }
-    };
-    // weights of class li, k = 32 wave + 8 j + 4 lh + i (classes past `no` read as zero)
-    f32x4 wv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (li < no) wv[j] = *reinterpret_cast<const f32x4*>(W + (size_t)li * ldw + 32 * wave + 8 * j + 4 * lh);
-    }
-    // reduce phase: thread (row rm, class pair 2 rg, 2 rg + 1)
-    const int rm = tid >> 4, rg = tid & 15, c0 = 2 * rg;
-    const float b0 = c0 < no ? bias[c0] : 0.f, b1 = c0 + 1 < no ? bias[c0 + 1] : 0.f;
-    const unsigned pread = lds0 + (unsigned)(OF_PART + ((c0 >> 3) * 64 + rm + 32 * ((c0 >> 2) & 1)) * 16 + (c0 & 3) * 4);
-    const unsigned pwrite = lds0 + (unsigned)(OF_PART + wave * 4096 + lane * 16);
-    const unsigned fbase = lds0 + (unsigned)(li * 1024);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the weight loads: from here on the only vector-memory loads in flight are the DMAs
 
-    for (int t = 0; t < OF_STAGES - 1 && t < ntiles; ++t) dma(t);
-    for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed when at most the younger tiles' DMAs (4 per tile) and this wave's output stores of earlier tiles are outstanding:
-        // stores are older than every DMA that may stay in flight, so counting the DMAs alone is exact
-        ns_wait_vm(4 * (min(t + OF_STAGES - 2, ntiles - 1) - t));
-        __builtin_amdgcn_s_barrier();                   // A: tile t visible to every wave; every wave is done with tile t - 1's partials and stage
-        asm volatile("" ::: "memory");
-        if (t + OF_STAGES - 1 < ntiles) dma(t + OF_STAGES - 1);
-        const unsigned sb = fbase + (unsigned)((t % OF_STAGES) * OF_STAGE);
-        f32x4 xb[4];
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producer
+        auto dma = [&](int t) {                         // rows 8 wave .. +7 of tile t, one 1 KB row per instruction
+            unsigned char* st = lds + (t % OF_STAGES) * OF_STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned a = sb + (unsigned)((((2 * (4 * wave + j) + lh) ^ (li & 15))) << 4);
-            asm volatile("ds_read_b128 %0, %1" : "=v"(xb[j]) : "v"(a) : "memory");
+            for (int i = 0; i < 8; ++i) {
+                const int row = wave * 8 + i, gr = min(rbeg + t * OF_ROWS + row, rend - 1);
+                __builtin_amdgcn_global_load_lds(H + (size_t)gr * ldh + ((lane ^ (row & 15)) << 2), (lds_ptr_t)(st + row * 1024), 16, 0, 0);
+            }
+        };
+        // weights of class li, k = 64 wave + 8 j + 4 lh + i (classes past `no` read as zero)
+        f32x4 wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (li < no) wv[j] = *reinterpret_cast<const f32x4*>(W + (size_t)li * ldw + 64 * wave + 8 * j + 4 * lh);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]) : : "memory");
-        f32x16 acc;
+        const unsigned fbase = lds0 + (unsigned)(li * 1024);
+        // the slice is parked with row li of class quad g = 2 q + lh in slot (li + 2 g) & 31 of the quad's 512 bytes: a consumer wave (8 rows x 8
+        // quads) then reads 16 different 16-byte slots in every 16 lanes
+        unsigned pw[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int q = 0; q < 4; ++q) pw[q] = lds0 + (unsigned)(OF_PART + wave * 4096 + q * 1024 + lh * 512 + ((li + 2 * (2 * q + lh)) & 31) * 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the weight loads: from here on this wave's only vector-memory operations are the DMAs
+        for (int t = 0; t < OF_STAGES - 1 && t < ntiles; ++t) dma(t);
+        for (int t = 0; t < ntiles; ++t) {
+            // tile t has landed when at most the younger tiles' DMAs (8 per tile, at most two tiles) are outstanding
+            const int younger = min(t + OF_STAGES - 2, ntiles - 1) - t;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // tile t visible to every producer; tile t - 1's stage is free; the consumers are done with area t & 1
+            asm volatile("" ::: "memory");
+            if (t + OF_STAGES - 1 < ntiles) dma(t + OF_STAGES - 1);      // into tile t - 1's stage
+            const unsigned sb = fbase + (unsigned)((t % OF_STAGES) * OF_STAGE);
+            f32x4 xb[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 8; ++j) {
+                const unsigned a = sb + (unsigned)((((2 * (8 * wave + j) + lh) ^ (li & 15))) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xb[j]) : "v"(a) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]), "+v"(xb[7]) : : "memory");
+            f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][i], xb[j][i], acc, 0, 0, 0);
-        // lane (li = row, lh) holds classes 8 q + 4 lh + e in acc[4 q + e]: park the slice.  The writes are inline asm, which the compiler's hazard
-        // recogniser does not look into: an LDS instruction that reads the destination of a 16-pass MFMA needs 18 wait states the hardware does
-        // NOT interlock (without them the slice leaves before the last MFMAs have landed -- seen as a few per cent error in every output)
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc) : : "memory");
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            if (q == 0) asm volatile("ds_write_b128 %0, %1" : : "v"(pwrite), "v"(v) : "memory");
-            if (q == 1) asm volatile("ds_write_b128 %0, %1 offset:1024" : : "v"(pwrite), "v"(v) : "memory");
-            if (q == 2) asm volatile("ds_write_b128 %0, %1 offset:2048" : : "v"(pwrite), "v"(v) : "memory");
-            if (q == 3) asm volatile("ds_write_b128 %0, %1 offset:3072" : : "v"(pwrite), "v"(v) : "memory");
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][i], xb[j][i], acc, 0, 0, 0);
+            // lane (li = row, lh) holds classes 8 q + 4 lh + e in acc[4 q + e]: park the slice.  The writes are inline asm, which the compiler's hazard
+            // recogniser does not look into: an LDS instruction that reads the destination of a 16-pass MFMA needs 18 wait states the hardware does
+            // NOT interlock (without them the slice leaves before the last MFMAs have landed -- seen as a few per cent error in every output)
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc) : : "memory");
+            const unsigned ao = (unsigned)((t & 1) * OF_AREA);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                asm volatile("ds_write_b128 %0, %1" : : "v"(pw[q] + ao), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                   // B: all eight slices parked
-        asm volatile("" ::: "memory");
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 s[8];
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) asm volatile("ds_read_b64 %0, %1" : "=v"(s[w8]) : "v"(pread + (unsigned)(w8 * 4096)) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : : "memory");
-        float x0 = s[0][0], x1 = s[0][1];
-#pragma unroll
-        for (int w8 = 1; w8 < 8; ++w8) { x0 += s[w8][0]; x1 += s[w8][1]; }
-        x0 += b0; x1 += b1;
-        const bool on0 = c0 < no, on1 = c0 + 1 < no;
-        if (act == 2) {
-            float mx = fmaxf(on0 ? x0 : -INFINITY, on1 ? x1 : -INFINITY);
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-            const float e0 = on0 ? expf(x0 - mx) : 0.f, e1 = on1 ? expf(x1 - mx) : 0.f;
-            float sum = e0 + e1;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d);
-            const float inv = 1.f / sum;
-            x0 = e0 * inv; x1 = e1 * inv;
-        }
-        const int m = rbeg + t * OF_ROWS + rm;
-        if (m < rend) {
-            float* o = out + (size_t)m * ldo + c0;
-            if (on0) o[0] = x0;
-            if (on1) o[1] = x1;
-        }
+        __builtin_amdgcn_s_barrier();                   // the last tile's slices are parked
+        return;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // -------------------------------------------------------------------- consumer: thread (row rm, class quad cg = classes 4 cg .. +3)
+    const int ct = tid - 256, rm = ct >> 3, cg = ct & 7, c0 = 4 * cg;
+    float bq[4];
+    bool on[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { on[e] = c0 + e < no; bq[e] = on[e] ? bias[c0 + e] : 0.f; }
+    const unsigned pread = lds0 + (unsigned)(OF_PART + (cg >> 1) * 1024 + (cg & 1) * 512 + ((rm + 2 * cg) & 31) * 16);
+    // The outputs leave as BUFFER stores through a descriptor cut to this block's rows: a lane without an output (class >= no, row past the end)
+    // gets an offset past the range and the hardware drops it -- no branches around the stores
+    const int nrows = __builtin_amdgcn_readfirstlane(rend - rbeg);
+    const unsigned long long oa = (unsigned long long)(uintptr_t)(out + (size_t)rbeg * ldo);
+    const unsigned oa_lo = __builtin_amdgcn_readfirstlane((unsigned)oa), oa_hi = __builtin_amdgcn_readfirstlane((unsigned)(oa >> 32));
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>((uintptr_t)(((unsigned long long)oa_hi << 32) | oa_lo)), 0,
+        (int)__builtin_amdgcn_readfirstlane((unsigned)((((size_t)(nrows - 1)) * ldo + no) * 4)), 0x00020000);
+    auto reduce = [&](int t) {
+        const unsigned pr = pread + (unsigned)((t & 1) * OF_AREA);
+        f32x4 s[4];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) asm volatile("ds_read_b128 %0, %1" : "=v"(s[w4]) : "v"(pr + (unsigned)(w4 * 4096)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]) : : "memory");
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ((s[0][e] + s[1][e]) + s[2][e]) + s[3][e] + bq[e];
+        if (act == 2) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, on[e] ? x[e] : -INFINITY);
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = on[e] ? expf(x[e] - mx) : 0.f; sum += x[e]; }
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) sum += __shfl_xor(sum, d);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] *= inv;
+        }
+        const int lr = t * OF_ROWS + rm;                // row within the block's range
+        const int off = (lr * ldo + c0) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[e]), rs_o, (lr < nrows && on[e]) ? off + 4 * e : -1, 0, 0);
+    };
+    for (int t = 0; t < ntiles; ++t) {
+        __builtin_amdgcn_s_barrier();                   // tile t - 1's slices are parked (area (t - 1) & 1)
+        asm volatile("" ::: "memory");
+        if (t > 0) reduce(t - 1);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    reduce(ntiles - 1);
 }
 
 extern "C" int clift_out_layer_fwd(const float* H, int ldh, const float* W, int ldw, const float* b, int no, int M, float* out, int ldo, int act,
