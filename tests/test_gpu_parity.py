@@ -953,7 +953,8 @@ def test_psnr_parity_over_a_training_trajectory():
 
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
-                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads"])
+                                     "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads",
+                                     "g12a_training_steps_argmax"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
@@ -968,6 +969,7 @@ def test_g12_reference_training_steps_on_gpu(fixture):
     mode = str(g["mode"]) if "mode" in g else "slow_fast"
     sf = mode == "slow_fast"
     grids = "grid_heads" in fixture                # sixth fixture: both heads on their own VM grids (the allgrid overlay), plain contrastive loss
+    wmode = str(g["weight_mode"]) if "weight_mode" in g else "softmax"      # seventh fixture: semantic_weight_mode "argmax" (R:142-143)
     P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E, slow_fast=sf, sem_grid=grids, inst_grid=grids), res, 2.5, 0.45)
     if grids:
         m = cl.TensorVMSplit(list(res), num_semantics_comps=(32, 32, 32), num_instance_comps=(32, 32, 32), num_semantic_classes=C_,
@@ -976,9 +978,9 @@ def test_g12_reference_training_steps_on_gpu(fixture):
         missing, unexpected = m.load_state_dict({k: v.to(DEV) for k, v in P.items()}, strict=True)
         assert not missing and not unexpected
     else:
-        m = build_model(cl, P, res, C_, E, float(g["shift"]), slow_fast=sf)
-    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
-    cfg = default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
+        m = build_model(cl, P, res, C_, E, float(g["shift"]), mode=wmode, slow_fast=sf)
+    r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode=wmode).to(DEV)
+    cfg = default_config(chunk=int(g["chunk"]), semantic_weight_mode=wmode, late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
                          use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False, max_instances=E)
     if "sce" in g and float(g["sce"][1]) != 0.0:          # fourth fixture: config.use_symmetric_ce (SCELoss, T:74-77)
         cfg.use_symmetric_ce, cfg.ce_alpha, cfg.ce_beta = True, float(g["sce"][0]), float(g["sce"][1])

@@ -234,7 +234,7 @@ def test_g11_metrics_vs_reference():
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
                                      "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads",
-                                     "g12gs_training_steps_grid_heads_slow_fast"])
+                                     "g12gs_training_steps_grid_heads_slow_fast", "g12a_training_steps_argmax"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -248,7 +248,8 @@ def test_g12_three_reference_training_steps(fixture):
     mode = str(g["mode"]) if "mode" in g else "slow_fast"
     grids = "grid_heads" in fixture               # sixth fixture: both heads on VM grids (the allgrid overlay)
     P = op.add_blob(op.make_params(int(g["seed"]), res, C, E, slow_fast=(mode == "slow_fast"), sem_grid=grids, inst_grid=grids), res, 2.5, 0.45)
-    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]))
+    cfg = orender.RenderCfg(T(g["aabb"]), res, density_shift=float(g["shift"]),
+                            semantic_weight_mode=str(g["weight_mode"]) if "weight_mode" in g else "softmax")      # eighth fixture: "argmax" (R:142-143)
     tr = CpuTrainer(P, cfg, chunk=int(g["chunk"]), epoch=int(g["epoch"]), class_weights=T(g["class_weights"]), late_semantic_optimization=1,
                     instance_optimization_epoch=3,
                     instance_loss_mode=mode, use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False,
