@@ -165,8 +165,6 @@ class HotPathTrainer:
                                             ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
                                             ("use_proj", False), ("use_feature_regularization", False))
                        if getattr(config, k, v) != v]
-        if getattr(config, "probabilistic_ce_mode", "TTAConf") not in ("TTAConf", "NoTTAConf"):
-            unsupported.append(("probabilistic_ce_mode", "TTAConf / NoTTAConf"))
         if unsupported:
             raise NotImplementedError("HotPathTrainer: config options outside the contrastive-lift hot path: " +
                                       ", ".join(f"{k}={getattr(config, k)!r} (only {v!r} is built)" for k, v in unsupported))
@@ -515,20 +513,24 @@ class HotPathTrainer:
         maskf = mask.to(torch.float32) if mask is not None else None        # T:156-158 (masked pixels contribute nothing)
         self.losses.zero_()
         # T:177-182: "TTAConf" = soft targets x confidences; "NoTTAConf" = the label map as the target (class indices = one-hot rows for the
-        # same kernel) x confidences
+        # same kernel) x confidences; any other string = the label map as the target, NO confidences -- and since the mask reaches the
+        # semantic term only through the zeroed confidences (T:158), masked pixels count in that form
         ce_mode = getattr(c, "probabilistic_ce_mode", "TTAConf")
-        if ce_mode == "NoTTAConf":
+        rgb_k, gt_k, conf_k, mask_k = rgb, batch["rgbs"], batch["confidences"], maskf
+        if ce_mode != "TTAConf":
             batch = dict(batch)
             batch["probabilities"] = torch.nn.functional.one_hot(batch["semantics"].long(), sem.shape[1]).to(torch.float32)
-        elif ce_mode != "TTAConf":       # (the unweighted form also counts masked pixels, T:182: not built)
-            raise NotImplementedError(f"HotPathTrainer: probabilistic_ce_mode={ce_mode!r} (TTAConf and NoTTAConf are built)")
+            if ce_mode != "NoTTAConf":
+                conf_k, mask_k = None, None
+                if maskf is not None:       # T:156-157 by hand (both sides zeroed: a masked pixel's colour gradient is 0 either way)
+                    rgb_k, gt_k = rgb * maskf[:, None], batch["rgbs"] * maskf[:, None]
         if getattr(c, "use_symmetric_ce", False):       # T:74-77: SCELoss(ce_alpha, ce_beta, weights) replaces the cross entropy
-            _lib.call("clift_pixel_losses_sce", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
-                      _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
+            _lib.call("clift_pixel_losses_sce", _lib.ptr(rgb_k), _lib.ptr(gt_k), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
+                      _lib.ptr(conf_k), _lib.ptr(self.class_weights), _lib.ptr(mask_k), B, sem.shape[1], w_rgb, w_sem,
                       float(c.ce_alpha), float(c.ce_beta), _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
         else:
-            _lib.call("clift_pixel_losses", _lib.ptr(rgb), _lib.ptr(batch["rgbs"]), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
-                      _lib.ptr(batch["confidences"]), _lib.ptr(self.class_weights), _lib.ptr(maskf), B, sem.shape[1], w_rgb, w_sem,
+            _lib.call("clift_pixel_losses", _lib.ptr(rgb_k), _lib.ptr(gt_k), _lib.ptr(sem), _lib.ptr(batch["probabilities"]),
+                      _lib.ptr(conf_k), _lib.ptr(self.class_weights), _lib.ptr(mask_k), B, sem.shape[1], w_rgb, w_sem,
                       _lib.ptr(self.losses), _lib.ptr(g_rgb), _lib.ptr(g_sem), _lib.stream())
         gd = w_rgb * self.current_lambda_dist_reg / len(ctxs)
         if getattr(self, "_g_dist", (None, None))[0] != gd:          # (a device scalar that changes once per epoch: kept instead of refilled every step)

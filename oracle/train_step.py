@@ -84,7 +84,7 @@ class CpuTrainer:
         for s_ in self.scheds:
             s_.step()
 
-    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None, segments=None):
+    def main_pass(self, rays, rgbs, probs, conf, jitter, white_flags, mask=None, segments=None, ce_mode="TTAConf", semantics=None):
         """``segments`` = dict(rays, group, conf, jitter, n_groups): the segment-consistency term of T:185-197 (active from
         segment_optimization_epoch on in the shipped configs)."""
         self.opt_main.zero_grad(set_to_none=True)
@@ -99,6 +99,10 @@ class CpuTrainer:
         if mask is not None:                      # T:156-158: masked pixels contribute neither colour nor semantics
             keep = mask.to(rgb.dtype)
             rgb, rgbs, conf = rgb * keep[:, None], rgbs * keep[:, None], conf * keep
+        if ce_mode != "TTAConf":                  # T:179-182: the label map is the target (a one-hot row for the same row formula) ...
+            probs = torch.nn.functional.one_hot(semantics.long(), sem.shape[1]).to(sem.dtype)
+            if ce_mode != "NoTTAConf":            # ... and without the confidences every pixel counts, the masked ones too (the mask only zeroes confs, T:158)
+                conf = torch.ones_like(conf)
         dreg = torch.stack([o[5] for o in outs]).mean()
         l_rgb = torch.nn.functional.mse_loss(rgb, rgbs)
         l_tv = olosses.total_tv(self.P, self.l_tvd, self.l_tva, self.l_tvs, self.l_tvi, self.sem_on, self.inst_on)

@@ -471,7 +471,7 @@ def g11_metrics():
 
 
 def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_steps", steps=3, segments=False, sce=None, E=3, n_ids=4, grids=False,
-                       weight_mode="softmax"):
+                       weight_mode="softmax", ce_mode="TTAConf"):
     """Three full ``training_step``s of the REFERENCE trainer class -- TensoRFTrainer.configure_optimizers (T:98-103),
     .forward / .forward_instance (T:105-133), .training_step (T:148-228), .calculate_instance_clustering_loss + EMA
     (T:230-329) -- called unbound on a shim that supplies only what Lightning would (optimizers(), manual_backward, log,
@@ -494,7 +494,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
         use_distilled_features_semantic=False, use_distilled_features_instance=False, feature_optimization_end_epoch=0,
         late_semantic_optimization=1, instance_optimization_epoch=3, segment_optimization_epoch=(2 if segments else 100),
         segment_grouping_mode=("argmax_conf" if segments else "none"), batch_size_segments=6, chunk_segment=50,
-        probabilistic_ce_mode="TTAConf", use_proj=False, max_instances=E)
+        probabilistic_ce_mode=ce_mode, use_proj=False, max_instances=E)
     m = build_reference_model(P, res, C, E, shift=-3.0, softmax=(weight_mode == "softmax"), slow_fast=(mode == "slow_fast"), sem_mlp=not grids,
                               inst_mlp=not grids)                                          # (T:54: Identity output unless the mode is "softmax")
     rr = build_reference_renderer(aabb, res, weight_mode)
@@ -553,7 +553,7 @@ def g12_training_steps(mode="slow_fast", use_delta=False, fname="g12_training_st
                for g in o.param_groups] for o in sh._opts]
 
     out = dict(res=np.array(res), C=C, E=E, seed=121, shift=-3.0, aabb=aabb, B=B, Bi=Bi, steps=steps, epoch=epoch, chunk=cfg.chunk,
-               mode=np.array(mode), weight_mode=np.array(weight_mode), use_delta=int(use_delta), sce=np.array(sce if sce is not None else [0.0, 0.0], np.float64),
+               mode=np.array(mode), weight_mode=np.array(weight_mode), ce_mode=np.array(ce_mode), use_delta=int(use_delta), sce=np.array(sce if sce is not None else [0.0, 0.0], np.float64),
                class_weights=cw, lambda_dist=np.float64(sh.current_lambda_dist_reg),
                opt_groups=np.array([[g[0], g[1], g[2][0], g[2][1], g[3]] for o in groups for g in o], np.float64),
                opt_group_counts=np.array([len(o) for o in groups]))
@@ -1229,11 +1229,19 @@ def main():
     g21_epoch_boundary()
     g6a_forward_argmax()
     g12a()
+    g12p()
 
 
 def g12a():
     """semantic_weight_mode "argmax" through two training_step()s (R:142-143 inside T:148-228; the semantic MLP ends in Identity, T:54)."""
     g12_training_steps(fname="g12a_training_steps_argmax", steps=2, weight_mode="argmax")
+
+
+def g12p():
+    """probabilistic_ce_mode (T:177-182): "NoTTAConf" = the label map as the target x confidences; any other string ("NoConf" here) = the label map,
+    no confidences -- masked pixels count in that form (the mask reaches the semantic term only through the zeroed confidences, T:158)."""
+    g12_training_steps(fname="g12n_training_steps_nottaconf", steps=2, ce_mode="NoTTAConf")
+    g12_training_steps(fname="g12p_training_steps_noconf", steps=2, ce_mode="NoConf")
 
 
 def g12gs():

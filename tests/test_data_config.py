@@ -254,7 +254,8 @@ def test_trainer_rejects_unbuilt_config_variants():
     HotPathTrainer(m, r, default_config())                                   # the shipped settings construct fine
     HotPathTrainer(m, r, default_config(use_symmetric_ce=True))             # SCELoss is built (round 2)
     HotPathTrainer(m, r, default_config(probabilistic_ce_mode="NoTTAConf"))  # the label map as the target (round 6)
-    for k, v in (("probabilistic_ce_mode", "NoConf"), ("optimize_instance_only", True)):
+    HotPathTrainer(m, r, default_config(probabilistic_ce_mode="NoConf"))     # any other string: label map, no confidences (T:181-182; golden G12p)
+    for k, v in (("optimize_instance_only", True),):
         with pytest.raises(NotImplementedError):
             HotPathTrainer(m, r, default_config(**{k: v}))
 

@@ -954,7 +954,7 @@ def test_psnr_parity_over_a_training_trajectory():
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
                                      "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads",
-                                     "g12a_training_steps_argmax"])
+                                     "g12a_training_steps_argmax", "g12n_training_steps_nottaconf", "g12p_training_steps_noconf"])
 def test_g12_reference_training_steps_on_gpu(fixture):
     """The product trainer (HIP kernels, arena Adam) replays the three training_step()s recorded from the REFERENCE trainer
     class (golden G12: chunked forwards with chunk = 40, masked pixels, recorded jitter / white-background draws, slow-fast
@@ -980,7 +980,7 @@ def test_g12_reference_training_steps_on_gpu(fixture):
     else:
         m = build_model(cl, P, res, C_, E, float(g["shift"]), mode=wmode, slow_fast=sf)
     r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode=wmode).to(DEV)
-    cfg = default_config(chunk=int(g["chunk"]), semantic_weight_mode=wmode, late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
+    cfg = default_config(chunk=int(g["chunk"]), semantic_weight_mode=wmode, probabilistic_ce_mode=str(g["ce_mode"]) if "ce_mode" in g else "TTAConf", late_semantic_optimization=1, instance_optimization_epoch=3, instance_loss_mode=mode,
                          use_delta=bool(int(g["use_delta"])) if "use_delta" in g else False, max_instances=E)
     if "sce" in g and float(g["sce"][1]) != 0.0:          # fourth fixture: config.use_symmetric_ce (SCELoss, T:74-77)
         cfg.use_symmetric_ce, cfg.ce_alpha, cfg.ce_beta = True, float(g["sce"][0]), float(g["sce"][1])
@@ -991,7 +991,7 @@ def test_g12_reference_training_steps_on_gpu(fixture):
         white = [bool(x) for x in g[f"s{st}.white"]]
         assert len(set(white)) == 1          # the recorded coin flips of one step happen to agree: one flag per main pass
         batch0 = dict(rays=d(g[f"s{st}.rays"]), rgbs=d(g[f"s{st}.rgbs"]), probabilities=d(g[f"s{st}.probs"]),
-                      confidences=d(g[f"s{st}.confs"]), mask=d(g[f"s{st}.mask"]))
+                      confidences=d(g[f"s{st}.confs"]), mask=d(g[f"s{st}.mask"]), semantics=d(g[f"s{st}.probs"]).argmax(-1))
         seg, sjit = None, None
         if f"s{st}.srays" in g:          # third fixture: the segment-consistency term (batch[2], T:185-197)
             seg = dict(rays=d(g[f"s{st}.srays"]), group=d(g[f"s{st}.sgroup"]), confidences=d(g[f"s{st}.sconf"]), n_groups=6)

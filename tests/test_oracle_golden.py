@@ -234,7 +234,8 @@ def test_g11_metrics_vs_reference():
 
 @pytest.mark.parametrize("fixture", ["g12_training_steps", "g12c_training_steps_contrastive", "g12s_training_steps_segments",
                                      "g12e_training_steps_sce", "g12l_training_steps_linear_assignment", "g12g_training_steps_grid_heads",
-                                     "g12gs_training_steps_grid_heads_slow_fast", "g12a_training_steps_argmax"])
+                                     "g12gs_training_steps_grid_heads_slow_fast", "g12a_training_steps_argmax",
+                                     "g12n_training_steps_nottaconf", "g12p_training_steps_noconf"])
 def test_g12_three_reference_training_steps(fixture):
     """The oracle's CpuTrainer replays three training_step()s of the REFERENCE TensoRFTrainer (optimizer groups, chunked
     forwards, masked MSE + TV + confidence-weighted CE + ramped dist-reg, Adam; EMA -> slow-fast loss -> Adam on the fast
@@ -276,8 +277,10 @@ def test_g12_three_reference_training_steps(fixture):
         if f"s{st}.srays" in g:          # third fixture: the segment-consistency term of T:185-197 (batch[2])
             seg = dict(rays=T(g[f"s{st}.srays"]), group=torch.from_numpy(g[f"s{st}.sgroup"]), conf=T(g[f"s{st}.sconf"]),
                        jitter=T(g[f"s{st}.sjitter"]), n_groups=6)
+        ce_mode = str(g["ce_mode"]) if "ce_mode" in g else "TTAConf"          # ninth / tenth fixtures: probabilistic_ce_mode NoTTAConf / NoConf (T:177-182)
         o = tr.main_pass(T(g[f"s{st}.rays"]), T(g[f"s{st}.rgbs"]), T(g[f"s{st}.probs"]), T(g[f"s{st}.confs"]), T(g[f"s{st}.jitter"]),
-                         [bool(x) for x in g[f"s{st}.white"]], mask=torch.from_numpy(g[f"s{st}.mask"]), segments=seg)
+                         [bool(x) for x in g[f"s{st}.white"]], mask=torch.from_numpy(g[f"s{st}.mask"]), segments=seg, ce_mode=ce_mode,
+                         semantics=T(g[f"s{st}.probs"]).argmax(-1))           # (the generator's label map: batch[0]["semantics"] = probs.argmax(-1))
         if seg is not None:
             rel_close(o["loss_segment"], g[f"s{st}.loss_segment"], 1e-4, what=f"step {st} loss_segment")
         rel_close(o["loss_rgb"], g[f"s{st}.loss_rgb"], 1e-4, what=f"step {st} loss_rgb")
