@@ -161,8 +161,7 @@ class HotPathTrainer:
     def __init__(self, model, renderer, config, class_weights=None, current_epoch=0, white_bg=False):
         self.model, self.renderer, self.config = model, renderer, config
         # config variants of the reference that this trainer does not implement fail loudly instead of being ignored
-        unsupported = [(k, v) for k, v in (("optimize_instance_only", False),
-                                            ("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
+        unsupported = [(k, v) for k, v in (("use_distilled_features_semantic", False), ("use_distilled_features_instance", False),
                                             ("use_proj", False), ("use_feature_regularization", False))
                        if getattr(config, k, v) != v]
         if unsupported:
@@ -675,7 +674,8 @@ class HotPathTrainer:
                                self.current_epoch >= self.config.segment_optimization_epoch) else None
         if lean is None:
             lean = bool(getattr(self.config, "skip_discarded_instance_heads", False))
-        self.main_pass(batch[0], lean=lean, segments=seg)
+        if not getattr(self.config, "optimize_instance_only", False):          # T:151: only the instance branch is optimised when set
+            self.main_pass(batch[0], lean=lean, segments=seg)
         if self.current_epoch >= self.config.instance_optimization_epoch and batch.get(1):
             self.instance_pass(batch[1])
 

@@ -255,7 +255,8 @@ def test_trainer_rejects_unbuilt_config_variants():
     HotPathTrainer(m, r, default_config(use_symmetric_ce=True))             # SCELoss is built (round 2)
     HotPathTrainer(m, r, default_config(probabilistic_ce_mode="NoTTAConf"))  # the label map as the target (round 6)
     HotPathTrainer(m, r, default_config(probabilistic_ce_mode="NoConf"))     # any other string: label map, no confidences (T:181-182; golden G12p)
-    for k, v in (("optimize_instance_only", True),):
+    HotPathTrainer(m, r, default_config(optimize_instance_only=True))        # T:151: the main pass is skipped
+    for k, v in (("use_proj", True), ("use_distilled_features_semantic", True)):
         with pytest.raises(NotImplementedError):
             HotPathTrainer(m, r, default_config(**{k: v}))
 

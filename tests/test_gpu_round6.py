@@ -369,3 +369,41 @@ def test_argmax_semantic_weight_mode(fused, monkeypatch):
         rel_close(frame["semantics"].cpu(), outs[1].detach().cpu(), 1e-5, what="frame semantics")
         rel_close(frame["instances"].cpu(), outs[2].detach().cpu(), 1e-5, what="frame instances")
         assert int(hit.sum()) > 200
+
+
+def test_optimize_instance_only_skips_the_main_pass():
+    """optimize_instance_only (T:151): training_step leaves everything the main optimizer owns untouched (bit for bit, Adam moments included) and
+    moves the instance branch exactly as the instance pass alone does."""
+    import contrastive_lift_amd as cl
+    from oracle import params as op
+    from contrastive_lift_amd.trainer import HotPathTrainer, default_config
+    from test_gpu_parity import build_model
+    g = load_golden("g12_training_steps")
+    res = tuple(int(x) for x in g["res"])
+    C_, E = int(g["C"]), int(g["E"])
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    batch = {0: dict(rays=d(g["s0.rays"]), rgbs=d(g["s0.rgbs"]), probabilities=d(g["s0.probs"]), confidences=d(g["s0.confs"]), mask=d(g["s0.mask"]),
+                     semantics=d(g["s0.probs"]).argmax(-1)),
+             1: [dict(rays=d(g["s0.irays"]), instances=d(g["s0.labels"]), confidences=d(g["s0.iconf"]))]}
+    res_ = []
+    for only in (True, False):
+        P = op.add_blob(op.make_params(int(g["seed"]), res, C_, E), res, 2.5, 0.45)
+        m = build_model(cl, P, res, C_, E, float(g["shift"]))
+        r = cl.TensoRFRenderer(T(g["aabb"]), list(res), semantic_weight_mode="softmax").to(DEV)
+        tr = HotPathTrainer(m, r, default_config(chunk=int(g["chunk"]), late_semantic_optimization=1, instance_optimization_epoch=3, max_instances=E,
+                                                 optimize_instance_only=only, host_rng=True), class_weights=T(g["class_weights"]), current_epoch=4)
+        before = m.param_flat.detach().clone()
+        torch.manual_seed(5)
+        if only:
+            tr.training_step(batch)
+        else:
+            tr.instance_pass(batch[1])
+        torch.cuda.synchronize()
+        res_.append((before, m.param_flat.detach().clone(), tr.opt_main.m.detach().clone(), dict(tr.opt_main.t)))
+    (b0, a0, m0, t0), (b1, a1, m1, t1) = res_
+    assert torch.equal(b0, b1)
+    moved = (a0 != b0)
+    lo, hi = min(m.arena.groups[k][0] for k in ("inst_fast", "inst_slow")), max(m.arena.groups[k][1] for k in ("inst_fast", "inst_slow"))
+    assert int(moved[:lo].sum()) == 0 and int(moved[hi:].sum()) == 0 and int(moved[lo:hi].sum()) > 0      # only the instance branch moved
+    assert float(m0.abs().max()) == 0.0 and all(v == 0 for v in t0.values())                               # the main Adam never stepped
+    assert float((a0 - a1).abs().max()) <= 1e-6                                                            # ... and it moved as the instance pass alone moves it
